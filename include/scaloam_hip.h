@@ -1,0 +1,219 @@
+/*
+ * scaloam_hip.h — C-ABI of libscaloam_hip.so: the MI355X (gfx950) implementation of SC-A-LOAM's
+ * data-parallel hot path.  The reference (swoonge/SC-A-LOAM) has no plugin/FFI interface: its stages
+ * are welded into ROS node main()s.  Each entry point below is therefore a *call-site cut*: it replaces
+ * the cited lines of the reference, and INTEGRATION.md shows the few lines a maintainer changes in each
+ * node to call it.  Plain C: opaque handles, raw pointers and sizes, int status codes; nothing throws
+ * or aborts across this boundary.
+ *
+ * Conventions
+ *  - Every context owns one HIP stream, its device buffers and pinned staging.  All arrays passed in or
+ *    out are caller-owned and only need to stay valid for the duration of the call.  `_device` variants
+ *    take pointers into GPU memory of the context's device instead of host memory.
+ *  - Points are `PointXYZI` as the reference uses them (include/aloam_velodyne/common.h:43):
+ *    4 packed floats x,y,z,intensity (16 B) on the host side.  On the device everything is SoA.
+ *  - A context is single-caller (like the reference's node threads) except the ScanContext context,
+ *    which serialises insert/detect internally (the reference calls them from two threads with no
+ *    common lock: laserPosegraphOptimization.cpp:633-642 vs :718).
+ *  - Status: 0 ok, <0 SCAL_E_*; scal_last_error() gives a message for the calling thread.
+ */
+#ifndef SCALOAM_HIP_H
+#define SCALOAM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+enum {
+    SCAL_OK = 0,
+    SCAL_E_ARG = -1,          /* bad argument */
+    SCAL_E_LIDAR_TYPE = -2,   /* unknown lidar_type (reference: ROS_BREAK, scanRegistration.cpp:214-218) */
+    SCAL_E_SCAN_LINE = -3,    /* scan_line not 16/32/64 (reference exits, scanRegistration.cpp:486-490) */
+    SCAL_E_TOO_MANY = -4,     /* more points than max_points (reference scratch is 400000, scanRegistration.cpp:68-71) */
+    SCAL_E_EMPTY = -5,        /* no point survives the NaN / range filters (reference would read points[0]) */
+    SCAL_E_HIP = -6,          /* HIP runtime error */
+    SCAL_E_NO_DEVICE = -7,    /* no gfx950 device / code object missing: the product never falls back to a CPU path */
+    SCAL_E_CAPACITY = -8,     /* a device-side capacity was exceeded (segment longer than the LDS sort, map pool full) */
+    SCAL_E_STATE = -9         /* call order violated (e.g. fetch before run) */
+};
+const char* scal_last_error(void);
+/* number of visible HIP devices, -1 if the runtime cannot initialise */
+int scal_device_count(void);
+const char* scal_version(void);
+
+/* ------------------------------------------------------------------ stage A: feature extraction
+ * Replaces laserCloudHandler, src/scanRegistration.cpp:134-421 (NaN/range filter, ring id + relative
+ * time, ring-major reorder, curvature, per-(ring,sixth) sort + greedy sharp/lessSharp/flat picks,
+ * lessFlat + per-ring 0.2 m voxel grid).  The five output clouds are what the node publishes at :426-454. */
+enum { SCAL_VLP16 = 0, SCAL_HDL32 = 1, SCAL_HDL64 = 2, SCAL_OS1_64 = 3 };
+
+typedef struct {
+    int lidar_type;        /* SCAL_*  (rosparam lidar_type, scanRegistration.cpp:481) */
+    int n_scans;           /* rosparam scan_line (:480) */
+    double minimum_range;  /* rosparam minimum_range (:482) */
+    int max_points;        /* capacity; <= 400000 */
+    int float_math;        /* 0: atan/sqrt of :168 promote to double (the pinned GCC 5 toolchain); 1: float overloads */
+    int check_finite;      /* 1: drop non-finite points (pcl::removeNaNFromPointCloud on a non-dense cloud, :138) */
+    int device;            /* HIP device ordinal */
+} scal_features_config;
+
+typedef struct {
+    /* caller-owned host arrays; capacities in points unless noted; NULL = not wanted */
+    float* cloud;      /* [max_points][4] ordered cloud, intensity = scanID + 0.1*relTime (/velodyne_cloud_2) */
+    int* src_index;    /* [max_points] input index of every ordered point */
+    float* curvature;  /* [max_points] cloudCurvature */
+    int* label;        /* [max_points] cloudLabel */
+    int* ring_start;   /* [n_scans] scanStartInd */
+    int* ring_end;     /* [n_scans] scanEndInd */
+    int* sharp;        /* [2*6*n_scans]  indices into `cloud`, reference emission order */
+    int* less_sharp;   /* [20*6*n_scans] */
+    int* flat;         /* [4*6*n_scans] */
+    float* less_flat;  /* [max_points][4] downsampled lessFlat cloud */
+    /* filled by the call */
+    int n_kept, n_sharp, n_less_sharp, n_flat, n_less_flat;
+    int n_tied_segments; /* segments whose sort met equal curvatures (std::sort order is unspecified there) */
+} scal_features_out;
+
+typedef struct scal_features scal_features_t;
+int scal_features_create(const scal_features_config* cfg, scal_features_t** ctx);
+void scal_features_destroy(scal_features_t* ctx);
+/* host input: xyz at xyz + i*stride_bytes (PointCloud2 layout). Synchronous. */
+int scal_features_run(scal_features_t* ctx, const void* xyz, int n, int stride_bytes, scal_features_out* out);
+/* device input (float*, stride in floats), asynchronous on the context's stream; results stay on the GPU
+ * for scal_odom_step_features / scal_map_step_features / scal_sc_insert_features. */
+int scal_features_run_device(scal_features_t* ctx, const float* d_xyz, int n, int stride_floats);
+/* wait for the last run and copy results to the host */
+int scal_features_fetch(scal_features_t* ctx, scal_features_out* out);
+int scal_features_sync(scal_features_t* ctx);
+
+/* ------------------------------------------------------------------ voxel grid
+ * Replaces pcl::VoxelGrid<PointXYZI>::filter at scanRegistration.cpp:414-418,
+ * laserMapping.cpp:543-551, :793-801 and laserPosegraphOptimization.cpp:629-631. */
+typedef struct scal_voxel scal_voxel_t;
+int scal_voxel_create(int max_points, int device, scal_voxel_t** ctx);
+void scal_voxel_destroy(scal_voxel_t* ctx);
+int scal_voxel_downsample(scal_voxel_t* ctx, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out);
+
+/* ------------------------------------------------------------------ stage D: ScanContext
+ * Replaces SCManager (include/scancontext/Scancontext.h:57-123, Scancontext.cpp), call sites
+ * laserPosegraphOptimization.cpp:639 (insert) and :718 (detect). */
+typedef struct {
+    double max_radius;  /* PC_MAX_RADIUS, setMaximumRadius (Scancontext.cpp:267-270) */
+    double dist_thres;  /* SC_DIST_THRES, setSCdistThres (:262-265) */
+    int max_keyframes;  /* database capacity on this device */
+    int float_math;     /* atan overload at Scancontext.cpp:26-35, as in scal_features_config */
+    int device;
+    /* sharding (multi-GPU): this context stores keyframes i with i % n_shards == shard; 1/0 = everything */
+    int n_shards, shard;
+} scal_sc_config;
+
+typedef struct {
+    int loop_id;      /* -1: no loop (Scancontext.cpp:338, :406-408) */
+    float yaw_rad;    /* deg2rad(shift * 6 deg) (:422) */
+    double min_dist;  /* best SC distance among the candidates */
+    int nn_idx;       /* its keyframe index */
+    int nn_shift;     /* its column shift */
+    int cand_idx[3];  /* ring-key KNN candidates, ascending key distance */
+    float cand_keydist[3];
+    double cand_scdist[3];
+    int cand_shift[3];
+} scal_sc_result;
+
+typedef struct scal_sc scal_sc_t;
+int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** ctx);
+void scal_sc_destroy(scal_sc_t* ctx);
+int scal_sc_size(scal_sc_t* ctx);
+/* makeAndSaveScancontextAndKeys(cloud) — cloud already downsampled by the caller as the reference does */
+int scal_sc_insert_cloud(scal_sc_t* ctx, const float* xyzi, int n);
+int scal_sc_insert_cloud_device(scal_sc_t* ctx, const float* d_x, const float* d_y, const float* d_z, const int* d_n, int n_max);
+/* saveScancontextAndKeys(desc): 20x60 doubles, column-major */
+int scal_sc_insert_descriptor(scal_sc_t* ctx, const double* desc_colmajor);
+int scal_sc_get_descriptor(scal_sc_t* ctx, int idx, double* desc_colmajor, float* ringkey20);
+/* makeScancontext only (no insert) */
+int scal_sc_make_descriptor(scal_sc_t* ctx, const float* xyzi, int n, double* desc_colmajor);
+/* detectLoopClosureID(): query = newest keyframe; reproduces the >=31 gate, the 30-query tree period,
+ * the exclusion of the newest 30 keys and the 3-candidate / 7-shift search (Scancontext.cpp:336-427). */
+int scal_sc_detect(scal_sc_t* ctx, scal_sc_result* res);
+/* distanceBtnScanContext for descriptor pairs already in the database */
+int scal_sc_distance_pairs(scal_sc_t* ctx, const int* idx_a, const int* idx_b, int n_pairs, double* dist, int* shift);
+/* dense mode: all 60 shifts for queries [q0,q1) x database [d0,d1): min over shifts; mode 0 = the
+ * reference's 7-shift search around the sector-key alignment, 1 = exhaustive 60 shifts. */
+int scal_sc_distance_matrix(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift);
+/* sharded search pieces (one context per GPU): local top-3 for the newest GLOBAL key, then a merge of the
+ * gathered per-shard records (the all-gather itself is the caller's: RCCL via torch.distributed). */
+typedef struct {
+    float key_dist;
+    int idx; /* global keyframe index, -1 = empty */
+    double sc_dist;
+    int shift;
+    int pad;
+} scal_sc_cand;
+int scal_sc_shard_query(scal_sc_t* ctx, const double* query_desc_colmajor, int global_size_at_rebuild, scal_sc_cand out[3]);
+int scal_sc_merge_candidates(const scal_sc_cand* gathered, int n_records, double dist_thres, scal_sc_result* res);
+
+/* ------------------------------------------------------------------ stage C: scan-to-map
+ * Replaces process(), src/laserMapping.cpp:310-802 and :845-849. */
+typedef struct {
+    float line_res, plane_res; /* rosparams mapping_line_resolution / mapping_plane_resolution (:915-916) */
+    int max_scan_points;       /* capacity of one full-resolution scan */
+    int max_map_points;        /* capacity of the rolling 21x21x11 cube window, per feature class */
+    int device;
+} scal_map_config;
+
+typedef struct {
+    int n_corner_stack, n_surf_stack, n_corner_map, n_surf_map;
+    int n_edge[2], n_plane[2];      /* residual blocks per outer iteration (:563) */
+    int lm_iters[2], lm_success[2]; /* LM iterations / accepted steps per outer iteration */
+    double cost_init[2], cost_final[2];
+    int solved;                     /* 0: map too small (:555, :731-734), pose = prior */
+    int n_map_corner_total, n_map_surf_total;
+} scal_map_stats;
+
+typedef struct scal_map scal_map_t;
+int scal_map_create(const scal_map_config* cfg, scal_map_t** ctx);
+void scal_map_destroy(scal_map_t* ctx);
+/* one process() pass.  corner_last / surf_last / full_res: PointXYZI host arrays (full_res may be NULL).
+ * q_wodom (x,y,z,w), t_wodom: /laser_odom_to_init pose.  Outputs: q_w_curr, t_w_curr (/aft_mapped_to_init),
+ * registered (full_res transformed, :845-849; may be NULL). */
+int scal_map_step(scal_map_t* ctx, const float* corner_last, int n_corner, const float* surf_last, int n_surf,
+                  const float* full_res, int n_full, const double* q_wodom, const double* t_wodom, double* q_w_curr,
+                  double* t_w_curr, float* registered, scal_map_stats* stats);
+/* same, inputs taken from a features context on the same device (lessSharp / lessFlat / ordered cloud) */
+int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom,
+                           double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
+/* current map points of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap content); returns count */
+int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
+int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);
+
+/* ------------------------------------------------------------------ stage B: scan-to-scan odometry
+ * Replaces the main loop body of src/laserOdometry.cpp:267-291, :299-506, :554-568. */
+typedef struct {
+    int max_points; /* capacity of the lessFlat cloud */
+    int device;
+} scal_odom_config;
+typedef struct {
+    int n_edge[2], n_plane[2];
+    int lm_iters[2], lm_success[2];
+    double cost_init[2], cost_final[2];
+} scal_odom_stats;
+typedef struct scal_odom scal_odom_t;
+int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** ctx);
+void scal_odom_destroy(scal_odom_t* ctx);
+int scal_odom_step(scal_odom_t* ctx, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp,
+                   const float* flat, int n_flat, const float* less_flat, int n_less_flat, double* q_last_curr,
+                   double* t_last_curr, double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
+int scal_odom_step_features(scal_odom_t* ctx, scal_features_t* feat, double* q_last_curr, double* t_last_curr,
+                            double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
+
+/* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
+ * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,
+ * for a host that keeps ceres::Problem orchestration.  kind: 0 LidarEdgeFactor(a,b),
+ * 1 LidarPlaneFactor(j, unit normal), 2 LidarPlaneNormFactor(n, d in pb[0]).  Arrays are [n][3] doubles. */
+int scal_factors_eval(int device, int n, const int* kind, const double* cp, const double* pa, const double* pb,
+                      const double* x7 /* qx qy qz qw tx ty tz */, double* cost, double* gradient6, double* hessian6x6);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCALOAM_HIP_H */

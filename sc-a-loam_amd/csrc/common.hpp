@@ -1,0 +1,96 @@
+// Host-side plumbing shared by every stage of libscaloam_hip.so: error reporting, RAII device/pinned buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+#include "../../include/scaloam_hip.h"
+
+namespace scal {
+
+void set_error(const char* fmt, ...);
+
+#define SCAL_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            ::scal::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SCAL_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define SCAL_TRY(expr)           \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != SCAL_OK) return _rc; \
+    } while (0)
+
+// selects the device and verifies it is a gfx950 part: the product path must fail loudly otherwise
+int select_device(int device);
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            p = nullptr;
+            return SCAL_E_HIP;
+        }
+        n = count;
+        return SCAL_OK;
+    }
+    int zero(hipStream_t s) {
+        hipError_t e = hipMemsetAsync(p, 0, n * sizeof(T), s);
+        if (e != hipSuccess) {
+            set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+            return SCAL_E_HIP;
+        }
+        return SCAL_OK;
+    }
+};
+
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    int alloc(size_t count) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        if (count == 0) count = 1;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&p), count * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+            p = nullptr;
+            return SCAL_E_HIP;
+        }
+        n = count;
+        return SCAL_OK;
+    }
+};
+
+inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace scal

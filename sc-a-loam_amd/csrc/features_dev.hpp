@@ -1,0 +1,34 @@
+// Device-resident results of stage A, shared with the stages that consume them without a host round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct scal_features;
+
+namespace scal {
+
+struct FeatParams {
+    float start_ori, end_ori;
+    int first_idx, last_idx, flip_idx, empty, error, n_tied;
+    int n_kept;
+    int ring_count[64];
+    int ring_off[65];
+    int scan_start[64], scan_end[64];
+    int n_sharp, n_less_sharp, n_flat, n_less_flat;
+    int lf_ring_cnt[64];
+    int lf_ring_off[65];
+};
+
+struct FeatDeviceView {
+    const FeatParams* P;                 // counts live on the device
+    const float *x, *y, *z, *i;          // ordered cloud, SoA, P->n_kept points
+    const float *lfx, *lfy, *lfz, *lfi;  // lessFlat cloud, SoA, P->n_less_flat points
+    const float *sharp_xyzi, *less_xyzi, *flat_xyzi;  // picked points, AoS xyzi
+    int cap;
+    hipStream_t stream;
+    int device;
+    int n_scans;
+};
+
+FeatDeviceView features_view(scal_features* c);
+
+}  // namespace scal

@@ -1,0 +1,750 @@
+// Stage D on gfx950: ScanContext descriptor construction, ring-key top-3 and column-shift cosine distance.
+// Replaces SCManager, /root/reference/include/scancontext/Scancontext.cpp (:151-195 makeScancontext, :198-227 keys,
+// :69-148 distances, :336-427 detectLoopClosureID); call sites laserPosegraphOptimization.cpp:639, :718.
+//
+// Database layout in HBM (one slot per keyframe, slot = global index / n_shards):
+//   desc   [cap][1200] f64, column-major 20x60 exactly as Eigen stores it (9.6 KB per keyframe)
+//   rkey   [cap][20]   f32 ring key (row means cast to float, Scancontext.cpp:62-66) — what the kd-tree indexes
+//   skey   [cap][60]   f64 sector key (column means)
+//   cnorm  [cap][60]   f64 column norms (hoisted out of distDirectSC, :78-81)
+// Kernels: k_sc_make (one workgroup per scan: LDS atomic-max polar binning on an order-preserving integer image
+// of the f32 height, then keys/norms), k_sc_topk (brute-force ring-key distances in nanoflann's f32 accumulation
+// order, per-block top-3), k_sc_detect (merge top-3, one wave per candidate runs the sector-key alignment and the
+// 7-shift cosine distance), k_sc_pairs / k_sc_matrix (batched distances).
+// All reductions that the reference does through Eigen follow Eigen 3.3's SSE2 order: four interleaved partial
+// sums, (s0+s2)+(s1+s3) — see oracle/scancontext.cpp.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include <cmath>
+#include <cfloat>
+
+namespace scal {
+
+constexpr int NR = 20, NS = 60, DESC = NR * NS;
+
+struct SCRec {  // per-candidate record produced on the device
+    float key_dist;
+    int idx;
+    double sc_dist;
+    int shift;
+    int pad;
+};
+
+// Eigen redux order for sizes divisible by 4: lanes j = i mod 4 summed sequentially, (s0+s2)+(s1+s3)
+template <class F>
+__device__ __forceinline__ double eigen_sum4(int size, F at) {
+    double s0 = at(0), s1 = at(1), s2 = at(2), s3 = at(3);
+    for (int i = 4; i < size; i += 4) {
+        s0 += at(i), s1 += at(i + 1);
+        s2 += at(i + 2), s3 += at(i + 3);
+    }
+    return (s0 + s2) + (s1 + s3);
+}
+
+// xy2theta, Scancontext.cpp:23-36 (float in, float out)
+__device__ __forceinline__ float xy2theta(float x, float y, int float_math) {
+    auto at = [&](float v) -> double {
+        const double a = atan(static_cast<double>(v));
+        return float_math ? static_cast<double>(static_cast<float>(a)) : a;
+    };
+    if ((x >= 0) & (y >= 0)) return static_cast<float>((180 / M_PI) * at(y / x));
+    if ((x < 0) & (y >= 0)) return static_cast<float>(180 - ((180 / M_PI) * at(y / (-x))));
+    if ((x < 0) & (y < 0)) return static_cast<float>(180 + ((180 / M_PI) * at(y / x)));
+    if ((x >= 0) & (y < 0)) return static_cast<float>(360 - ((180 / M_PI) * at((-y) / x)));
+    return NAN;
+}
+
+__device__ __forceinline__ int ceil_to_int(double v) {  // int(ceil(v)); NaN -> INT_MIN like cvttsd2si
+    const double c = ceil(v);
+    if (!(c == c)) return INT_MIN;
+    if (c >= 2147483648.0 || c < -2147483648.0) return INT_MIN;
+    return static_cast<int>(c);
+}
+
+// points may be AoS xyzi (stride 4, y=z=null) or SoA
+__global__ void __launch_bounds__(1024) k_sc_make(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
+                                                  int stride, const int* __restrict__ d_n, int n_host, double max_radius, int float_math,
+                                                  double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
+                                                  double* __restrict__ cnorm) {
+    __shared__ unsigned cell[DESC];
+    __shared__ double d[DESC];
+    const int n = d_n ? *d_n : n_host;
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x) cell[i] = 0u;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        float x, y, z;
+        if (py) {
+            x = px[k], y = py[k], z = pz[k];
+        } else {
+            x = px[(size_t)k * stride], y = px[(size_t)k * stride + 1], z = px[(size_t)k * stride + 2];
+        }
+        const float zz = static_cast<float>(static_cast<double>(z) + 2.0);  // LIDAR_HEIGHT (Scancontext.h:83, cpp:168)
+        const float azim_range = sqrtf(x * x + y * y);                      // :171
+        const float azim_angle = xy2theta(x, y, float_math);                // :172
+        if (static_cast<double>(azim_range) > max_radius) continue;         // :175
+        if (zz != zz) continue;                                             // desc < NaN is false
+        const int ring_idx = max(min(NR, ceil_to_int((static_cast<double>(azim_range) / max_radius) * NR)), 1);    // :178
+        const int sctor_idx = max(min(NS, ceil_to_int((static_cast<double>(azim_angle) / 360.0) * NS)), 1);        // :179
+        atomicMax(&cell[(ring_idx - 1) + NR * (sctor_idx - 1)], float_to_ordered(zz));                             // :182-183
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
+        double v = 0.0;  // empty cell: -1000 -> 0 (:187-190)
+        if (cell[i] != 0u) {
+            const float f = ordered_to_float(cell[i]);
+            if (static_cast<double>(f) > -1000.0) v = static_cast<double>(f);
+        }
+        d[i] = v;
+        desc[i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NR) {  // makeRingkeyFromScancontext (:198-211) + eig2stdvec cast (:62-66)
+        const int r = threadIdx.x;
+        const double m = eigen_sum4(NS, [&](int c) { return d[r + NR * c]; }) / NS;
+        rkey[r] = static_cast<float>(m);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) {  // makeSectorkeyFromScancontext (:214-227), column norms
+        const int c = threadIdx.x - 64;
+        skey[c] = eigen_sum4(NR, [&](int r) { return d[r + NR * c]; }) / NR;
+        cnorm[c] = sqrt(eigen_sum4(NR, [&](int r) { return d[r + NR * c] * d[r + NR * c]; }));
+    }
+}
+
+// keys / norms of a descriptor supplied by the caller (saveScancontextAndKeys, :236-246)
+__global__ void __launch_bounds__(128) k_sc_keys(const double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
+                                                 double* __restrict__ cnorm) {
+    if (threadIdx.x < NR) {
+        const int r = threadIdx.x;
+        rkey[r] = static_cast<float>(eigen_sum4(NS, [&](int c) { return desc[r + NR * c]; }) / NS);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) {
+        const int c = threadIdx.x - 64;
+        skey[c] = eigen_sum4(NR, [&](int r) { return desc[r + NR * c]; }) / NR;
+        cnorm[c] = sqrt(eigen_sum4(NR, [&](int r) { return desc[r + NR * c] * desc[r + NR * c]; }));
+    }
+}
+
+// nanoflann L2_Adaptor<float>::evalMetric (nanoflann.hpp:383-408): five groups of four, f32
+__device__ __forceinline__ float key_dist(const float* __restrict__ a, const float* __restrict__ b) {
+    float result = 0.f;
+#pragma unroll
+    for (int g = 0; g < NR; g += 4) {
+        const float d0 = a[g] - b[g], d1 = a[g + 1] - b[g + 1], d2 = a[g + 2] - b[g + 2], d3 = a[g + 3] - b[g + 3];
+        result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    return result;
+}
+
+// block-wide three smallest of one u64 key per thread (key = dist bits << 32 | index); smem: 16 u64
+__device__ __forceinline__ void block_top3(unsigned long long mine, unsigned long long* out3, unsigned long long* smem) {
+    const int nw = blockDim.x >> 6;
+    for (int round = 0; round < 3; ++round) {
+        unsigned long long m = wave_min_u64(mine);
+        if (lane_id() == 0) smem[wave_id()] = m;
+        __syncthreads();
+        unsigned long long best = smem[0];
+        for (int q = 1; q < nw; ++q) best = smem[q] < best ? smem[q] : best;
+        __syncthreads();
+        out3[round] = best;
+        if (mine == best) mine = ~0ull;
+    }
+}
+
+// local slot s holds global keyframe index s * n_shards + shard
+__global__ void __launch_bounds__(256) k_sc_topk(const float* __restrict__ rkey, const float* __restrict__ query, int n_local, int n_shards,
+                                                 int shard, int global_limit, unsigned long long* __restrict__ block_best) {
+    __shared__ unsigned long long smem[16];
+    __shared__ float q[NR];
+    if (threadIdx.x < NR) q[threadIdx.x] = query[threadIdx.x];
+    __syncthreads();
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine = ~0ull;
+    if (s < n_local) {
+        const int g = s * n_shards + shard;
+        if (g < global_limit) {
+            const float d = key_dist(q, rkey + (size_t)s * NR);
+            if (d == d) mine = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(g);
+        }
+    }
+    unsigned long long best[3];
+    block_top3(mine, best, smem);
+    if (threadIdx.x == 0) {
+        block_best[blockIdx.x * 3 + 0] = best[0];
+        block_best[blockIdx.x * 3 + 1] = best[1];
+        block_best[blockIdx.x * 3 + 2] = best[2];
+    }
+}
+
+// distanceBtnScanContext (:116-148) for one pair, executed by ONE wave.  scratch: 7*60 doubles of LDS per wave.
+__device__ __forceinline__ void wave_pair_distance(const double* __restrict__ d1, const double* __restrict__ n1, const double* __restrict__ v1,
+                                                   const double* __restrict__ d2, const double* __restrict__ n2, const double* __restrict__ v2,
+                                                   double* scratch, double* out_dist, int* out_shift) {
+    const int lane = lane_id();
+    // fastAlignUsingVkey (:93-113): Frobenius norm of vkey1 - circshift(vkey2, s); first strict minimum
+    double nrm = 1e300;
+    if (lane < NS) {
+        const int s = lane;
+        nrm = sqrt(eigen_sum4(NS, [&](int j) {
+            const double df = v1[j] - v2[(j - s + NS) % NS];
+            return df * df;
+        }));
+        if (!(nrm == nrm)) nrm = 1e300;
+    }
+    double best = nrm;
+    int bs = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o, 64);
+        const int os = __shfl_xor(bs, o, 64);
+        if (ob < best || (ob == best && os < bs)) best = ob, bs = os;
+    }
+    const int argmin_vkey_shift = (best < 10000000) ? bs : 0;
+    // SEARCH_RADIUS = round(0.5 * 0.1 * 60) = 3 (:123): shifts a, a+-1, a+-2, a+-3 mod 60, sorted ascending (:124-130)
+    int sh[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sh[k] = (argmin_vkey_shift + (k - 3) + NS) % NS;
+#pragma unroll
+    for (int a = 1; a < 7; ++a) {  // insertion sort of 7 ints
+        const int v = sh[a];
+        int b = a - 1;
+        while (b >= 0 && sh[b] > v) {
+            sh[b + 1] = sh[b];
+            --b;
+        }
+        sh[b + 1] = v;
+    }
+    // distDirectSC (:69-90) on (sc1, circshift(sc2, s)): shifted.col(j) = sc2.col((j - s) mod 60)
+    if (lane < NS) {
+        const int col = lane;
+        const double na = n1[col];
+        for (int k = 0; k < 7; ++k) {
+            const int c2 = (col - sh[k] + NS) % NS;
+            const double nb = n2[c2];
+            double sim = NAN;  // NaN marks "skipped"
+            if (!((na == 0) | (nb == 0))) {
+                const double* a = d1 + NR * col;
+                const double* b = d2 + NR * c2;
+                sim = eigen_sum4(NR, [&](int i) { return a[i] * b[i]; }) / (na * nb);
+                if (!(sim == sim)) sim = INFINITY;  // keep a genuine NaN distinguishable from "skipped": poisons the sum below
+            }
+            scratch[k * NS + col] = sim;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    double dist = 1e300;
+    if (lane < 7) {
+        double sum = 0;
+        int eff = 0;
+        for (int c = 0; c < NS; ++c) {
+            const double s = scratch[lane * NS + c];
+            if (s == s) {
+                sum = sum + (isinf(s) ? NAN : s);
+                eff = eff + 1;
+            }
+        }
+        dist = 1.0 - sum / eff;  // eff == 0 -> NaN, never selected (:139)
+    }
+    // first strict minimum in ascending shift order, starting from 10000000 (:133-144)
+    double bd = 10000000;
+    int bshift = 0;
+    for (int k = 0; k < 7; ++k) {
+        const double dk = __shfl(dist, k, 64);
+        if (dk < bd) bd = dk, bshift = sh[k];
+    }
+    *out_dist = bd;
+    *out_shift = bshift;
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct SCDb {
+    const double* desc;
+    const float* rkey;
+    const double* skey;
+    const double* cnorm;
+};
+
+// one block of 256 threads: merge per-block top-3, then waves 0..2 evaluate the three candidates (:385-400)
+__global__ void __launch_bounds__(256) k_sc_detect(const unsigned long long* __restrict__ block_best, int n_blocks, SCDb db, int n_shards,
+                                                   int shard, const double* __restrict__ qdesc, const double* __restrict__ qskey,
+                                                   const double* __restrict__ qnorm, int fill_missing_with_zero, SCRec* __restrict__ out) {
+    __shared__ unsigned long long smem[16];
+    __shared__ unsigned long long top[3];
+    __shared__ double scratch[3][7 * NS];
+    unsigned long long mine = ~0ull;
+    unsigned long long second = ~0ull, third = ~0ull;
+    // each thread scans a strided share of the candidates and keeps its own three smallest
+    for (int i = threadIdx.x; i < n_blocks * 3; i += blockDim.x) {
+        unsigned long long v = block_best[i];
+        if (v < mine) {
+            third = second, second = mine, mine = v;
+        } else if (v < second) {
+            third = second, second = v;
+        } else if (v < third) {
+            third = v;
+        }
+    }
+    // three rounds of block argmin over each thread's current head
+    for (int round = 0; round < 3; ++round) {
+        unsigned long long m = wave_min_u64(mine);
+        if (lane_id() == 0) smem[wave_id()] = m;
+        __syncthreads();
+        unsigned long long best = smem[0];
+        for (int q = 1; q < 4; ++q) best = smem[q] < best ? smem[q] : best;
+        if (threadIdx.x == 0) top[round] = best;
+        __syncthreads();
+        if (mine == best && best != ~0ull) mine = second, second = third, third = ~0ull;
+    }
+    __syncthreads();
+    const int w = wave_id();
+    if (w < 3) {
+        const unsigned long long t = top[w];
+        SCRec r;
+        r.key_dist = FLT_MAX, r.idx = -1, r.sc_dist = 10000000, r.shift = 0, r.pad = 0;
+        int g = -1;
+        if (t != ~0ull) {
+            g = static_cast<int>(t & 0xffffffffu);
+            r.key_dist = __uint_as_float(static_cast<unsigned>(t >> 32));
+        } else if (fill_missing_with_zero && shard == 0) {
+            g = 0;  // unused KNN slots keep the caller's zero-initialised index (Scancontext.cpp:372, nanoflann.hpp:193-198)
+        }
+        if (g >= 0) {
+            const int s = g / n_shards;
+            double dist;
+            int shift;
+            wave_pair_distance(qdesc, qnorm, qskey, db.desc + (size_t)s * DESC, db.cnorm + (size_t)s * NS, db.skey + (size_t)s * NS, scratch[w],
+                               &dist, &shift);
+            r.idx = g, r.sc_dist = dist, r.shift = shift;
+        }
+        if (lane_id() == 0) out[w] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sc_pairs(SCDb db, const int* __restrict__ ia, const int* __restrict__ ib, int n_pairs,
+                                                  double* __restrict__ dist, int* __restrict__ shift) {
+    __shared__ double scratch[4][7 * NS];
+    const int w = wave_id();
+    const int p = blockIdx.x * 4 + w;
+    if (p >= n_pairs) return;
+    const int a = ia[p], b = ib[p];
+    double d;
+    int s;
+    wave_pair_distance(db.desc + (size_t)a * DESC, db.cnorm + (size_t)a * NS, db.skey + (size_t)a * NS, db.desc + (size_t)b * DESC,
+                       db.cnorm + (size_t)b * NS, db.skey + (size_t)b * NS, scratch[w], &d, &s);
+    if (lane_id() == 0) dist[p] = d, shift[p] = s;
+}
+
+// dense block of the pair grid, one wave per (query, database) pair.
+// mode 0: the reference's 7-shift search; mode 1: exhaustive over all 60 shifts (first strict minimum).
+__global__ void __launch_bounds__(256) k_sc_matrix(SCDb db, int q0, int nq, int d0, int nd, int mode, double* __restrict__ dist,
+                                                   int* __restrict__ shift) {
+    __shared__ double scratch[4][7 * NS];
+    const int w = wave_id(), lane = lane_id();
+    const long long p = static_cast<long long>(blockIdx.x) * 4 + w;
+    if (p >= static_cast<long long>(nq) * nd) return;
+    const int a = q0 + static_cast<int>(p / nd), b = d0 + static_cast<int>(p % nd);
+    const double* d1 = db.desc + (size_t)a * DESC;
+    const double* d2 = db.desc + (size_t)b * DESC;
+    const double* n1 = db.cnorm + (size_t)a * NS;
+    const double* n2 = db.cnorm + (size_t)b * NS;
+    double bd;
+    int bs;
+    if (mode == 0) {
+        wave_pair_distance(d1, n1, db.skey + (size_t)a * NS, d2, n2, db.skey + (size_t)b * NS, scratch[w], &bd, &bs);
+    } else {
+        // lane = shift: sequential sum over columns exactly as distDirectSC does
+        double dd = 1e300;
+        if (lane < NS) {
+            const int s = lane;
+            double sum = 0;
+            int eff = 0;
+            for (int col = 0; col < NS; ++col) {
+                const int c2 = (col - s + NS) % NS;
+                const double na = n1[col], nb = n2[c2];
+                if ((na == 0) | (nb == 0)) continue;
+                const double* x = d1 + NR * col;
+                const double* y = d2 + NR * c2;
+                sum = sum + eigen_sum4(NR, [&](int i) { return x[i] * y[i]; }) / (na * nb);
+                eff = eff + 1;
+            }
+            dd = 1.0 - sum / eff;
+            if (!(dd == dd)) dd = 1e300;
+        }
+        bd = dd, bs = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ob = __shfl_xor(bd, o, 64);
+            const int os = __shfl_xor(bs, o, 64);
+            if (ob < bd || (ob == bd && os < bs)) bd = ob, bs = os;
+        }
+        if (!(bd < 10000000)) bd = 10000000, bs = 0;
+    }
+    if (lane == 0) dist[p] = bd, shift[p] = bs;
+}
+
+}  // namespace scal
+
+using namespace scal;
+
+struct scal_sc {
+    scal_sc_config cfg;
+    hipStream_t stream = nullptr;
+    std::mutex mu;  // insert and detect come from two threads in the reference with no common lock
+    int cap = 0;
+    int n_global = 0;  // keyframes inserted (global count)
+    int n_local = 0;   // slots used on this shard
+    int tree_making_period_conter = 0;
+    int size_at_rebuild = 0;
+    DevBuf<double> desc, skey, cnorm;
+    DevBuf<float> rkey;
+    // query staging (newest keyframe may live on another shard)
+    DevBuf<double> qdesc, qskey, qnorm;
+    DevBuf<float> qrkey;
+    DevBuf<float> pts;
+    int pts_cap = 0;
+    DevBuf<unsigned long long> block_best;
+    DevBuf<SCRec> d_rec;
+    PinBuf<SCRec> h_rec;
+    DevBuf<int> d_pairs;
+    DevBuf<double> d_dist;
+    DevBuf<int> d_shift;
+    size_t pair_cap = 0;
+    SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
+    bool owns(int g) const { return cfg.n_shards <= 1 || (g % cfg.n_shards) == cfg.shard; }
+};
+
+extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
+    if (!cfg || !out || cfg->max_keyframes <= 0 || !(cfg->max_radius > 0)) {
+        set_error("scal_sc_create: bad argument");
+        return SCAL_E_ARG;
+    }
+    *out = nullptr;
+    SCAL_TRY(select_device(cfg->device));
+    auto* c = new scal_sc();
+    c->cfg = *cfg;
+    if (c->cfg.n_shards < 1) c->cfg.n_shards = 1, c->cfg.shard = 0;
+    if (c->cfg.shard < 0 || c->cfg.shard >= c->cfg.n_shards) {
+        delete c;
+        set_error("shard %d out of range for %d shards", cfg->shard, cfg->n_shards);
+        return SCAL_E_ARG;
+    }
+    c->cap = cfg->max_keyframes;
+    int rc = SCAL_OK;
+    auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
+    A(c->desc.alloc((size_t)c->cap * DESC));
+    A(c->skey.alloc((size_t)c->cap * NS));
+    A(c->cnorm.alloc((size_t)c->cap * NS));
+    A(c->rkey.alloc((size_t)c->cap * NR));
+    A(c->qdesc.alloc(DESC)); A(c->qskey.alloc(NS)); A(c->qnorm.alloc(NS)); A(c->qrkey.alloc(NR));
+    A(c->block_best.alloc((size_t)3 * div_up(c->cap, 256) + 3));
+    A(c->d_rec.alloc(4));
+    A(c->h_rec.alloc(4));
+    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        rc = SCAL_E_HIP;
+    }
+    if (rc != SCAL_OK) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return SCAL_OK;
+}
+
+extern "C" void scal_sc_destroy(scal_sc_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+extern "C" int scal_sc_size(scal_sc_t* c) {
+    if (!c) return SCAL_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->n_global;
+}
+
+// build the descriptor of a cloud into the query staging slot; when this shard owns the new global index, also
+// into its database slot
+static int make_into(scal_sc* c, const float* px, const float* py, const float* pz, int stride, const int* d_n, int n_host, bool insert) {
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(k_sc_make, dim3(1), dim3(1024), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->qdesc.p,
+                       c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_HIP(hipGetLastError());
+    if (insert) {
+        const int g = c->n_global;
+        if (c->owns(g)) {
+            if (c->n_local >= c->cap) {
+                set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
+                return SCAL_E_CAPACITY;
+            }
+            const size_t sl = c->n_local;
+            SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+            SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+            SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+            SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
+            c->n_local++;
+        }
+        c->n_global++;
+    }
+    return SCAL_OK;
+}
+
+static int upload_points(scal_sc* c, const float* xyzi, int n) {
+    if (n > c->pts_cap) {
+        const int nc = std::max(n, 65536);
+        SCAL_TRY(c->pts.alloc((size_t)nc * 4));
+        c->pts_cap = nc;
+    }
+    if (n > 0) SCAL_HIP(hipMemcpyAsync(c->pts.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_insert_cloud(scal_sc_t* c, const float* xyzi, int n) {
+    if (!c || n < 0 || (n > 0 && !xyzi)) {
+        set_error("scal_sc_insert_cloud: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(upload_points(c, xyzi, n));
+    SCAL_TRY(make_into(c, c->pts.p, nullptr, nullptr, 4, nullptr, n, true));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_insert_cloud_device(scal_sc_t* c, const float* d_x, const float* d_y, const float* d_z, const int* d_n, int n_max) {
+    if (!c || !d_x || !d_y || !d_z || n_max < 0) {
+        set_error("scal_sc_insert_cloud_device: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    return make_into(c, d_x, d_y, d_z, 1, d_n, n_max, true);
+}
+
+extern "C" int scal_sc_make_descriptor(scal_sc_t* c, const float* xyzi, int n, double* desc) {
+    if (!c || !desc || n < 0 || (n > 0 && !xyzi)) {
+        set_error("scal_sc_make_descriptor: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(upload_points(c, xyzi, n));
+    SCAL_TRY(make_into(c, c->pts.p, nullptr, nullptr, 4, nullptr, n, false));
+    SCAL_HIP(hipMemcpyAsync(desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_insert_descriptor(scal_sc_t* c, const double* desc) {
+    if (!c || !desc) {
+        set_error("scal_sc_insert_descriptor: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    const int g = c->n_global;
+    if (c->owns(g)) {
+        if (c->n_local >= c->cap) {
+            set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
+            return SCAL_E_CAPACITY;
+        }
+        const size_t sl = c->n_local;
+        SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
+        c->n_local++;
+    }
+    c->n_global++;
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_get_descriptor(scal_sc_t* c, int idx, double* desc, float* ringkey20) {
+    if (!c) return SCAL_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (idx < 0 || idx >= c->n_global || !c->owns(idx)) {
+        set_error("keyframe %d is not stored on this shard", idx);
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const size_t sl = idx / c->cfg.n_shards;
+    if (desc) SCAL_HIP(hipMemcpyAsync(desc, c->desc.p + sl * DESC, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
+    if (ringkey20) SCAL_HIP(hipMemcpyAsync(ringkey20, c->rkey.p + sl * NR, sizeof(float) * NR, hipMemcpyDeviceToHost, c->stream));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    return SCAL_OK;
+}
+
+// ring-key top-3 over global indices < limit on this shard + SC distance of the three; records -> h_rec[0..2]
+static int search_local(scal_sc* c, int limit, bool fill_zero) {
+    hipStream_t s = c->stream;
+    const int nb = std::max(1, div_up(c->n_local, 256));
+    hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
+                       c->block_best.p);
+    hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
+                       c->qnorm.p, fill_zero ? 1 : 0, c->d_rec.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_rec.p, c->d_rec.p, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+static void finish_result(const SCRec* rec, int n, double thres, scal_sc_result* res) {
+    // the three smallest key distances overall (ties: lower index), evaluated in that order with strict '<' (:385-400)
+    std::vector<SCRec> v;
+    for (int i = 0; i < n; ++i)
+        if (rec[i].idx >= 0) v.push_back(rec[i]);
+    std::stable_sort(v.begin(), v.end(), [](const SCRec& a, const SCRec& b) { return a.key_dist < b.key_dist || (a.key_dist == b.key_dist && a.idx < b.idx); });
+    if (v.size() > 3) v.resize(3);
+    double min_dist = 10000000;
+    int nn_align = 0, nn_idx = 0;
+    for (int i = 0; i < 3; ++i) {
+        res->cand_idx[i] = 0, res->cand_keydist[i] = 0.f, res->cand_scdist[i] = 10000000, res->cand_shift[i] = 0;
+    }
+    for (size_t i = 0; i < v.size(); ++i) {
+        res->cand_idx[i] = v[i].idx, res->cand_keydist[i] = v[i].key_dist, res->cand_scdist[i] = v[i].sc_dist, res->cand_shift[i] = v[i].shift;
+        if (v[i].sc_dist < min_dist) min_dist = v[i].sc_dist, nn_align = v[i].shift, nn_idx = v[i].idx;
+    }
+    res->loop_id = (min_dist < thres) ? nn_idx : -1;  // :406-408
+    res->min_dist = min_dist;
+    res->nn_idx = nn_idx;
+    res->nn_shift = nn_align;
+    const float deg = static_cast<float>(nn_align * (360.0 / 60.0));  // PC_UNIT_SECTORANGLE; deg2rad(float) (:17-20, :422)
+    res->yaw_rad = static_cast<float>(deg * M_PI / 180.0);
+}
+
+extern "C" int scal_sc_detect(scal_sc_t* c, scal_sc_result* res) {
+    if (!c || !res) {
+        set_error("scal_sc_detect: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::memset(res, 0, sizeof *res);
+    res->loop_id = -1;
+    res->min_dist = 10000000;
+    if (c->cfg.n_shards > 1) {
+        set_error("scal_sc_detect needs the whole database on one context; use scal_sc_shard_query + scal_sc_merge_candidates");
+        return SCAL_E_STATE;
+    }
+    const int NUM_EXCLUDE_RECENT = 30, TREE_MAKING_PERIOD_ = 30;
+    if (c->n_global < NUM_EXCLUDE_RECENT + 1) return SCAL_OK;  // :346-350
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (c->tree_making_period_conter % TREE_MAKING_PERIOD_ == 0) c->size_at_rebuild = c->n_global;  // :353-364
+    c->tree_making_period_conter++;
+    // query = newest keyframe (:340-341)
+    const size_t sl = c->n_global - 1;
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, c->desc.p + sl * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->qskey.p, c->skey.p + sl * NS, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->qnorm.p, c->cnorm.p + sl * NS, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->qrkey.p, c->rkey.p + sl * NR, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
+    SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true));
+    finish_result(c->h_rec.p, 3, c->cfg.dist_thres, res);
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_shard_query(scal_sc_t* c, const double* query_desc, int global_size_at_rebuild, scal_sc_cand out[3]) {
+    if (!c || !query_desc || !out) {
+        set_error("scal_sc_shard_query: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, query_desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_TRY(search_local(c, global_size_at_rebuild - 30, true));
+    static_assert(sizeof(SCRec) == sizeof(scal_sc_cand), "record layout");
+    std::memcpy(out, c->h_rec.p, sizeof(SCRec) * 3);
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_merge_candidates(const scal_sc_cand* gathered, int n_records, double dist_thres, scal_sc_result* res) {
+    if (!gathered || !res || n_records < 0) {
+        set_error("scal_sc_merge_candidates: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::memset(res, 0, sizeof *res);
+    // a shard that found fewer than three real neighbours pads with keyframe 0 only on shard 0; drop padded
+    // duplicates when real candidates exist elsewhere
+    std::vector<SCRec> v(n_records);
+    std::memcpy(v.data(), gathered, sizeof(SCRec) * n_records);
+    int real = 0;
+    for (auto& r : v)
+        if (r.idx >= 0 && r.key_dist < FLT_MAX) ++real;
+    if (real >= 3)
+        for (auto& r : v)
+            if (!(r.key_dist < FLT_MAX)) r.idx = -1;
+    finish_result(v.data(), n_records, dist_thres, res);
+    return SCAL_OK;
+}
+
+static int ensure_pairs(scal_sc* c, size_t n) {
+    if (n > c->pair_cap) {
+        SCAL_TRY(c->d_pairs.alloc(2 * n));
+        SCAL_TRY(c->d_dist.alloc(n));
+        SCAL_TRY(c->d_shift.alloc(n));
+        c->pair_cap = n;
+    }
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_distance_pairs(scal_sc_t* c, const int* idx_a, const int* idx_b, int n_pairs, double* dist, int* shift) {
+    if (!c || n_pairs < 0 || (n_pairs > 0 && (!idx_a || !idx_b || !dist || !shift))) {
+        set_error("scal_sc_distance_pairs: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_pairs == 0) return SCAL_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->cfg.n_shards > 1) {
+        set_error("scal_sc_distance_pairs needs an unsharded context");
+        return SCAL_E_STATE;
+    }
+    for (int i = 0; i < n_pairs; ++i)
+        if (idx_a[i] < 0 || idx_a[i] >= c->n_global || idx_b[i] < 0 || idx_b[i] >= c->n_global) {
+            set_error("pair %d references a keyframe outside [0, %d)", i, c->n_global);
+            return SCAL_E_ARG;
+        }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(ensure_pairs(c, n_pairs));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->d_pairs.p, idx_a, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->d_pairs.p + n_pairs, idx_b, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_sc_pairs, dim3(div_up(n_pairs, 4)), dim3(256), 0, s, c->db(), c->d_pairs.p, c->d_pairs.p + n_pairs, n_pairs, c->d_dist.p,
+                       c->d_shift.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * n_pairs, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(shift, c->d_shift.p, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_distance_matrix(scal_sc_t* c, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift) {
+    if (!c || !dist || !shift || q0 < 0 || d0 < 0 || q1 < q0 || d1 < d0 || (mode != 0 && mode != 1)) {
+        set_error("scal_sc_distance_matrix: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->cfg.n_shards > 1 || q1 > c->n_global || d1 > c->n_global) {
+        set_error("scal_sc_distance_matrix: range outside the database (or sharded context)");
+        return SCAL_E_ARG;
+    }
+    const size_t np = static_cast<size_t>(q1 - q0) * (d1 - d0);
+    if (np == 0) return SCAL_OK;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(ensure_pairs(c, np));
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, q1 - q0, d0, d1 - d0, mode, c->d_dist.p,
+                       c->d_shift.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * np, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(shift, c->d_shift.p, sizeof(int) * np, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}

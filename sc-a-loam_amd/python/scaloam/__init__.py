@@ -1,0 +1,416 @@
+"""ctypes binding of libscaloam_hip.so (include/scaloam_hip.h) for tests, bench.py and Python callers.
+
+This is plumbing only: every function forwards to the C-ABI; there is no Python or CPU implementation
+behind it, and loading fails loudly when the HIP library has not been built.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libscaloam_hip.so"))
+
+VLP16, HDL32, HDL64, OS1_64 = 0, 1, 2, 3
+SCAN_LINES = {VLP16: 16, HDL32: 32, HDL64: 64, OS1_64: 64}
+
+OK, E_ARG, E_LIDAR_TYPE, E_SCAN_LINE, E_TOO_MANY, E_EMPTY, E_HIP, E_NO_DEVICE, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int)
+
+
+class ScalError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"scaloam_hip error {code}: {msg}")
+        self.code = code
+
+
+class FeaturesConfig(C.Structure):
+    _fields_ = [("lidar_type", C.c_int), ("n_scans", C.c_int), ("minimum_range", C.c_double), ("max_points", C.c_int),
+                ("float_math", C.c_int), ("check_finite", C.c_int), ("device", C.c_int)]
+
+
+class FeaturesOut(C.Structure):
+    _fields_ = [("cloud", _f32p), ("src_index", _i32p), ("curvature", _f32p), ("label", _i32p), ("ring_start", _i32p),
+                ("ring_end", _i32p), ("sharp", _i32p), ("less_sharp", _i32p), ("flat", _i32p), ("less_flat", _f32p),
+                ("n_kept", C.c_int), ("n_sharp", C.c_int), ("n_less_sharp", C.c_int), ("n_flat", C.c_int),
+                ("n_less_flat", C.c_int), ("n_tied_segments", C.c_int)]
+
+
+class SCConfig(C.Structure):
+    _fields_ = [("max_radius", C.c_double), ("dist_thres", C.c_double), ("max_keyframes", C.c_int), ("float_math", C.c_int),
+                ("device", C.c_int), ("n_shards", C.c_int), ("shard", C.c_int)]
+
+
+class SCResult(C.Structure):
+    _fields_ = [("loop_id", C.c_int), ("yaw_rad", C.c_float), ("min_dist", C.c_double), ("nn_idx", C.c_int), ("nn_shift", C.c_int),
+                ("cand_idx", C.c_int * 3), ("cand_keydist", C.c_float * 3), ("cand_scdist", C.c_double * 3), ("cand_shift", C.c_int * 3)]
+
+
+class SCCand(C.Structure):
+    _fields_ = [("key_dist", C.c_float), ("idx", C.c_int), ("sc_dist", C.c_double), ("shift", C.c_int), ("pad", C.c_int)]
+
+
+class MapConfig(C.Structure):
+    _fields_ = [("line_res", C.c_float), ("plane_res", C.c_float), ("max_scan_points", C.c_int), ("max_map_points", C.c_int),
+                ("device", C.c_int)]
+
+
+class MapStats(C.Structure):
+    _fields_ = [("n_corner_stack", C.c_int), ("n_surf_stack", C.c_int), ("n_corner_map", C.c_int), ("n_surf_map", C.c_int),
+                ("n_edge", C.c_int * 2), ("n_plane", C.c_int * 2), ("lm_iters", C.c_int * 2), ("lm_success", C.c_int * 2),
+                ("cost_init", C.c_double * 2), ("cost_final", C.c_double * 2), ("solved", C.c_int),
+                ("n_map_corner_total", C.c_int), ("n_map_surf_total", C.c_int)]
+
+
+class OdomConfig(C.Structure):
+    _fields_ = [("max_points", C.c_int), ("device", C.c_int)]
+
+
+class OdomStats(C.Structure):
+    _fields_ = [("n_edge", C.c_int * 2), ("n_plane", C.c_int * 2), ("lm_iters", C.c_int * 2), ("lm_success", C.c_int * 2),
+                ("cost_init", C.c_double * 2), ("cost_final", C.c_double * 2)]
+
+
+# every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "scal_last_error", "scal_device_count", "scal_version",
+    "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_fetch",
+    "scal_features_sync",
+    "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample",
+    "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
+    "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_distance_pairs",
+    "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom",
+    "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features",
+    "scal_factors_eval",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libscaloam_hip.so.  Raises if it is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C sc-a-loam_amd` or __graft_entry__.build()")
+    L = C.CDLL(LIB_PATH)
+    L.scal_last_error.restype = C.c_char_p
+    L.scal_version.restype = C.c_char_p
+    vp = C.c_void_p
+    L.scal_features_create.argtypes = [C.POINTER(FeaturesConfig), C.POINTER(vp)]
+    L.scal_features_destroy.argtypes = [vp]
+    L.scal_features_destroy.restype = None
+    L.scal_features_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeaturesOut)]
+    L.scal_features_run_device.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.scal_features_fetch.argtypes = [vp, C.POINTER(FeaturesOut)]
+    L.scal_features_sync.argtypes = [vp]
+    L.scal_voxel_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    L.scal_voxel_destroy.argtypes = [vp]
+    L.scal_voxel_destroy.restype = None
+    L.scal_voxel_downsample.argtypes = [vp, _f32p, C.c_int, C.c_float, _f32p, _i32p]
+    L.scal_sc_create.argtypes = [C.POINTER(SCConfig), C.POINTER(vp)]
+    L.scal_sc_destroy.argtypes = [vp]
+    L.scal_sc_destroy.restype = None
+    L.scal_sc_size.argtypes = [vp]
+    L.scal_sc_insert_cloud.argtypes = [vp, _f32p, C.c_int]
+    L.scal_sc_insert_cloud_device.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.scal_sc_insert_descriptor.argtypes = [vp, _f64p]
+    L.scal_sc_get_descriptor.argtypes = [vp, C.c_int, _f64p, _f32p]
+    L.scal_sc_make_descriptor.argtypes = [vp, _f32p, C.c_int, _f64p]
+    L.scal_sc_detect.argtypes = [vp, C.POINTER(SCResult)]
+    L.scal_sc_distance_pairs.argtypes = [vp, _i32p, _i32p, C.c_int, _f64p, _i32p]
+    L.scal_sc_distance_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _i32p]
+    L.scal_sc_shard_query.argtypes = [vp, _f64p, C.c_int, C.POINTER(SCCand)]
+    L.scal_sc_merge_candidates.argtypes = [C.POINTER(SCCand), C.c_int, C.c_double, C.POINTER(SCResult)]
+    L.scal_map_create.argtypes = [C.POINTER(MapConfig), C.POINTER(vp)]
+    L.scal_map_destroy.argtypes = [vp]
+    L.scal_map_destroy.restype = None
+    L.scal_map_step.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f32p, C.POINTER(MapStats)]
+    L.scal_map_step_features.argtypes = [vp, vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(MapStats)]
+    L.scal_map_export.argtypes = [vp, C.c_int, _f32p, C.c_int]
+    L.scal_map_get_wmap_wodom.argtypes = [vp, _f64p, _f64p]
+    L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
+    L.scal_odom_destroy.argtypes = [vp]
+    L.scal_odom_destroy.restype = None
+    L.scal_odom_step.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p, _f64p,
+                                 C.POINTER(OdomStats)]
+    L.scal_odom_step_features.argtypes = [vp, vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(OdomStats)]
+    L.scal_factors_eval.argtypes = [C.c_int, C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise ScalError(rc, lib().scal_last_error().decode())
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def device_count():
+    return lib().scal_device_count()
+
+
+# ---------------------------------------------------------------------------------------------- stage A
+class ScanRegistration:
+    """Mirror of the reference's scanRegistration node state (scan_line, lidar_type, minimum_range rosparams,
+    scanRegistration.cpp:480-482) with laserCloudHandler as a method."""
+
+    def __init__(self, lidar_type, minimum_range, max_points=400000, float_math=0, check_finite=1, device=0, n_scans=None):
+        self.cfg = FeaturesConfig(lidar_type, SCAN_LINES.get(lidar_type, 0) if n_scans is None else n_scans, float(minimum_range),
+                                  max_points, float_math, check_finite, device)
+        self.h = C.c_void_p()
+        _check(lib().scal_features_create(C.byref(self.cfg), C.byref(self.h)))
+        self.n_scans = self.cfg.n_scans
+        m = max_points
+        ns = self.n_scans
+        self._b = dict(cloud=np.zeros((m, 4), np.float32), src_index=np.zeros(m, np.int32), curvature=np.zeros(m, np.float32),
+                       label=np.zeros(m, np.int32), ring_start=np.zeros(ns, np.int32), ring_end=np.zeros(ns, np.int32),
+                       sharp=np.zeros(12 * ns, np.int32), less_sharp=np.zeros(120 * ns, np.int32), flat=np.zeros(24 * ns, np.int32),
+                       less_flat=np.zeros((m, 4), np.float32))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().scal_features_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _out(self):
+        b = self._b
+        return FeaturesOut(_p(b["cloud"], _f32p), _p(b["src_index"], _i32p), _p(b["curvature"], _f32p), _p(b["label"], _i32p),
+                           _p(b["ring_start"], _i32p), _p(b["ring_end"], _i32p), _p(b["sharp"], _i32p), _p(b["less_sharp"], _i32p),
+                           _p(b["flat"], _i32p), _p(b["less_flat"], _f32p))
+
+    def _pack(self, o):
+        b = self._b
+        k = o.n_kept
+        return dict(n_kept=k, cloud=b["cloud"][:k].copy(), src_index=b["src_index"][:k].copy(), curvature=b["curvature"][:k].copy(),
+                    label=b["label"][:k].copy(), ring_start=b["ring_start"].copy(), ring_end=b["ring_end"].copy(),
+                    sharp=b["sharp"][:o.n_sharp].copy(), less_sharp=b["less_sharp"][:o.n_less_sharp].copy(),
+                    flat=b["flat"][:o.n_flat].copy(), less_flat=b["less_flat"][:o.n_less_flat].copy(), n_tied_segments=o.n_tied_segments)
+
+    def laserCloudHandler(self, xyz):
+        xyz = _f32(xyz)
+        o = self._out()
+        stride = xyz.strides[0] if xyz.shape[0] > 0 else 4 * xyz.shape[1]
+        _check(lib().scal_features_run(self.h, xyz.ctypes.data, xyz.shape[0], stride, C.byref(o)))
+        return self._pack(o)
+
+    def run_device(self, d_ptr, n, stride_floats):
+        _check(lib().scal_features_run_device(self.h, d_ptr, n, stride_floats))
+
+    def fetch(self):
+        o = self._out()
+        _check(lib().scal_features_fetch(self.h, C.byref(o)))
+        return self._pack(o)
+
+    def sync(self):
+        _check(lib().scal_features_sync(self.h))
+
+
+# ---------------------------------------------------------------------------------------------- voxel grid
+class VoxelGrid:
+    def __init__(self, max_points=400000, device=0):
+        self.h = C.c_void_p()
+        _check(lib().scal_voxel_create(max_points, device, C.byref(self.h)))
+        self.cap = max_points
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().scal_voxel_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def filter(self, xyzi, leaf):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        out = np.zeros((max(1, xyzi.shape[0]), 4), np.float32)
+        n = C.c_int(0)
+        _check(lib().scal_voxel_downsample(self.h, _p(xyzi, _f32p), xyzi.shape[0], C.c_float(leaf), _p(out, _f32p), C.byref(n)))
+        return out[:n.value].copy()
+
+
+# ---------------------------------------------------------------------------------------------- stage D
+class SCManager:
+    """Mirror of the reference's SCManager public API (Scancontext.h:62-79, :107-108).  Descriptors cross this
+    boundary as [ring, sector] numpy arrays; the C-ABI itself uses Eigen's column-major layout."""
+
+    def __init__(self, max_radius=80.0, dist_thres=0.2, max_keyframes=8192, float_math=0, device=0, n_shards=1, shard=0):
+        self.cfg = SCConfig(max_radius, dist_thres, max_keyframes, float_math, device, n_shards, shard)
+        self.h = C.c_void_p()
+        _check(lib().scal_sc_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().scal_sc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def size(self):
+        return lib().scal_sc_size(self.h)
+
+    def makeScancontext(self, xyzi):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        d = np.zeros(1200)
+        _check(lib().scal_sc_make_descriptor(self.h, _p(xyzi, _f32p), xyzi.shape[0], _p(d, _f64p)))
+        return d.reshape(60, 20).T.copy()
+
+    def makeAndSaveScancontextAndKeys(self, xyzi):
+        xyzi = _f32(xyzi).reshape(-1, 4)
+        _check(lib().scal_sc_insert_cloud(self.h, _p(xyzi, _f32p), xyzi.shape[0]))
+
+    def saveScancontextAndKeys(self, desc_ring_sector):
+        d = _f64(np.asarray(desc_ring_sector).T.reshape(-1))
+        _check(lib().scal_sc_insert_descriptor(self.h, _p(d, _f64p)))
+
+    def get(self, idx):
+        d = np.zeros(1200)
+        k = np.zeros(20, np.float32)
+        _check(lib().scal_sc_get_descriptor(self.h, idx, _p(d, _f64p), _p(k, _f32p)))
+        return d.reshape(60, 20).T.copy(), k
+
+    def detectLoopClosureID(self):
+        r = SCResult()
+        _check(lib().scal_sc_detect(self.h, C.byref(r)))
+        return dict(loop_id=r.loop_id, yaw=r.yaw_rad, min_dist=r.min_dist, nn_idx=r.nn_idx, nn_shift=r.nn_shift,
+                    cand=np.array(r.cand_idx[:]), cand_d=np.array(r.cand_keydist[:], np.float32), cand_sc=np.array(r.cand_scdist[:]),
+                    cand_shift=np.array(r.cand_shift[:]))
+
+    def distance_pairs(self, ia, ib):
+        ia = np.ascontiguousarray(ia, np.int32)
+        ib = np.ascontiguousarray(ib, np.int32)
+        d = np.zeros(ia.shape[0])
+        s = np.zeros(ia.shape[0], np.int32)
+        _check(lib().scal_sc_distance_pairs(self.h, _p(ia, _i32p), _p(ib, _i32p), ia.shape[0], _p(d, _f64p), _p(s, _i32p)))
+        return d, s
+
+    def distance_matrix(self, q0, q1, d0, d1, mode=0):
+        d = np.zeros((q1 - q0, d1 - d0))
+        s = np.zeros((q1 - q0, d1 - d0), np.int32)
+        _check(lib().scal_sc_distance_matrix(self.h, q0, q1, d0, d1, mode, _p(d, _f64p), _p(s, _i32p)))
+        return d, s
+
+    def shard_query(self, query_desc_ring_sector, global_size_at_rebuild):
+        d = _f64(np.asarray(query_desc_ring_sector).T.reshape(-1))
+        out = (SCCand * 3)()
+        _check(lib().scal_sc_shard_query(self.h, _p(d, _f64p), global_size_at_rebuild, out))
+        return out
+
+
+def merge_candidates(cands, dist_thres):
+    arr = (SCCand * len(cands))(*cands)
+    r = SCResult()
+    _check(lib().scal_sc_merge_candidates(arr, len(cands), dist_thres, C.byref(r)))
+    return dict(loop_id=r.loop_id, yaw=r.yaw_rad, min_dist=r.min_dist, nn_idx=r.nn_idx, nn_shift=r.nn_shift,
+                cand=np.array(r.cand_idx[:]), cand_d=np.array(r.cand_keydist[:], np.float32))
+
+
+# ---------------------------------------------------------------------------------------------- stage C
+class LaserMapping:
+    """Mirror of the reference's laserMapping node state (mapping_line_resolution / mapping_plane_resolution,
+    laserMapping.cpp:915-916) with one process() pass as `process`."""
+
+    def __init__(self, line_res=0.4, plane_res=0.8, max_scan_points=400000, max_map_points=4000000, device=0):
+        self.cfg = MapConfig(line_res, plane_res, max_scan_points, max_map_points, device)
+        self.h = C.c_void_p()
+        _check(lib().scal_map_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().scal_map_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def process(self, corner_last, surf_last, full_res, q_wodom, t_wodom, want_registered=False):
+        c = _f32(corner_last).reshape(-1, 4)
+        s = _f32(surf_last).reshape(-1, 4)
+        f = _f32(full_res).reshape(-1, 4) if full_res is not None else None
+        q = _f64(q_wodom)
+        t = _f64(t_wodom)
+        qo = np.zeros(4)
+        to = np.zeros(3)
+        reg = np.zeros_like(f) if (want_registered and f is not None) else None
+        st = MapStats()
+        _check(lib().scal_map_step(self.h, _p(c, _f32p), c.shape[0], _p(s, _f32p), s.shape[0], _p(f, _f32p), 0 if f is None else f.shape[0],
+                                   _p(q, _f64p), _p(t, _f64p), _p(qo, _f64p), _p(to, _f64p), _p(reg, _f32p), C.byref(st)))
+        return qo, to, st, reg
+
+    def process_features(self, feat, q_wodom, t_wodom):
+        q = _f64(q_wodom)
+        t = _f64(t_wodom)
+        qo = np.zeros(4)
+        to = np.zeros(3)
+        st = MapStats()
+        _check(lib().scal_map_step_features(self.h, feat.h, _p(q, _f64p), _p(t, _f64p), _p(qo, _f64p), _p(to, _f64p), C.byref(st)))
+        return qo, to, st
+
+    def export(self, which):
+        n = lib().scal_map_export(self.h, which, None, 0)
+        if n < 0:
+            _check(n)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        m = lib().scal_map_export(self.h, which, _p(out, _f32p), n)
+        return out[:m]
+
+    def wmap_wodom(self):
+        q = np.zeros(4)
+        t = np.zeros(3)
+        _check(lib().scal_map_get_wmap_wodom(self.h, _p(q, _f64p), _p(t, _f64p)))
+        return q, t
+
+
+# ---------------------------------------------------------------------------------------------- stage B
+class LaserOdometry:
+    def __init__(self, max_points=400000, device=0):
+        self.cfg = OdomConfig(max_points, device)
+        self.h = C.c_void_p()
+        _check(lib().scal_odom_create(C.byref(self.cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().scal_odom_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def step(self, sharp, less_sharp, flat, less_flat):
+        a = [_f32(x).reshape(-1, 4) for x in (sharp, less_sharp, flat, less_flat)]
+        qlc, tlc, qw, tw = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        st = OdomStats()
+        _check(lib().scal_odom_step(self.h, _p(a[0], _f32p), a[0].shape[0], _p(a[1], _f32p), a[1].shape[0], _p(a[2], _f32p), a[2].shape[0],
+                                    _p(a[3], _f32p), a[3].shape[0], _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
+        return qlc, tlc, qw, tw, st
+
+    def step_features(self, feat):
+        qlc, tlc, qw, tw = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        st = OdomStats()
+        _check(lib().scal_odom_step_features(self.h, feat.h, _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
+        return qlc, tlc, qw, tw, st
+
+
+def factors_eval(kind, cp, pa, pb, x7, device=0):
+    kind = np.ascontiguousarray(kind, np.int32)
+    cp, pa, pb, x7 = _f64(cp), _f64(pa), _f64(pb), _f64(x7)
+    cost = np.zeros(1)
+    g = np.zeros(6)
+    H = np.zeros((6, 6))
+    _check(lib().scal_factors_eval(device, kind.shape[0], _p(kind, _i32p), _p(cp, _f64p), _p(pa, _f64p), _p(pb, _f64p), _p(x7, _f64p),
+                                   _p(cost, _f64p), _p(g, _f64p), _p(H, _f64p)))
+    return cost[0], g, H

@@ -1,0 +1,178 @@
+"""Voxel grid and ScanContext parity (HIP path through the C-ABI vs the oracle)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("leaf", [0.2, 0.4, 0.8])
+def test_voxel_real_scan(O, S, golden, leaf):
+    a = golden("Seosan01_000000.npy")
+    vg = S.VoxelGrid()
+    g = vg.filter(a, leaf)
+    o, guard = O.voxel_grid(a, leaf, order_mode=1)
+    assert guard == 0
+    assert g.shape == o.shape
+    assert np.array_equal(_bits(g), _bits(o))
+    vg.close()
+
+
+def test_voxel_edge_cases(O, S):
+    vg = S.VoxelGrid(max_points=100000)
+    assert vg.filter(np.zeros((0, 4), np.float32), 0.4).shape == (0, 4)
+    one = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
+    assert np.array_equal(vg.filter(one, 0.4), one)
+    # duplicates and negative coordinates
+    rng = np.random.default_rng(1)
+    p = rng.uniform(-30, 30, (5000, 4)).astype(np.float32)
+    p = np.concatenate([p, p[:500]])
+    g = vg.filter(p, 0.4)
+    o, _ = O.voxel_grid(p, 0.4, order_mode=1)
+    assert np.array_equal(_bits(g), _bits(o))
+    # PCL's overflow guard: leaf far too small for the extent => output is the input, unchanged
+    q = rng.uniform(-500, 500, (3000, 4)).astype(np.float32)
+    g = vg.filter(q, 0.001)
+    o, guard = O.voxel_grid(q, 0.001, order_mode=1)
+    assert guard == 1
+    assert np.array_equal(_bits(g), _bits(o)) and np.array_equal(_bits(g), _bits(q))
+    vg.close()
+
+
+def test_voxel_idempotent_and_order(O, S, golden):
+    """Size-independent properties: output sorted by voxel index, one point per voxel, re-filtering is stable."""
+    a = golden("KAIST03_000007.npy")
+    vg = S.VoxelGrid()
+    g = vg.filter(a, 0.4)
+    inv = np.float32(1.0) / np.float32(0.4)
+    ijk = np.floor(g[:, :3] * inv).astype(np.int64)
+    ijk -= np.floor(a[:, :3].min(0) * inv).astype(np.int64)
+    dims = ijk.max(0) + 2
+    idx = ijk[:, 0] + ijk[:, 1] * dims[0] + ijk[:, 2] * dims[0] * dims[1]
+    assert (np.diff(idx) > 0).all()
+    g2 = vg.filter(g, 0.4)
+    assert g2.shape[0] <= g.shape[0]
+    vg.close()
+
+
+def _sc_pair(O, S, **kw):
+    return O.SCManager(**kw), S.SCManager(**kw)
+
+
+def test_sc_descriptor_and_keys(O, S, golden):
+    vg = S.VoxelGrid()
+    for name in ["KAIST03_000000.npy", "Seosan01_000000.npy", "Seosan01_000011.npy"]:
+        a = golden(name)
+        ds = vg.filter(a, 0.4)  # the detector's input is the keyframe downsampled at 0.4 m (PGO :629-631)
+        for fm in (0, 1):
+            om, gm = _sc_pair(O, S, max_radius=80.0, float_math=fm)
+            do = om.makeScancontext(ds)
+            dg = gm.makeScancontext(ds)
+            assert np.array_equal(do, dg)
+            om.makeAndSaveScancontextAndKeys(ds)
+            gm.makeAndSaveScancontextAndKeys(ds)
+            d1, k1 = om.get(0)
+            d2, k2 = gm.get(0)
+            assert np.array_equal(d1, d2)
+            assert np.array_equal(k1.view(np.uint32), k2.view(np.uint32))
+            gm.close()
+    vg.close()
+
+
+def _random_descs(rng, n, revisit_every=7):
+    """Descriptors with the statistics of real ones (occupancy ~0.5, heights -2.8..18) plus shifted revisits."""
+    out = []
+    for i in range(n):
+        if i >= 40 and i % revisit_every == 0:
+            j = int(rng.integers(0, i - 35))
+            d = np.roll(out[j], int(rng.integers(0, 60)), axis=1) + rng.normal(0, 0.05, (20, 60)) * (out[j] != 0)
+        else:
+            d = rng.uniform(-2.0, 18.0, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+            d[:, rng.integers(0, 60, 3)] = 0.0  # empty sectors
+        out.append(d)
+    return out
+
+
+def test_sc_detect_stream(O, S):
+    """Insertion-order replay: the >=31 gate, the 30-query tree period and the exclusion of the newest 30 keys
+    (Scancontext.cpp:346-365) must give the same candidates, distances, shift and loop id at every step."""
+    rng = np.random.default_rng(42)
+    descs = _random_descs(rng, 150)
+    om, gm = _sc_pair(O, S, max_radius=80.0, dist_thres=0.2)
+    loops = 0
+    for i, d in enumerate(descs):
+        om.saveScancontextAndKeys(d)
+        gm.saveScancontextAndKeys(d)
+        ro = om.detectLoopClosureID()
+        rg = gm.detectLoopClosureID()
+        assert rg["loop_id"] == ro["loop_id"], i
+        if i >= 30:
+            assert np.array_equal(rg["cand"], ro["cand"]), (i, rg["cand"], ro["cand"])
+            assert rg["nn_idx"] == ro["nn_idx"]
+            assert abs(rg["min_dist"] - ro["min_dist"]) <= 1e-12
+            assert rg["yaw"] == ro["yaw"]
+        loops += ro["loop_id"] >= 0
+    assert loops > 5
+    assert gm.size() == 150
+    gm.close()
+
+
+def test_sc_pair_and_matrix(O, S):
+    rng = np.random.default_rng(7)
+    descs = _random_descs(rng, 48)
+    gm = S.SCManager()
+    for d in descs:
+        gm.saveScancontextAndKeys(d)
+    ia = rng.integers(0, 48, 200).astype(np.int32)
+    ib = rng.integers(0, 48, 200).astype(np.int32)
+    dist, shift = gm.distance_pairs(ia, ib)
+    for k in range(200):
+        do, so = O.sc_distance(descs[ia[k]], descs[ib[k]])
+        assert abs(dist[k] - do) <= 1e-12 and shift[k] == so
+    D, Sh = gm.distance_matrix(0, 12, 0, 48, mode=1)
+    for q in range(12):
+        for j in range(48):
+            full = O.sc_distance_full(descs[q], descs[j])
+            full = np.where(np.isnan(full), 1e300, full)
+            assert abs(D[q, j] - full.min()) <= 1e-12
+            assert Sh[q, j] == int(np.argmin(full))
+    D0, S0 = gm.distance_matrix(3, 9, 10, 30, mode=0)
+    for q in range(3, 9):
+        for j in range(10, 30):
+            do, so = O.sc_distance(descs[q], descs[j])
+            assert abs(D0[q - 3, j - 10] - do) <= 1e-12 and S0[q - 3, j - 10] == so
+    gm.close()
+
+
+def test_sc_sharded_equals_single(O, S):
+    """Keyframe i lives on shard i % G; per-shard top-3 + merge must equal the single-context answer."""
+    rng = np.random.default_rng(11)
+    descs = _random_descs(rng, 100)
+    single = S.SCManager(dist_thres=0.3)
+    G = 4
+    shards = [S.SCManager(dist_thres=0.3, n_shards=G, shard=s) for s in range(G)]
+    counter = 0
+    size_at_rebuild = 0
+    for i, d in enumerate(descs):
+        single.saveScancontextAndKeys(d)
+        for sh in shards:
+            sh.saveScancontextAndKeys(d)
+        ref = single.detectLoopClosureID()
+        if i + 1 < 31:
+            continue
+        if counter % 30 == 0:
+            size_at_rebuild = i + 1
+        counter += 1
+        cands = []
+        for sh in shards:
+            cands += list(sh.shard_query(d, size_at_rebuild))
+        got = S.merge_candidates(cands, 0.3)
+        assert got["loop_id"] == ref["loop_id"], i
+        assert got["nn_idx"] == ref["nn_idx"] and abs(got["min_dist"] - ref["min_dist"]) <= 1e-12
+        assert np.array_equal(got["cand"], ref["cand"])
+    for sh in shards:
+        sh.close()
+    single.close()
