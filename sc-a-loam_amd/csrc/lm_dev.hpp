@@ -1,0 +1,359 @@
+// On-device Levenberg-Marquardt for the reference's two pose problems (laserOdometry.cpp:284-291, :494-499;
+// laserMapping.cpp:566-573, :713-721): residual blocks of lidarFactor.hpp:12-138 over q (4, Eigen quaternion
+// parameterisation) and t (3), HuberLoss(0.1), DENSE_QR, max_num_iterations 4, Ceres defaults otherwise.
+//
+// What runs where:
+//   k_lm_eval   one thread per residual block: residual, analytic Jacobian of the un-normalised Eigen rotation
+//               (equal to Ceres' autodiff up to rounding), projection through the 4x3
+//               plus-Jacobian, Huber weight per block; block-reduced to 28 doubles (cost, g[6], upper H[21])
+//               with wave shuffles and a fixed-order LDS stage => bitwise run-to-run reproducible, no float atomics.
+//   k_lm_step   one wave: sums the per-block partials in a fixed order and advances Ceres' trust-region state
+//               machine (Jacobi scaling fixed at iteration 0, D = sqrt(clamp(diag)/radius), step acceptance,
+//               parameter/function/gradient tolerances, radius update).  The damped 6x6 system is solved by
+//               Cholesky on the normal equations, which is algebraically what Ceres' DENSE_QR on [J; D] solves.
+// The whole <=4-iteration solve is a fixed chain eval,step,(eval,step)x4 on one stream: every data-dependent
+// decision stays on the GPU, finished solves turn the remaining kernels into no-ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_utils.hpp"
+
+namespace scal {
+
+// residual blocks, structure of arrays; slot i is live iff valid[i] != 0
+struct FactorSoA {
+    int* valid;
+    int* kind;    // 0 LidarEdgeFactor(a,b)  1 LidarPlaneFactor(j, unit normal)  2 LidarPlaneNormFactor(n, d)
+    double* cp;   // [3][cap]
+    double* pa;   // [3][cap]
+    double* pb;   // [3][cap]
+    int cap;
+};
+
+struct LMState {
+    double x[7];     // qx qy qz qw tx ty tz (accepted point)
+    double cand[7];  // candidate point being evaluated
+    double x_cost, mcc, radius, decrease_factor, x_norm;
+    double H[21], g[6], scale[6];
+    int iteration, done, successful, started, enabled;
+    int termination;  // 0 max iterations, 1 gradient, 2 parameter, 3 function, 4 no residual blocks
+    double cost_init, cost_final;
+    int n_blocks_live[3];
+};
+
+__device__ __forceinline__ void quat_plus(const double* x, const double* delta, double* o) {
+    // EigenQuaternionParameterization::Plus: [sin|d| d/|d|, cos|d|] (x) q, no half angle
+    const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+    if (nd > 0.0) {
+        const double s = sin(nd) / nd;
+        const double ax = s * delta[0], ay = s * delta[1], az = s * delta[2], aw = cos(nd);
+        const double bx = x[0], by = x[1], bz = x[2], bw = x[3];
+        o[0] = aw * bx + ax * bw + ay * bz - az * by;
+        o[1] = aw * by + ay * bw + az * bx - ax * bz;
+        o[2] = aw * bz + az * bw + ax * by - ay * bx;
+        o[3] = aw * bw - ax * bx - ay * by - az * bz;
+    } else {
+        o[0] = x[0], o[1] = x[1], o[2] = x[2], o[3] = x[3];
+    }
+    o[4] = x[4] + delta[3], o[5] = x[5] + delta[4], o[6] = x[6] + delta[5];
+}
+
+// Eigen q*v: v + w*2(u x v) + u x 2(u x v)
+__device__ __forceinline__ void quat_rotate(const double* q, double vx, double vy, double vz, double* o) {
+    double ux = q[1] * vz - q[2] * vy, uy = q[2] * vx - q[0] * vz, uz = q[0] * vy - q[1] * vx;
+    ux += ux, uy += uy, uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    o[0] = (vx + q[3] * ux) + cx;
+    o[1] = (vy + q[3] * uy) + cy;
+    o[2] = (vz + q[3] * uz) + cz;
+}
+
+// robustified contribution of one block to (cost, g, H); acc[0]=cost, acc[1..6]=g, acc[7..27]=upper H row-major
+__device__ __forceinline__ void factor_accumulate(int kind, const double* cp, const double* pa, const double* pb, const double* x, double* acc) {
+    const double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+    double lp[3];
+    quat_rotate(x, cp[0], cp[1], cp[2], lp);
+    lp[0] += x[4], lp[1] += x[5], lp[2] += x[6];
+    // d lp / d(qx,qy,qz) = -2w[cp]x - 2[u x cp]x - 2[u]x[cp]x ;  d lp / d qw = 2 (u x cp)
+    const double c0 = cp[0], c1 = cp[1], c2 = cp[2];
+    const double ucx = qy * c2 - qz * c1, ucy = qz * c0 - qx * c2, ucz = qx * c1 - qy * c0;
+    // [u]x[cp]x = cp u^T - (u.cp) I
+    const double udc = qx * c0 + qy * c1 + qz * c2;
+    double A[3][3];
+    // -2w[cp]x
+    A[0][0] = 0, A[0][1] = 2 * qw * c2, A[0][2] = -2 * qw * c1;
+    A[1][0] = -2 * qw * c2, A[1][1] = 0, A[1][2] = 2 * qw * c0;
+    A[2][0] = 2 * qw * c1, A[2][1] = -2 * qw * c0, A[2][2] = 0;
+    // -2[u x cp]x
+    A[0][1] += 2 * ucz, A[0][2] += -2 * ucy;
+    A[1][0] += -2 * ucz, A[1][2] += 2 * ucx;
+    A[2][0] += 2 * ucy, A[2][1] += -2 * ucx;
+    // -2 (cp u^T - (u.cp) I)
+    const double cpv[3] = {c0, c1, c2}, uv[3] = {qx, qy, qz};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A[r][c] += -2 * cpv[r] * uv[c] + (r == c ? 2 * udc : 0.0);
+    const double bq[3] = {2 * ucx, 2 * ucy, 2 * ucz};
+    // plus-Jacobian P (4x3): rows [w,z,-y], [-z,w,x], [y,-x,w], [-x,-y,-z]
+    const double P[4][3] = {{qw, qz, -qy}, {-qz, qw, qx}, {qy, -qx, qw}, {-qx, -qy, -qz}};
+    double JL[3][6];  // d lp / d local
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) JL[r][c] = A[r][0] * P[0][c] + A[r][1] * P[1][c] + A[r][2] * P[2][c] + bq[r] * P[3][c];
+        JL[r][3] = r == 0, JL[r][4] = r == 1, JL[r][5] = r == 2;
+    }
+    double res[3], J[3][6];
+    int nr;
+    if (kind == 0) {  // r = (lp-a) x (lp-b) / |a-b| ; dr/dlp = [b-a]x / |a-b|
+        const double ax = lp[0] - pa[0], ay = lp[1] - pa[1], az = lp[2] - pa[2];
+        const double bx = lp[0] - pb[0], by = lp[1] - pb[1], bz = lp[2] - pb[2];
+        const double dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const double den = sqrt(dx * dx + dy * dy + dz * dz);
+        res[0] = (ay * bz - az * by) / den, res[1] = (az * bx - ax * bz) / den, res[2] = (ax * by - ay * bx) / den;
+        const double ex = -dx / den, ey = -dy / den, ez = -dz / den;  // (b - a)/den
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            J[0][c] = -ez * JL[1][c] + ey * JL[2][c];
+            J[1][c] = ez * JL[0][c] - ex * JL[2][c];
+            J[2][c] = -ey * JL[0][c] + ex * JL[1][c];
+        }
+        nr = 3;
+    } else {
+        double nx, ny, nz;
+        if (kind == 1) {  // (lp - j) . n
+            nx = pb[0], ny = pb[1], nz = pb[2];
+            res[0] = (lp[0] - pa[0]) * nx + (lp[1] - pa[1]) * ny + (lp[2] - pa[2]) * nz;
+        } else {  // n . lp + d
+            nx = pa[0], ny = pa[1], nz = pa[2];
+            res[0] = (nx * lp[0] + ny * lp[1] + nz * lp[2]) + pb[0];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) J[0][c] = nx * JL[0][c] + ny * JL[1][c] + nz * JL[2][c];
+        nr = 1;
+    }
+    double s = 0;
+    for (int r = 0; r < nr; ++r) s += res[r] * res[r];
+    // HuberLoss(0.1): rho = s | 2a sqrt(s) - a^2 ; rho' = 1 | a / sqrt(s); rho'' <= 0 => scale rows by sqrt(rho')
+    double rho0, rho1;
+    if (s > 0.01) {
+        const double rt = sqrt(s);
+        rho0 = 2.0 * 0.1 * rt - 0.01;
+        rho1 = fmax(2.2250738585072014e-308, 0.1 / rt);
+    } else {
+        rho0 = s, rho1 = 1.0;
+    }
+    acc[0] += 0.5 * rho0;
+    for (int r = 0; r < nr; ++r) {
+        int k = 7;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[1 + a] += rho1 * J[r][a] * res[r];
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[k++] += rho1 * J[r][a] * J[r][b];
+        }
+    }
+}
+
+constexpr int LM_NACC = 28;
+
+// which = 0: evaluate at st->x (iteration zero), 1: at st->cand
+__global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
+                                                 double* __restrict__ partials) {
+    __shared__ double red[4][LM_NACC];
+    const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
+    const int nb = (n + 255) / 256;
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    if (!st->enabled || st->done) return;
+    const double* x = which ? st->cand : st->x;
+    double xl[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) xl[k] = x[k];
+    double acc[LM_NACC];
+#pragma unroll
+    for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && f.valid[i]) {
+        const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
+        const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
+        const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
+        factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < LM_NACC; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane_id() == 0) red[wave_id()][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < LM_NACC) partials[blockIdx.x * LM_NACC + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__device__ __forceinline__ int hidx(int a, int b) {  // index into upper-triangular row-major H[21], a <= b
+    return a * 6 - a * (a - 1) / 2 + (b - a);
+}
+
+// solve (Hs + diag(d2)) y = gs by Cholesky; returns false when not positive definite / not finite
+__device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, const double* gs, double* y) {
+    double L[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = Hs[hidx(j, i)] + (i == j ? d2[i] : 0.0);
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                L[i][i] = sqrt(s);
+            } else {
+                L[i][j] = s / L[j][j];
+            }
+        }
+    double z[6];
+    for (int i = 0; i < 6; ++i) {
+        double s = gs[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * z[k];
+        z[i] = s / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double s = z[i];
+        for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
+        y[i] = s / L[i][i];
+    }
+    for (int i = 0; i < 6; ++i)
+        if (!isfinite(y[i])) return false;
+    return true;
+}
+
+// LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep; loops over invalid steps
+__device__ __forceinline__ void lm_compute_candidate(LMState* st) {
+    const int max_num_iterations = 4;
+    while (!st->done) {
+        if (st->iteration >= max_num_iterations) {
+            st->done = 1, st->termination = 0;
+            break;
+        }
+        st->iteration++;
+        double Hs[21], gs[6], d2[6];
+        for (int a = 0; a < 6; ++a) {
+            gs[a] = st->g[a] * st->scale[a];
+            for (int b = a; b < 6; ++b) Hs[hidx(a, b)] = st->H[hidx(a, b)] * st->scale[a] * st->scale[b];
+        }
+        for (int a = 0; a < 6; ++a) d2[a] = fmin(fmax(Hs[hidx(a, a)], 1e-6), 1e32) / st->radius;
+        double y[6];
+        bool ok = chol_solve6(Hs, d2, gs, y);
+        double mcc = 0.0;
+        if (ok) {
+            // model_cost_change = -(J s).(r + J s/2) with s = -y  =  y.gs - y^T Hs y / 2
+            double yg = 0.0, yhy = 0.0;
+            for (int a = 0; a < 6; ++a) {
+                yg += y[a] * gs[a];
+                double row = 0.0;
+                for (int b = 0; b < 6; ++b) row += Hs[a <= b ? hidx(a, b) : hidx(b, a)] * y[b];
+                yhy += y[a] * row;
+            }
+            mcc = yg - 0.5 * yhy;
+            ok = mcc > 0.0;
+        }
+        if (!ok) {  // HandleInvalidStep -> StepIsInvalid
+            st->radius = st->radius / st->decrease_factor;
+            st->decrease_factor *= 2.0;
+            continue;
+        }
+        double delta[6];
+        for (int a = 0; a < 6; ++a) delta[a] = -y[a] * st->scale[a];
+        st->mcc = mcc;
+        quat_plus(st->x, delta, st->cand);
+        return;
+    }
+}
+
+// One wave.  phase 0: partials hold the evaluation at x (iteration zero).  phase 1: at the candidate.
+__global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double* __restrict__ partials, const int* __restrict__ d_nslots, int cap,
+                                                int phase) {
+    __shared__ double tot[LM_NACC];
+    if (!st->enabled || st->done) return;
+    const int n = d_nslots ? min(*d_nslots, cap) : cap;
+    const int nb = (n + 255) / 256;
+    if (threadIdx.x < LM_NACC) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partials[b * LM_NACC + threadIdx.x];  // fixed order
+        tot[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
+    auto grad_max_norm = [&]() {
+        double neg[6], proj[7], m = 0.0;
+        for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
+        quat_plus(st->x, neg, proj);
+        for (int k = 0; k < 7; ++k) m = fmax(m, fabs(st->x[k] - proj[k]));
+        return m;
+    };
+    if (phase == 0) {
+        st->x_cost = tot[0];
+        st->cost_init = tot[0];
+        st->cost_final = tot[0];
+        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+        for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));  // Jacobi scaling, iteration 0 only
+        double xn = 0.0;
+        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+        st->x_norm = sqrt(xn);
+        st->started = 1;
+        if (grad_max_norm() <= gradient_tolerance) {
+            st->done = 1, st->termination = 1;
+            return;
+        }
+        lm_compute_candidate(st);
+        return;
+    }
+    // candidate evaluated
+    const double candidate_cost = tot[0];
+    double sn = 0.0;
+    for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
+    if (sqrt(sn) <= parameter_tolerance * (st->x_norm + parameter_tolerance)) {
+        st->done = 1, st->termination = 2;
+        return;
+    }
+    if (fabs(st->x_cost - candidate_cost) <= function_tolerance * st->x_cost) {
+        st->done = 1, st->termination = 3;
+        return;
+    }
+    const double relative_decrease = (st->x_cost - candidate_cost) / st->mcc;
+    if (relative_decrease > min_relative_decrease) {
+        for (int k = 0; k < 7; ++k) st->x[k] = st->cand[k];
+        double xn = 0.0;
+        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+        st->x_norm = sqrt(xn);
+        st->x_cost = candidate_cost;
+        st->cost_final = candidate_cost;
+        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+        st->successful++;
+        const double t = 2.0 * relative_decrease - 1.0;
+        st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+        st->radius = fmin(1e16, st->radius);
+        st->decrease_factor = 2.0;
+        if (grad_max_norm() <= gradient_tolerance) {
+            st->done = 1, st->termination = 1;
+            return;
+        }
+    } else {
+        st->radius = st->radius / st->decrease_factor;
+        st->decrease_factor *= 2.0;
+    }
+    lm_compute_candidate(st);
+}
+
+// (re)arm the solver at the pose currently in st->x.  enabled = 0 turns the whole chain into no-ops.
+__global__ void k_lm_reset(LMState* st, const int* __restrict__ d_enable, const int* __restrict__ d_live_count) {
+    if (threadIdx.x != 0) return;
+    st->radius = 1e4, st->decrease_factor = 2.0;
+    st->iteration = 0, st->done = 0, st->successful = 0, st->started = 0, st->termination = 0;
+    st->x_cost = 0, st->cost_init = 0, st->cost_final = 0, st->mcc = 0;
+    st->enabled = d_enable ? *d_enable : 1;
+    if (d_live_count && *d_live_count == 0) {
+        // no residual blocks: Ceres finds no non-constant parameter block and returns the input unchanged
+        st->done = 1, st->termination = 4;
+    }
+}
+
+}  // namespace scal

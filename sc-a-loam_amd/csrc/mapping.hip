@@ -1,0 +1,928 @@
+// Stage C on gfx950: scan-to-map registration.  Replaces process(), /root/reference/src/laserMapping.cpp:310-802,
+// :845-849 (see include/scaloam_hip.h).
+//
+// Map layout in HBM.  The reference keeps 21x21x11 cubes of 50 m, each a separate PointCloud (:74-104).  Here each
+// feature class (corner, surf) is ONE SoA array x[] y[] z[] i[] plus a packed absolute cube coordinate per point;
+// the rolling window (:313-508) is index arithmetic on the host (cen offsets), never a copy: points whose cube
+// leaves the window are dropped by the next re-filter pass, which is exactly the slab the reference clears.
+//
+// Per scan, one stream, one host sync at the end (pose + statistics read-back):
+//   stack downsample (:543-551)        VoxelFilter (voxel.hip) on the incoming corner / surf clouds
+//   submap gather + kd-tree (:510-560) replaced by a 1 m uniform cell grid over the 5x5x3 valid cubes
+//                                      (250x250x150 cells): k_grid_count / k_grid_alloc / k_grid_fill bin the valid
+//                                      map points with atomics; both acceptance gates need the 5th neighbour
+//                                      within 1 m (:585, :653) so the 27 surrounding cells hold every candidate
+//   association (:578-688)             k_assoc_edge / k_assoc_plane: exact 5-NN by f32 (dx^2+dy^2)+dz^2, ties by map
+//                                      index; 3x3 Jacobi eigen-decomposition (edge) or pivoted Householder QR
+//                                      (plane) in f64 registers -> residual blocks
+//   solve (:713-721) x2 (:563)         lm_dev.hpp, all on the device
+//   insert + per-cube voxel (:738-802) k_insert_keys -> radix sort by (cube, voxel) -> k_map_reduce; cubes outside
+//                                      the 5x5x3 valid set keep raw points in arrival order, as the reference does
+//   registration (:845-849)            k_transform_cloud
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "voxel_dev.hpp"
+#include "radix_sort.hpp"
+#include "lm_dev.hpp"
+#include "features_dev.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace scal {
+
+constexpr int CW = 21, CH = 21, CD = 11;       // laserCloudWidth/Height/Depth (:77-79)
+constexpr int GX = 250, GY = 250, GZ = 150;    // 1 m cells over the 5x5x3 valid cubes
+constexpr int GCELLS = GX * GY * GZ;
+
+struct MapParams {
+    int cenW, cenH, cenD;       // laserCloudCenWidth/Height/Depth after this scan's shifts
+    int cI, cJ, cK;             // centerCube indices
+    int ox, oy, oz;             // grid origin [m] = 50*(c-2-cen)-25 (integers)
+    float inv_line, inv_plane;  // 1/leaf as PCL computes it (f32)
+};
+
+struct MapCounters {
+    int n_corner_in, n_surf_in;          // incoming clouds
+    int n_corner_stack, n_surf_stack;    // after the stack voxel grid
+    int n_valid[2];                      // map points inside the 5x5x3 window (corner, surf)
+    int cursor[2];                       // grid fill cursors
+    int solve_on;                        // laserCloudCornerFromMapNum > 10 && SurfFromMapNum > 50 (:555)
+    int n_slots;                         // residual-block slots = n_corner_stack + n_surf_stack
+    int n_live;                          // live residual blocks of the current outer iteration
+    int n_edge[2], n_plane[2];
+    int lm_iters[2], lm_success[2];
+    double cost_init[2], cost_final[2];
+    int n_total[2];                      // map points to sort in the re-filter pass (old + new)
+    int n_map_new[2];                    // map size after the re-filter
+    int error;
+};
+
+__device__ __forceinline__ int pack_cube(int ai, int aj, int ak) { return (ai + 512) | ((aj + 512) << 10) | ((ak + 512) << 20); }
+__device__ __forceinline__ void unpack_cube(int p, int& ai, int& aj, int& ak) {
+    ai = (p & 1023) - 512, aj = ((p >> 10) & 1023) - 512, ak = ((p >> 20) & 1023) - 512;
+}
+// cube coordinate of a map-frame coordinate: int((p + 25)/50) with the reference's negative fix (:742-751), minus cen
+__device__ __forceinline__ int cube_abs(float p) {
+    const double v = static_cast<double>(p) + 25.0;
+    int c = static_cast<int>(v / 50.0);
+    if (v < 0) c--;
+    return c;
+}
+
+__device__ __forceinline__ int grid_cell(const MapParams& mp, float x, float y, float z) {
+    int cx = static_cast<int>(floorf(x)) - mp.ox, cy = static_cast<int>(floorf(y)) - mp.oy, cz = static_cast<int>(floorf(z)) - mp.oz;
+    cx = min(max(cx, 0), GX - 1), cy = min(max(cy, 0), GY - 1), cz = min(max(cz, 0), GZ - 1);
+    return cx + GX * (cy + GY * cz);
+}
+
+__device__ __forceinline__ bool cube_valid(const MapParams& mp, int packed) {
+    int ai, aj, ak;
+    unpack_cube(packed, ai, aj, ak);
+    const int I = ai + mp.cenW, J = aj + mp.cenH, K = ak + mp.cenD;
+    return abs(I - mp.cI) <= 2 && abs(J - mp.cJ) <= 2 && abs(K - mp.cK) <= 1 && I >= 0 && I < CW && J >= 0 && J < CH && K >= 0 && K < CD;
+}
+
+struct MapCloud {
+    float *x, *y, *z, *w;
+    int* cube;
+};
+
+// ---------------------------------------------------------------------------------------------- grid build
+__global__ void __launch_bounds__(256) k_grid_count(MapCloud m, int n, MapParams mp, int* __restrict__ cnt, int* __restrict__ rank,
+                                                    MapCounters* C, int cls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool v = false;
+    if (i < n && cube_valid(mp, m.cube[i])) {
+        v = true;
+        rank[i] = atomicAdd(&cnt[grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
+    } else if (i < n) {
+        rank[i] = -1;
+    }
+    const uint64_t b = __ballot(v);
+    if (lane_id() == 0 && b) atomicAdd(&C->n_valid[cls], __popcll(b));
+}
+
+__global__ void __launch_bounds__(256) k_grid_alloc(MapCloud m, int n, MapParams mp, const int* __restrict__ cnt, const int* __restrict__ rank,
+                                                    int* __restrict__ start, MapCounters* C, int cls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rank[i] == 0) {
+        const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
+        start[c] = atomicAdd(&C->cursor[cls], cnt[c]);
+    }
+    if (i == 0 && cls == 1) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555 (corner grid was counted first)
+}
+
+struct GridPts {
+    float *x, *y, *z;
+    int* idx;
+};
+
+__global__ void __launch_bounds__(256) k_grid_fill(MapCloud m, int n, MapParams mp, const int* __restrict__ rank, const int* __restrict__ start,
+                                                   GridPts g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rank[i] >= 0) {
+        const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
+        const int p = start[c] + rank[i];
+        g.x[p] = m.x[i], g.y[p] = m.y[i], g.z[p] = m.z[i], g.idx[p] = i;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_grid_clear(MapCloud m, int n, MapParams mp, const int* __restrict__ rank, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && rank[i] >= 0) cnt[grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------- association
+struct Knn5 {
+    float d[5];
+    int id[5];
+    float px[5], py[5], pz[5];
+};
+
+// exact 5 nearest map points of q among the 27 cells around it; ascending (distance, map index)
+__device__ __forceinline__ void knn5(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g, float qx,
+                                     float qy, float qz, Knn5& r) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) r.d[k] = 3.4e38f, r.id[k] = 0x7fffffff, r.px[k] = r.py[k] = r.pz[k] = 0.f;
+    const int cx = static_cast<int>(floorf(qx)) - mp.ox, cy = static_cast<int>(floorf(qy)) - mp.oy, cz = static_cast<int>(floorf(qz)) - mp.oz;
+    // a query further than one cell outside the grid has no map point within 1 m
+    if (cx < -1 || cx > GX || cy < -1 || cy > GY || cz < -1 || cz > GZ) return;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, GX - 1);
+    const int y0 = max(cy - 1, 0), y1 = min(cy + 1, GY - 1);
+    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, GZ - 1);
+    for (int zz = z0; zz <= z1; ++zz)
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) {
+                const int c = xx + GX * (yy + GY * zz);
+                const int n = cnt[c];
+                if (n == 0) continue;
+                const int s = start[c];
+                for (int t = s; t < s + n; ++t) {
+                    const float px = g.x[t], py = g.y[t], pz = g.z[t];
+                    // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
+                    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+                    float dist = dx * dx;
+                    dist += dy * dy;
+                    dist += dz * dz;
+                    const int id = g.idx[t];
+                    if (dist < r.d[4] || (dist == r.d[4] && id < r.id[4])) {
+                        int k = 4;
+                        while (k > 0 && (r.d[k - 1] > dist || (r.d[k - 1] == dist && r.id[k - 1] > id))) {
+                            r.d[k] = r.d[k - 1], r.id[k] = r.id[k - 1], r.px[k] = r.px[k - 1], r.py[k] = r.py[k - 1], r.pz[k] = r.pz[k - 1];
+                            --k;
+                        }
+                        r.d[k] = dist, r.id[k] = id, r.px[k] = px, r.py[k] = py, r.pz[k] = pz;
+                    }
+                }
+            }
+}
+
+// symmetric 3x3 eigen-decomposition by cyclic Jacobi (stands in for Eigen::SelfAdjointEigenSolver, :606);
+// returns the largest eigenvalue's unit eigenvector and the two largest eigenvalues
+__device__ __forceinline__ void eig3_largest(double a00, double a01, double a02, double a11, double a12, double a22, double* w1, double* w2,
+                                             double* dir) {
+    double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (off <= 1e-40 * diag || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    // ascending order of the diagonal; ties keep the lower index first (as a stable sort of three)
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (a[o1][o1] < a[o0][o0]) { int t = o0; o0 = o1; o1 = t; }
+    if (a[o2][o2] < a[o1][o1]) { int t = o1; o1 = o2; o2 = t; }
+    if (a[o1][o1] < a[o0][o0]) { int t = o0; o0 = o1; o1 = t; }
+    *w1 = a[o1][o1];
+    *w2 = a[o2][o2];
+    double n = sqrt(v[0][o2] * v[0][o2] + v[1][o2] * v[1][o2] + v[2][o2] * v[2][o2]);
+    dir[0] = v[0][o2] / n, dir[1] = v[1][o2] / n, dir[2] = v[2][o2] / n;
+}
+
+// least squares A n = b for a 5x3 A by column-pivoted Householder QR (stands in for colPivHouseholderQr().solve, :664)
+__device__ __forceinline__ void colpiv_qr_5x3(double A[5][3], double b[5], double x[3]) {
+    int perm[3] = {0, 1, 2};
+    double rdiag[3] = {0, 0, 0};
+    double maxpivot = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int best = k;
+        double bestn = -1;
+        for (int j = k; j < 3; ++j) {
+            double s = 0;
+            for (int i = k; i < 5; ++i) s += A[i][j] * A[i][j];
+            if (s > bestn) bestn = s, best = j;
+        }
+        if (best != k) {
+            for (int i = 0; i < 5; ++i) {
+                const double t = A[i][k];
+                A[i][k] = A[i][best];
+                A[i][best] = t;
+            }
+            const int t = perm[k];
+            perm[k] = perm[best];
+            perm[best] = t;
+        }
+        double tail = 0;
+        for (int i = k + 1; i < 5; ++i) tail += A[i][k] * A[i][k];
+        const double c0 = A[k][k];
+        double tau, beta;
+        if (tail <= 2.2250738585072014e-308) {
+            tau = 0, beta = c0;
+            for (int i = k + 1; i < 5; ++i) A[i][k] = 0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0) beta = -beta;
+            for (int i = k + 1; i < 5; ++i) A[i][k] /= (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        A[k][k] = beta;
+        rdiag[k] = beta;
+        maxpivot = fmax(maxpivot, fabs(beta));
+        if (tau != 0) {
+            for (int c = k + 1; c < 3; ++c) {
+                double s = A[k][c];
+                for (int i = k + 1; i < 5; ++i) s += A[i][k] * A[i][c];
+                s *= tau;
+                A[k][c] -= s;
+                for (int i = k + 1; i < 5; ++i) A[i][c] -= s * A[i][k];
+            }
+            double s = b[k];
+            for (int i = k + 1; i < 5; ++i) s += A[i][k] * b[i];
+            s *= tau;
+            b[k] -= s;
+            for (int i = k + 1; i < 5; ++i) b[i] -= s * A[i][k];
+        }
+    }
+    const double thr = 2.220446049250313e-16 * 3.0 * maxpivot;
+    int rank = 0;
+    for (int k = 0; k < 3; ++k)
+        if (fabs(rdiag[k]) > thr) ++rank;
+    double y[3] = {0, 0, 0};
+    for (int k = rank - 1; k >= 0; --k) {
+        double s = b[k];
+        for (int c = k + 1; c < rank; ++c) s -= A[k][c] * y[c];
+        y[k] = s / A[k][k];
+    }
+    x[0] = x[1] = x[2] = 0;
+    for (int k = 0; k < 3; ++k) x[perm[k]] = y[k];
+}
+
+// pointAssociateToMap (:155-164): f64 rotate + translate, stored back as f32
+__device__ __forceinline__ void associate_to_map(const double* x7, float px, float py, float pz, float* o) {
+    double r[3];
+    quat_rotate(x7, static_cast<double>(px), static_cast<double>(py), static_cast<double>(pz), r);
+    o[0] = static_cast<float>(r[0] + x7[4]);
+    o[1] = static_cast<float>(r[1] + x7[5]);
+    o[2] = static_cast<float>(r[2] + x7[6]);
+}
+
+// slots [0, n_corner_stack): edge candidates; [n_corner_stack, n_corner_stack + n_surf_stack): plane candidates
+__global__ void __launch_bounds__(128) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
+                                               GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
+                                               const LMState* __restrict__ st, MapCounters* C, int outer, FactorSoA f) {
+    if (!C->solve_on) return;
+    const int nc = C->n_corner_stack, ns = C->n_surf_stack;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc + ns) return;
+    double x7[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+    const bool is_edge = i < nc;
+    const int j = is_edge ? i : i - nc;
+    const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
+    float sel[3];
+    associate_to_map(x7, ox, oy, oz, sel);
+    Knn5 nn;
+    if (is_edge)
+        knn5(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], nn);
+    else
+        knn5(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], nn);
+    int valid = 0;
+    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+    if (static_cast<double>(nn.d[4]) < 1.0) {  // :585 / :653
+        if (is_edge) {
+            double cx = 0, cy = 0, cz = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) cx = cx + nn.px[k], cy = cy + nn.py[k], cz = cz + nn.pz[k];  // :594
+            cx = cx / 5.0, cy = cy / 5.0, cz = cz / 5.0;
+            double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {  // raw scatter sum, not divided (:599-604)
+                const double zx = nn.px[k] - cx, zy = nn.py[k] - cy, zz = nn.pz[k] - cz;
+                m00 = m00 + zx * zx, m01 = m01 + zx * zy, m02 = m02 + zx * zz;
+                m11 = m11 + zy * zy, m12 = m12 + zy * zz, m22 = m22 + zz * zz;
+            }
+            double w1, w2, dir[3];
+            eig3_largest(m00, m01, m02, m11, m12, m22, &w1, &w2, dir);
+            if (w2 > 3 * w1) {  // :612
+                valid = 1;
+                pa[0] = 0.1 * dir[0] + cx, pa[1] = 0.1 * dir[1] + cy, pa[2] = 0.1 * dir[2] + cz;     // :616
+                pb[0] = -0.1 * dir[0] + cx, pb[1] = -0.1 * dir[1] + cy, pb[2] = -0.1 * dir[2] + cz;  // :617
+            }
+        } else {
+            double A[5][3], b[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) A[k][0] = nn.px[k], A[k][1] = nn.py[k], A[k][2] = nn.pz[k], b[k] = -1.0;
+            double nv[3];
+            colpiv_qr_5x3(A, b, nv);
+            const double nrm = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+            const double d = 1 / nrm;  // negative_OA_dot_norm (:665)
+            nv[0] /= nrm, nv[1] /= nrm, nv[2] /= nrm;
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (fabs(nv[0] * nn.px[k] + nv[1] * nn.py[k] + nv[2] * nn.pz[k] + d) > 0.2) ok = false;  // :673-676
+            if (ok && nrm == nrm) {
+                valid = 1;
+                pa[0] = nv[0], pa[1] = nv[1], pa[2] = nv[2];
+                pb[0] = d;
+            }
+        }
+    }
+    f.valid[i] = valid;
+    f.kind[i] = is_edge ? 0 : 2;
+    f.cp[i] = ox, f.cp[f.cap + i] = oy, f.cp[2 * f.cap + i] = oz;
+    f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
+    f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
+    const uint64_t be = __ballot(valid && is_edge), bp = __ballot(valid && !is_edge);
+    if (lane_id() == 0) {
+        if (be) atomicAdd(&C->n_edge[outer], __popcll(be));
+        if (bp) atomicAdd(&C->n_plane[outer], __popcll(bp));
+        if (be | bp) atomicAdd(&C->n_live, __popcll(be | bp));
+    }
+}
+
+__global__ void k_counts_after_stack(MapCounters* C, int cap) {
+    C->n_slots = min(C->n_corner_stack + C->n_surf_stack, cap);
+}
+__global__ void k_outer_begin(MapCounters* C, int outer) {
+    C->n_live = 0;
+    C->n_edge[outer] = 0, C->n_plane[outer] = 0;
+}
+__global__ void k_outer_end(MapCounters* C, const LMState* st, int outer) {
+    C->lm_iters[outer] = st->enabled ? st->iteration : 0;
+    C->lm_success[outer] = st->enabled ? st->successful : 0;
+    C->cost_init[outer] = st->enabled ? st->cost_init : 0.0;
+    C->cost_final[outer] = st->enabled ? st->cost_final : 0.0;
+}
+__global__ void k_set_pose(LMState* st, const double* x7) {
+    if (threadIdx.x < 7) st->x[threadIdx.x] = x7[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------- insert + re-filter
+// appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
+//   key layout: [cube index 13 bits][no-merge 1][vz 9][vy 9][vx 9]; dropped points get ~0
+__global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA4 stack, const int* __restrict__ d_nstack, const LMState* __restrict__ st,
+                                                     MapParams mp, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
+                                                     int* __restrict__ vals, MapCounters* C, int cls) {
+    const int ns = *d_nstack;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        C->n_total[cls] = min(n_old + ns, cap);
+        if (n_old + ns > cap) C->error = SCAL_E_CAPACITY;
+    }
+    if (i >= n_old + ns || i >= cap) return;
+    float x, y, z;
+    int pc;
+    if (i < n_old) {
+        x = m.x[i], y = m.y[i], z = m.z[i], pc = m.cube[i];
+    } else {
+        const int j = i - n_old;
+        double x7[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+        float sel[3];
+        associate_to_map(x7, stack.x[j], stack.y[j], stack.z[j], sel);  // :740 / :764
+        x = sel[0], y = sel[1], z = sel[2];
+        pc = pack_cube(cube_abs(x) , cube_abs(y), cube_abs(z));
+        // cube_abs already excludes cen; see unpack below
+        m.x[i] = x, m.y[i] = y, m.z[i] = z, m.w[i] = stack.w[j], m.cube[i] = pc;
+    }
+    int ai, aj, ak;
+    unpack_cube(pc, ai, aj, ak);
+    const int I = ai + mp.cenW, J = aj + mp.cenH, K = ak + mp.cenD;
+    unsigned long long k;
+    if (I < 0 || I >= CW || J < 0 || J >= CH || K < 0 || K >= CD) {
+        k = ~0ull;  // outside the 21x21x11 window: cleared slab (:346-347 ...) or rejected insert (:753-759)
+    } else {
+        const unsigned long long cidx = static_cast<unsigned long long>(I + CW * J + CW * CH * K);
+        if (abs(I - mp.cI) <= 2 && abs(J - mp.cJ) <= 2 && abs(K - mp.cK) <= 1) {
+            // voxel coordinates relative to one cell below the cube's lower face; lexicographic (vz,vy,vx) order equals
+            // PCL's idx order inside the cube
+            const int bx = static_cast<int>(floorf((50.0f * ai - 26.0f) * inv_leaf));
+            const int by = static_cast<int>(floorf((50.0f * aj - 26.0f) * inv_leaf));
+            const int bz = static_cast<int>(floorf((50.0f * ak - 26.0f) * inv_leaf));
+            int vx = static_cast<int>(floorf(x * inv_leaf)) - bx, vy = static_cast<int>(floorf(y * inv_leaf)) - by,
+                vz = static_cast<int>(floorf(z * inv_leaf)) - bz;
+            if (vx < 0 || vx > 511 || vy < 0 || vy > 511 || vz < 0 || vz > 511) C->error = SCAL_E_CAPACITY;
+            vx = min(max(vx, 0), 511), vy = min(max(vy, 0), 511), vz = min(max(vz, 0), 511);
+            k = (cidx << 28) | (static_cast<unsigned long long>(vz) << 18) | (static_cast<unsigned long long>(vy) << 9) | static_cast<unsigned long long>(vx);
+        } else {
+            k = (cidx << 28) | (1ull << 27);  // cube not re-filtered this scan: keep every point, arrival order
+        }
+    }
+    keys[i] = k;
+    vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_map_heads(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
+    const int n = *d_n;
+    const int nb = (n + 255) / 256;
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    __shared__ int s[17];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int head = 0;
+    if (i < n) {
+        const unsigned long long k = keys[i];
+        head = (k != ~0ull) && ((k & (1ull << 27)) || i == 0 || keys[i - 1] != k);
+    }
+    int total;
+    block_exclusive_scan(head, s, &total);
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) k_map_reduce(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+                                                    const int* __restrict__ d_n, const int* __restrict__ blockoff, MapCloud in, MapCloud out) {
+    const int n = *d_n;
+    const int nb = (n + 255) / 256;
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    __shared__ int s[17];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int head = 0;
+    unsigned long long k = 0;
+    if (i < n) {
+        k = keys[i];
+        head = (k != ~0ull) && ((k & (1ull << 27)) || i == 0 || keys[i - 1] != k);
+    }
+    int total;
+    const int rank = block_exclusive_scan(head, s, &total);
+    if (!head) return;
+    const int o = blockoff[blockIdx.x] + rank;
+    if (k & (1ull << 27)) {
+        const int g = vals[i];
+        out.x[o] = in.x[g], out.y[o] = in.y[g], out.z[o] = in.z[g], out.w[o] = in.w[g], out.cube[o] = in.cube[g];
+        return;
+    }
+    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+    int u = i;
+    while (u < n && keys[u] == k) {
+        const int g = vals[u];
+        ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
+        ++u;
+    }
+    const float c = static_cast<float>(u - i);
+    out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
+    out.cube[o] = in.cube[vals[i]];
+}
+
+__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, const LMState* __restrict__ st, SoA4 out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *d_n) return;
+    double x7[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+    float sel[3];
+    associate_to_map(x7, in.x[i], in.y[i], in.z[i], sel);
+    out.x[i] = sel[0], out.y[i] = sel[1], out.z[i] = sel[2], out.w[i] = in.w[i];
+}
+
+__global__ void __launch_bounds__(256) k_copy_soa(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
+    const int n = min(*d_n, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_n_out = n;
+    if (i < n) out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = in.w[i];
+}
+__global__ void __launch_bounds__(256) k_copy_aos(const float* __restrict__ aos, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
+    const int n = min(*d_n, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_n_out = n;
+    if (i < n) {
+        const float4 p = reinterpret_cast<const float4*>(aos)[i];
+        out.x[i] = p.x, out.y[i] = p.y, out.z[i] = p.z, out.w[i] = p.w;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_export_valid(MapCloud m, int n, MapParams mp, int* __restrict__ counter, float* __restrict__ out, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && cube_valid(mp, m.cube[i])) {
+        const int p = atomicAdd(counter, 1);
+        if (p < cap) reinterpret_cast<float4*>(out)[p] = make_float4(m.x[i], m.y[i], m.z[i], m.w[i]);
+    }
+}
+
+struct SoAStore {
+    DevBuf<float> x, y, z, w;
+    int alloc(size_t n) {
+        SCAL_TRY(x.alloc(n));
+        SCAL_TRY(y.alloc(n));
+        SCAL_TRY(z.alloc(n));
+        SCAL_TRY(w.alloc(n));
+        return SCAL_OK;
+    }
+    SoA4 v() { return SoA4{x.p, y.p, z.p, w.p}; }
+    CSoA4 cv() const { return CSoA4{x.p, y.p, z.p, w.p}; }
+};
+
+struct MapStore {
+    SoAStore pts[2];  // double buffered
+    DevBuf<int> cube[2];
+    int cur = 0;
+    int n = 0;  // host copy of the point count
+    MapCloud cloud(int b) { return MapCloud{pts[b].x.p, pts[b].y.p, pts[b].z.p, pts[b].w.p, cube[b].p}; }
+};
+
+struct GridStore {
+    DevBuf<int> cnt, start, rank;
+    SoAStore g;  // only x,y,z used
+    DevBuf<int> idx;
+    GridPts pts() { return GridPts{g.x.p, g.y.p, g.z.p, idx.p}; }
+};
+
+}  // namespace scal
+
+using namespace scal;
+
+struct scal_map {
+    scal_map_config cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    int scan_cap = 0, map_cap = 0, slot_cap = 0;
+    // host-side pose state (laserMapping.cpp:110-120)
+    double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};
+    int cenW = 10, cenH = 10, cenD = 5;  // :74-76
+    MapParams last_mp{};
+    bool have_mp = false;
+    // device
+    DevBuf<float> aos;  // upload staging
+    SoAStore corner_in, surf_in, full_in, full_out, corner_stack, surf_stack;
+    VoxelFilter vf;
+    MapStore map[2];  // corner, surf
+    GridStore grid[2];
+    RadixSort sorter;
+    DevBuf<unsigned long long> keys;
+    DevBuf<int> vals, blockcnt;
+    DevBuf<int> fvalid, fkind;
+    DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<LMState> d_st;
+    DevBuf<MapCounters> d_C;
+    DevBuf<double> d_x0;
+    DevBuf<int> d_nfull;
+    PinBuf<MapCounters> h_C;
+    PinBuf<LMState> h_st;
+    FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
+};
+
+extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
+    if (!cfg || !out || cfg->max_scan_points <= 0 || cfg->max_map_points <= 0 || !(cfg->line_res > 0) || !(cfg->plane_res > 0)) {
+        set_error("scal_map_create: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (cfg->line_res < 0.11f || cfg->plane_res < 0.11f) {
+        set_error("mapping resolutions below 0.11 m exceed the 512 voxel/cube key layout");
+        return SCAL_E_ARG;
+    }
+    *out = nullptr;
+    SCAL_TRY(select_device(cfg->device));
+    auto* c = new scal_map();
+    c->cfg = *cfg;
+    c->scan_cap = cfg->max_scan_points;
+    c->map_cap = cfg->max_map_points;
+    c->slot_cap = cfg->max_scan_points;
+    int rc = SCAL_OK;
+    auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
+    const size_t sc = c->scan_cap, mc = c->map_cap;
+    A(c->aos.alloc(sc * 4));
+    A(c->corner_in.alloc(sc)); A(c->surf_in.alloc(sc)); A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
+    A(c->corner_stack.alloc(sc)); A(c->surf_stack.alloc(sc));
+    A(c->vf.init(c->scan_cap));
+    for (int k = 0; k < 2; ++k) {
+        for (int b = 0; b < 2; ++b) {
+            A(c->map[k].pts[b].alloc(mc));
+            A(c->map[k].cube[b].alloc(mc));
+        }
+        A(c->grid[k].cnt.alloc(GCELLS)); A(c->grid[k].start.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
+        A(c->grid[k].g.x.alloc(mc)); A(c->grid[k].g.y.alloc(mc)); A(c->grid[k].g.z.alloc(mc)); A(c->grid[k].idx.alloc(mc));
+    }
+    A(c->sorter.init(c->map_cap));
+    A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
+    A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
+    A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
+    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
+    A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
+    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK) {
+        // the cell counters obey a zero invariant: every step clears exactly the cells it touched
+        for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cnt.zero(c->stream);
+        if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
+    }
+    if (rc != SCAL_OK) {
+        if (rc == SCAL_E_HIP) set_error("scal_map_create: HIP resource creation failed");
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return SCAL_OK;
+}
+
+extern "C" void scal_map_destroy(scal_map_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->ev) (void)hipEventDestroy(c->ev);
+    delete c;
+}
+
+namespace {
+
+// Eigen-equivalent host quaternion helpers, storage (x,y,z,w)
+void h_qmul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+void h_rot(const double* q, const double* v, double* o) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux, uy += uy, uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
+}
+
+// everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C
+int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, double* q_out, double* t_out, scal_map_stats* stats) {
+    hipStream_t s = c->stream;
+    // transformAssociateToMap (:143-147)
+    double x0[8] = {0};
+    h_qmul(c->q_wmap_wodom, q_wodom, x0);
+    double rt[3];
+    h_rot(c->q_wmap_wodom, t_wodom, rt);
+    x0[4] = rt[0] + c->t_wmap_wodom[0], x0[5] = rt[1] + c->t_wmap_wodom[1], x0[6] = rt[2] + c->t_wmap_wodom[2];
+    // :313-322
+    int cI = int((x0[4] + 25.0) / 50.0) + c->cenW, cJ = int((x0[5] + 25.0) / 50.0) + c->cenH, cK = int((x0[6] + 25.0) / 50.0) + c->cenD;
+    if (x0[4] + 25.0 < 0) cI--;
+    if (x0[5] + 25.0 < 0) cJ--;
+    if (x0[6] + 25.0 < 0) cK--;
+    // :324-508 — the pointer shuffles become offset updates; the cleared slabs are dropped by k_insert_keys
+    while (cI < 3) cI++, c->cenW++;
+    while (cI >= CW - 3) cI--, c->cenW--;
+    while (cJ < 3) cJ++, c->cenH++;
+    while (cJ >= CH - 3) cJ--, c->cenH--;
+    while (cK < 3) cK++, c->cenD++;
+    while (cK >= CD - 3) cK--, c->cenD--;
+    MapParams mp;
+    mp.cenW = c->cenW, mp.cenH = c->cenH, mp.cenD = c->cenD;
+    mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
+    mp.ox = 50 * (cI - 2 - c->cenW) - 25, mp.oy = 50 * (cJ - 2 - c->cenH) - 25, mp.oz = 50 * (cK - 1 - c->cenD) - 25;
+    mp.inv_line = 1.0f / c->cfg.line_res, mp.inv_plane = 1.0f / c->cfg.plane_res;
+    c->last_mp = mp;
+    c->have_mp = true;
+
+    MapCounters* C = c->d_C.p;
+    LMState* st = c->d_st.p;
+    SCAL_HIP(hipMemcpyAsync(c->d_x0.p, x0, sizeof(double) * 7, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st, c->d_x0.p);
+
+    // stack downsample (:543-551); 12 bits per axis: up to 4096 cells of the leaf size
+    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, c->cfg.line_res, 12, c->corner_stack.v(), &C->n_corner_stack));
+    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, c->cfg.plane_res, 12, c->surf_stack.v(), &C->n_surf_stack));
+    hipLaunchKernelGGL(k_counts_after_stack, dim3(1), dim3(1), 0, s, C, c->slot_cap);
+
+    // cell grids over the valid cubes
+    for (int k = 0; k < 2; ++k) {
+        MapStore& M = c->map[k];
+        GridStore& G = c->grid[k];
+        const int nb = std::max(1, div_up(M.n, 256));
+        MapCloud mc = M.cloud(M.cur);
+        hipLaunchKernelGGL(k_grid_count, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.cnt.p, G.rank.p, C, k);
+        hipLaunchKernelGGL(k_grid_alloc, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.cnt.p, G.rank.p, G.start.p, C, k);
+        hipLaunchKernelGGL(k_grid_fill, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.rank.p, G.start.p, G.pts());
+    }
+    // two outer iterations (:563)
+    FactorSoA F = c->factors();
+    const int slot_blocks = std::max(1, div_up(c->slot_cap, 256));
+    const int assoc_blocks = std::max(1, div_up(c->slot_cap, 128));
+    for (int outer = 0; outer < 2; ++outer) {
+        hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, C, outer);
+        hipLaunchKernelGGL(k_assoc, dim3(assoc_blocks), dim3(128), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p, c->grid[0].start.p,
+                           c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, outer, F);
+        hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->solve_on, &C->n_live);
+        hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
+        hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);
+        for (int it = 0; it < 4; ++it) {
+            hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 1, c->partials.p);
+            hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 1);
+        }
+        hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
+    }
+    // restore the zero invariant of the cell counters
+    for (int k = 0; k < 2; ++k) {
+        MapStore& M = c->map[k];
+        const int nb = std::max(1, div_up(M.n, 256));
+        hipLaunchKernelGGL(k_grid_clear, dim3(nb), dim3(256), 0, s, M.cloud(M.cur), M.n, mp, c->grid[k].rank.p, c->grid[k].cnt.p);
+    }
+    // insert + re-filter (:738-802)
+    for (int k = 0; k < 2; ++k) {
+        MapStore& M = c->map[k];
+        const int n_new_max = k == 0 ? c->scan_cap : c->scan_cap;
+        const int n_tot_max = std::min(c->map_cap, M.n + n_new_max);
+        const int nb = std::max(1, div_up(n_tot_max, 256));
+        MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
+        const CSoA4 stack = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
+        const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
+                           c->keys.p, c->vals.p, C, k);
+        unsigned long long* sk;
+        int* sv;
+        SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], 0, 48, &sk, &sv));
+        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sk, &C->n_total[k], c->blockcnt.p);
+        launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
+        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sk, sv, &C->n_total[k], c->blockcnt.p, in, outc);
+        M.cur ^= 1;
+    }
+    if (have_full) {
+        const int nb = std::max(1, div_up(c->scan_cap, 256));
+        hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, st, c->full_out.v());
+    }
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    const MapCounters& H = *c->h_C.p;
+    for (int k = 0; k < 2; ++k) c->map[k].n = H.n_map_new[k];
+    if (H.error) {
+        set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
+        return H.error;
+    }
+    const double* xf = c->h_st.p->x;
+    for (int i = 0; i < 4; ++i) q_out[i] = xf[i];
+    for (int i = 0; i < 3; ++i) t_out[i] = xf[4 + i];
+    {  // transformUpdate (:149-153): q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
+        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
+        const double qi[4] = {-q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2};
+        h_qmul(xf, qi, c->q_wmap_wodom);
+        double r2[3];
+        h_rot(c->q_wmap_wodom, t_wodom, r2);
+        for (int i = 0; i < 3; ++i) c->t_wmap_wodom[i] = xf[4 + i] - r2[i];
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->n_corner_stack = H.n_corner_stack, stats->n_surf_stack = H.n_surf_stack;
+        stats->n_corner_map = H.n_valid[0], stats->n_surf_map = H.n_valid[1];
+        for (int o = 0; o < 2; ++o) {
+            stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
+            stats->lm_iters[o] = H.lm_iters[o], stats->lm_success[o] = H.lm_success[o];
+            stats->cost_init[o] = H.cost_init[o], stats->cost_final[o] = H.cost_final[o];
+        }
+        stats->solved = H.solve_on;
+        stats->n_map_corner_total = H.n_map_new[0], stats->n_map_surf_total = H.n_map_new[1];
+    }
+    return SCAL_OK;
+}
+
+int reset_counters(scal_map* c, int n_corner, int n_surf, int n_full) {
+    MapCounters z;
+    std::memset(&z, 0, sizeof z);
+    z.n_corner_in = n_corner, z.n_surf_in = n_surf;
+    *c->h_C.p = z;
+    SCAL_HIP(hipMemcpyAsync(c->d_C.p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, c->stream));
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, &n_full, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    return SCAL_OK;
+}
+
+}  // namespace
+
+extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corner, const float* surf_last, int n_surf, const float* full_res,
+                             int n_full, const double* q_wodom, const double* t_wodom, double* q_w_curr, double* t_w_curr, float* registered,
+                             scal_map_stats* stats) {
+    if (!c || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr || n_corner < 0 || n_surf < 0 || n_full < 0 || (n_corner > 0 && !corner_last) ||
+        (n_surf > 0 && !surf_last)) {
+        set_error("scal_map_step: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_corner > c->scan_cap || n_surf > c->scan_cap || n_full > c->scan_cap) {
+        set_error("scal_map_step: input cloud larger than max_scan_points (%d)", c->scan_cap);
+        return SCAL_E_TOO_MANY;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const bool have_full = full_res != nullptr && n_full > 0;
+    int nf = have_full ? n_full : 0;
+    // n_full lives in pinned-less host memory for the async copy: stage through the counters struct instead
+    SCAL_TRY(reset_counters(c, n_corner, n_surf, nf));
+    SCAL_HIP(hipStreamSynchronize(s));  // &nf must not be read after return
+    auto up = [&](const float* src, int n, SoAStore& dst) -> int {
+        if (n > 0) {
+            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            launch_deinterleave(s, c->aos.p, n, dst.v());
+        }
+        return SCAL_OK;
+    };
+    SCAL_TRY(up(corner_last, n_corner, c->corner_in));
+    SCAL_TRY(up(surf_last, n_surf, c->surf_in));
+    if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
+    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, q_w_curr, t_w_curr, stats));
+    if (have_full && registered) {
+        launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
+        SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+    }
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom, double* q_w_curr,
+                                      double* t_w_curr, scal_map_stats* stats) {
+    if (!c || !feat || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr) {
+        set_error("scal_map_step_features: null argument");
+        return SCAL_E_ARG;
+    }
+    FeatDeviceView v = features_view(feat);
+    if (v.device != c->cfg.device) {
+        set_error("features context lives on device %d, map context on %d", v.device, c->cfg.device);
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_TRY(reset_counters(c, 0, 0, 0));
+    SCAL_HIP(hipStreamSynchronize(s));
+    // order after the feature extraction stream
+    SCAL_HIP(hipEventRecord(c->ev, v.stream));
+    SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
+    MapCounters* C = c->d_C.p;
+    // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563), full-res = ordered cloud
+    const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
+    hipLaunchKernelGGL(k_copy_aos, dim3(std::max(1, div_up(ls_cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp, c->corner_in.v(),
+                       &C->n_corner_in, c->scan_cap);
+    const int cap = std::min(c->scan_cap, v.cap);
+    hipLaunchKernelGGL(k_copy_soa, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat,
+                       c->surf_in.v(), &C->n_surf_in, c->scan_cap);
+    hipLaunchKernelGGL(k_copy_soa, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->full_in.v(),
+                       c->d_nfull.p, c->scan_cap);
+    return run_step(c, q_wodom, t_wodom, true, q_w_curr, t_w_curr, stats);
+}
+
+extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int cap) {
+    if (!c || (which != 0 && which != 1) || cap < 0) {
+        set_error("scal_map_export: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->have_mp || c->map[which].n == 0) return 0;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    MapStore& M = c->map[which];
+    int zero = 0;
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p + 1, &zero, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    const int room = std::min(cap, c->scan_cap);
+    hipLaunchKernelGGL(k_export_valid, dim3(std::max(1, div_up(M.n, 256))), dim3(256), 0, s, M.cloud(M.cur), M.n, c->last_mp, c->d_nfull.p + 1, c->aos.p,
+                       out_xyzi ? room : 0);
+    int n = 0;
+    SCAL_HIP(hipMemcpyAsync(&n, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    if (out_xyzi && room > 0) {
+        const int m = std::min(n, room);
+        SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+        return m;
+    }
+    return n;
+}
+
+extern "C" int scal_map_get_wmap_wodom(scal_map_t* c, double* q, double* t) {
+    if (!c || !q || !t) return SCAL_E_ARG;
+    for (int i = 0; i < 4; ++i) q[i] = c->q_wmap_wodom[i];
+    for (int i = 0; i < 3; ++i) t[i] = c->t_wmap_wodom[i];
+    return SCAL_OK;
+}

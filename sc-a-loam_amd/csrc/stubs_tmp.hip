@@ -3,12 +3,6 @@
 using namespace scal;
 #define NI(name) set_error(#name ": not implemented yet"); return SCAL_E_STATE;
 extern "C" {
-int scal_map_create(const scal_map_config*, scal_map_t**) { NI(scal_map_create) }
-void scal_map_destroy(scal_map_t*) {}
-int scal_map_step(scal_map_t*, const float*, int, const float*, int, const float*, int, const double*, const double*, double*, double*, float*, scal_map_stats*) { NI(scal_map_step) }
-int scal_map_step_features(scal_map_t*, scal_features_t*, const double*, const double*, double*, double*, scal_map_stats*) { NI(scal_map_step_features) }
-int scal_map_export(scal_map_t*, int, float*, int) { NI(scal_map_export) }
-int scal_map_get_wmap_wodom(scal_map_t*, double*, double*) { NI(scal_map_get_wmap_wodom) }
 int scal_odom_create(const scal_odom_config*, scal_odom_t**) { NI(scal_odom_create) }
 void scal_odom_destroy(scal_odom_t*) {}
 int scal_odom_step(scal_odom_t*, const float*, int, const float*, int, const float*, int, const float*, int, double*, double*, double*, double*, scal_odom_stats*) { NI(scal_odom_step) }
