@@ -136,9 +136,10 @@ __device__ __forceinline__ void factor_accumulate(int kind, const double* cp, co
     for (int r = 0; r < nr; ++r) s += res[r] * res[r];
     // HuberLoss(0.1): rho = s | 2a sqrt(s) - a^2 ; rho' = 1 | a / sqrt(s); rho'' <= 0 => scale rows by sqrt(rho')
     double rho0, rho1;
-    if (s > 0.01) {
+    const double huber_a = 0.1, huber_b = huber_a * huber_a;  // HuberLoss(a): b_ = a*a = 0.010000000000000002
+    if (s > huber_b) {
         const double rt = sqrt(s);
-        rho0 = 2.0 * 0.1 * rt - 0.01;
+        rho0 = 2.0 * huber_a * rt - huber_b;
         rho1 = fmax(2.2250738585072014e-308, 0.1 / rt);
     } else {
         rho0 = s, rho1 = 1.0;
@@ -158,7 +159,7 @@ __device__ __forceinline__ void factor_accumulate(int kind, const double* cp, co
 constexpr int LM_NACC = 28;
 
 // which = 0: evaluate at st->x (iteration zero), 1: at st->cand
-__global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
+static __global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
                                                  double* __restrict__ partials) {
     __shared__ double red[4][LM_NACC];
     const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
@@ -266,7 +267,7 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 }
 
 // One wave.  phase 0: partials hold the evaluation at x (iteration zero).  phase 1: at the candidate.
-__global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double* __restrict__ partials, const int* __restrict__ d_nslots, int cap,
+static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double* __restrict__ partials, const int* __restrict__ d_nslots, int cap,
                                                 int phase) {
     __shared__ double tot[LM_NACC];
     if (!st->enabled || st->done) return;
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double* __res
 }
 
 // (re)arm the solver at the pose currently in st->x.  enabled = 0 turns the whole chain into no-ops.
-__global__ void k_lm_reset(LMState* st, const int* __restrict__ d_enable, const int* __restrict__ d_live_count) {
+static __global__ void k_lm_reset(LMState* st, const int* __restrict__ d_enable, const int* __restrict__ d_live_count) {
     if (threadIdx.x != 0) return;
     st->radius = 1e4, st->decrease_factor = 2.0;
     st->iteration = 0, st->done = 0, st->successful = 0, st->started = 0, st->termination = 0;

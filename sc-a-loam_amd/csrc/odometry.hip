@@ -1,0 +1,435 @@
+// Stage B on gfx950: scan-to-scan odometry.  Replaces the main-loop body of /root/reference/src/laserOdometry.cpp
+// (:267-291 problem set-up, :299-384 edge correspondences, :387-483 plane correspondences, :494-506 solve and pose
+// integration, :554-568 hand-over of the lessSharp / lessFlat clouds).  DISTORTION is 0 (:59): s == 1 everywhere.
+//
+// Kernels (one stream; one host sync per scan for the pose read-back):
+//   k_odom_assoc   one WAVE per query point (sharp then flat).  TransformToStart (:111-129) in f64 -> f32.
+//                  The kd-tree NN(1) (:302, :390) is an exact brute-force argmin over the previous scan's cloud
+//                  (<= 6k corner / <= 60k surf points, 64 lanes striding, f32 ((dx^2+dy^2)+dz^2), ties -> lower
+//                  index); the reference's sequential walks over neighbouring rings (:312-361, :402-455) become
+//                  chunked wave scans: ballots find the first index past +-2.5 rings, and a 64-bit
+//                  (distance bits, visit order) key reproduces "first strictly smaller wins".
+//   lm_dev.hpp     the Ceres-equivalent solve, state persists across scans (para_q / para_t, :97-101).
+// Clouds are SoA x[] y[] z[] intensity[] in HBM; intensity carries the ring id in its integer part (:308).
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "voxel_dev.hpp"
+#include "lm_dev.hpp"
+#include "features_dev.hpp"
+#include <cmath>
+#include <algorithm>
+
+namespace scal {
+
+struct OdomCounters {
+    int n_sharp, n_flat, n_corner_last, n_surf_last;
+    int n_slots, n_live, enable;
+    int n_edge[2], n_plane[2];
+    int lm_iters[2], lm_success[2];
+    double cost_init[2], cost_final[2];
+    int n_less_sharp, n_less_flat;
+};
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    // (a.x-b.x)*(a.x-b.x) + (a.y-b.y)*(a.y-b.y) + (a.z-b.z)*(a.z-b.z), all f32 (:322-327)
+    return (ax - bx) * (ax - bx) + (ay - by) * (ay - by) + (az - bz) * (az - bz);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float d, unsigned seq) {
+    return (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | seq;
+}
+
+// one wave per query
+__global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st, OdomCounters* C,
+                                                    int outer, FactorSoA f) {
+    if (!C->enable) return;
+    const int ns = C->n_sharp, nf = C->n_flat;
+    const int q = blockIdx.x * 4 + wave_id();
+    if (q >= ns + nf || q >= f.cap) return;
+    const int lane = lane_id();
+    const bool is_edge = q < ns;
+    const int j = is_edge ? q : q - ns;
+    const CSoA4& Q = is_edge ? sharp : flat;
+    const CSoA4& T = is_edge ? CL : SL;
+    const int nT = is_edge ? C->n_corner_last : C->n_surf_last;
+    double x7[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+    const float ox = Q.x[j], oy = Q.y[j], oz = Q.z[j];
+    // TransformToStart: q_last_curr * p + t_last_curr in f64, stored to f32 (:120-127)
+    double r[3];
+    quat_rotate(x7, static_cast<double>(ox), static_cast<double>(oy), static_cast<double>(oz), r);
+    const float sx = static_cast<float>(r[0] + 1.0 * x7[4]), sy = static_cast<float>(r[1] + 1.0 * x7[5]), sz = static_cast<float>(r[2] + 1.0 * x7[6]);
+
+    // ---- NN(1): exact argmin of FLANN's L2_Simple<float>
+    unsigned long long best = ~0ull;
+    for (int t = lane; t < nT; t += 64) {
+        const float dx = sx - T.x[t], dy = sy - T.y[t], dz = sz - T.z[t];
+        float d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        const unsigned long long k = make_key(d, static_cast<unsigned>(t));
+        best = k < best ? k : best;
+    }
+    best = wave_min_u64(best);
+    int valid = 0;
+    int kind = is_edge ? 0 : 1;
+    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+    const float nnd = __uint_as_float(static_cast<unsigned>(best >> 32));
+    if (best != ~0ull && static_cast<double>(nnd) < 25.0) {  // DISTANCE_SQ_THRESHOLD (:65, :305, :393)
+        const int c = static_cast<int>(best & 0xffffffffu);
+        const int id = static_cast<int>(T.w[c]);  // closestPointScanID = int(intensity) (:308, :398)
+        unsigned long long k2 = ~0ull, k3 = ~0ull;
+        // ---- towards increasing index
+        for (int base = c + 1; base < nT; base += 64) {
+            const int t = base + lane;
+            const bool in = t < nT;
+            int rj = 0;
+            if (in) rj = static_cast<int>(T.w[t]);
+            const bool stop = in && (static_cast<double>(rj) > static_cast<double>(id) + 2.5);  // NEARBY_SCAN (:319, :405)
+            const uint64_t sm = __ballot(stop);
+            const int first = sm ? __ffsll(static_cast<long long>(sm)) - 1 : 64;
+            if (in && lane < first) {
+                const float d = sqdist(T.x[t], T.y[t], T.z[t], sx, sy, sz);
+                if (static_cast<double>(d) < 25.0) {
+                    const unsigned seq = static_cast<unsigned>(t - c - 1);
+                    if (is_edge) {
+                        if (rj > id) k2 = min(k2, make_key(d, seq));  // skip same-or-lower ring (:315)
+                    } else {
+                        if (rj <= id) k2 = min(k2, make_key(d, seq));  // :416
+                        else k3 = min(k3, make_key(d, seq));           // :422
+                    }
+                }
+            }
+            if (sm) break;
+        }
+        // ---- towards decreasing index
+        for (int base = c - 1; base >= 0; base -= 64) {
+            const int t = base - lane;
+            const bool in = t >= 0;
+            int rj = 0;
+            if (in) rj = static_cast<int>(T.w[t]);
+            const bool stop = in && (static_cast<double>(rj) < static_cast<double>(id) - 2.5);  // :345, :433
+            const uint64_t sm = __ballot(stop);
+            const int first = sm ? __ffsll(static_cast<long long>(sm)) - 1 : 64;
+            if (in && lane < first) {
+                const float d = sqdist(T.x[t], T.y[t], T.z[t], sx, sy, sz);
+                if (static_cast<double>(d) < 25.0) {
+                    const unsigned seq = 0x40000000u + static_cast<unsigned>(c - 1 - t);  // visited after every upward candidate
+                    if (is_edge) {
+                        if (rj < id) k2 = min(k2, make_key(d, seq));  // skip same-or-higher ring (:341)
+                    } else {
+                        if (rj >= id) k2 = min(k2, make_key(d, seq));  // :444
+                        else k3 = min(k3, make_key(d, seq));           // :449
+                    }
+                }
+            }
+            if (sm) break;
+        }
+        k2 = wave_min_u64(k2);
+        k3 = wave_min_u64(k3);
+        auto decode = [&](unsigned long long k) {
+            const unsigned seq = static_cast<unsigned>(k & 0xffffffffu);
+            return (seq & 0x40000000u) ? c - 1 - static_cast<int>(seq & 0x3fffffffu) : c + 1 + static_cast<int>(seq);
+        };
+        if (is_edge) {
+            if (k2 != ~0ull) {  // :363-383
+                const int i2 = decode(k2);
+                valid = 1;
+                pa[0] = T.x[c], pa[1] = T.y[c], pa[2] = T.z[c];
+                pb[0] = T.x[i2], pb[1] = T.y[i2], pb[2] = T.z[i2];
+            }
+        } else if (k2 != ~0ull && k3 != ~0ull) {  // :457-481
+            const int i2 = decode(k2), i3 = decode(k3);
+            valid = 1;
+            const double jx = T.x[c], jy = T.y[c], jz = T.z[c];
+            const double lx = T.x[i2], ly = T.y[i2], lz = T.z[i2];
+            const double mx = T.x[i3], my = T.y[i3], mz = T.z[i3];
+            // ljm_norm = (j - l) x (j - m), normalised (lidarFactor.hpp:64-65)
+            const double ax = jx - lx, ay = jy - ly, az = jz - lz, bx = jx - mx, by = jy - my, bz = jz - mz;
+            double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+            const double z = nx * nx + ny * ny + nz * nz;
+            if (z > 0) {
+                const double s = sqrt(z);
+                nx /= s, ny /= s, nz /= s;
+            }
+            pa[0] = jx, pa[1] = jy, pa[2] = jz;
+            pb[0] = nx, pb[1] = ny, pb[2] = nz;
+        }
+    }
+    if (lane == 0) {
+        f.valid[q] = valid;
+        f.kind[q] = kind;
+        f.cp[q] = ox, f.cp[f.cap + q] = oy, f.cp[2 * f.cap + q] = oz;
+        f.pa[q] = pa[0], f.pa[f.cap + q] = pa[1], f.pa[2 * f.cap + q] = pa[2];
+        f.pb[q] = pb[0], f.pb[f.cap + q] = pb[1], f.pb[2 * f.cap + q] = pb[2];
+        if (valid) {
+            atomicAdd(is_edge ? &C->n_edge[outer] : &C->n_plane[outer], 1);
+            atomicAdd(&C->n_live, 1);
+        }
+    }
+}
+
+__global__ void k_odom_outer_begin(OdomCounters* C, int outer, int cap) {
+    C->n_live = 0, C->n_edge[outer] = 0, C->n_plane[outer] = 0;
+    C->n_slots = min(C->n_sharp + C->n_flat, cap);
+}
+__global__ void k_odom_outer_end(OdomCounters* C, const LMState* st, int outer) {
+    C->lm_iters[outer] = st->enabled ? st->iteration : 0;
+    C->lm_success[outer] = st->enabled ? st->successful : 0;
+    C->cost_init[outer] = st->enabled ? st->cost_init : 0.0;
+    C->cost_final[outer] = st->enabled ? st->cost_final : 0.0;
+}
+__global__ void k_odom_init_pose(LMState* st) {
+    st->x[0] = st->x[1] = st->x[2] = 0.0, st->x[3] = 1.0;  // para_q = {0,0,0,1}, para_t = {0,0,0} (:97-98)
+    st->x[4] = st->x[5] = st->x[6] = 0.0;
+}
+__global__ void __launch_bounds__(256) k_odom_copy(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
+    const int n = min(*d_n, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_n_out = n;
+    if (i < n) out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = in.w[i];
+}
+__global__ void __launch_bounds__(256) k_odom_copy_aos(const float* __restrict__ aos, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out,
+                                                       int cap) {
+    const int n = min(*d_n, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_n_out = n;
+    if (i < n) {
+        const float4 p = reinterpret_cast<const float4*>(aos)[i];
+        out.x[i] = p.x, out.y[i] = p.y, out.z[i] = p.z, out.w[i] = p.w;
+    }
+}
+
+struct OSoA {
+    DevBuf<float> x, y, z, w;
+    int alloc(size_t n) {
+        SCAL_TRY(x.alloc(n));
+        SCAL_TRY(y.alloc(n));
+        SCAL_TRY(z.alloc(n));
+        SCAL_TRY(w.alloc(n));
+        return SCAL_OK;
+    }
+    SoA4 v() { return SoA4{x.p, y.p, z.p, w.p}; }
+    CSoA4 cv() const { return CSoA4{x.p, y.p, z.p, w.p}; }
+};
+
+}  // namespace scal
+
+using namespace scal;
+
+struct scal_odom {
+    scal_odom_config cfg;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    int cap = 0, feat_cap = 0, slot_cap = 0;
+    bool systemInited = false;
+    double q_w_curr[4] = {0, 0, 0, 1}, t_w_curr[3] = {0, 0, 0};  // :93-94
+    DevBuf<float> aos;
+    OSoA sharp, flat, less_sharp, less_flat;  // current scan
+    OSoA corner_last, surf_last;              // previous scan (kd-tree inputs, :567-568)
+    DevBuf<int> fvalid, fkind;
+    DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<LMState> d_st;
+    DevBuf<OdomCounters> d_C;
+    PinBuf<OdomCounters> h_C;
+    PinBuf<LMState> h_st;
+    FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
+};
+
+extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) {
+    if (!cfg || !out || cfg->max_points <= 0) {
+        set_error("scal_odom_create: bad argument");
+        return SCAL_E_ARG;
+    }
+    *out = nullptr;
+    SCAL_TRY(select_device(cfg->device));
+    auto* c = new scal_odom();
+    c->cfg = *cfg;
+    c->cap = cfg->max_points;
+    c->feat_cap = 120 * 64;  // lessSharp <= 20 per segment, 6 segments per ring (scanRegistration.cpp:314-328)
+    c->slot_cap = 36 * 64;   // sharp <= 2, flat <= 4 per segment
+    int rc = SCAL_OK;
+    auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
+    A(c->aos.alloc((size_t)c->cap * 4));
+    A(c->sharp.alloc(c->slot_cap)); A(c->flat.alloc(c->slot_cap));
+    A(c->less_sharp.alloc(c->feat_cap)); A(c->corner_last.alloc(c->feat_cap));
+    A(c->less_flat.alloc(c->cap)); A(c->surf_last.alloc(c->cap));
+    A(c->fvalid.alloc(c->slot_cap)); A(c->fkind.alloc(c->slot_cap));
+    A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
+    A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
+    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
+    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK) {
+        if (hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        hipLaunchKernelGGL(k_odom_init_pose, dim3(1), dim3(1), 0, c->stream, c->d_st.p);
+        if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
+    }
+    if (rc != SCAL_OK) {
+        if (rc == SCAL_E_HIP) set_error("scal_odom_create: HIP resource creation failed");
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return SCAL_OK;
+}
+
+extern "C" void scal_odom_destroy(scal_odom_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+    }
+    if (c->ev) (void)hipEventDestroy(c->ev);
+    delete c;
+}
+
+namespace {
+
+void o_qmul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+void o_rot(const double* q, const double* v, double* o) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux, uy += uy, uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
+}
+
+// inputs already in sharp / flat / less_sharp / less_flat with counts in d_C
+int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w, scal_odom_stats* stats) {
+    hipStream_t s = c->stream;
+    OdomCounters* C = c->d_C.p;
+    LMState* st = c->d_st.p;
+    FactorSoA F = c->factors();
+    const bool solve = c->systemInited;  // first frame: no optimisation (:267-271)
+    if (solve) {
+        const int slot_blocks = std::max(1, div_up(c->slot_cap, 256));
+        for (int outer = 0; outer < 2; ++outer) {  // :278
+            hipLaunchKernelGGL(k_odom_outer_begin, dim3(1), dim3(1), 0, s, C, outer, c->slot_cap);
+            hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
+                               c->surf_last.cv(), st, C, outer, F);
+            hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->enable, &C->n_live);
+            hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
+            hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);
+            for (int it = 0; it < 4; ++it) {
+                hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 1, c->partials.p);
+                hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 1);
+            }
+            hipLaunchKernelGGL(k_odom_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
+        }
+    }
+    // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets
+    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(c->feat_cap, 256))), dim3(256), 0, s, c->less_sharp.cv(), &C->n_less_sharp, c->corner_last.v(),
+                       &C->n_corner_last, c->feat_cap);
+    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, c->less_flat.cv(), &C->n_less_flat, c->surf_last.v(),
+                       &C->n_surf_last, c->cap);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    const double* x = c->h_st.p->x;
+    if (solve) {  // :504-505
+        double r[3];
+        o_rot(c->q_w_curr, x + 4, r);
+        for (int i = 0; i < 3; ++i) c->t_w_curr[i] = c->t_w_curr[i] + r[i];
+        double qn[4];
+        o_qmul(c->q_w_curr, x, qn);
+        for (int i = 0; i < 4; ++i) c->q_w_curr[i] = qn[i];
+    }
+    c->systemInited = true;
+    for (int i = 0; i < 4; ++i) q_lc[i] = x[i], q_w[i] = c->q_w_curr[i];
+    for (int i = 0; i < 3; ++i) t_lc[i] = x[4 + i], t_w[i] = c->t_w_curr[i];
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        if (solve) {
+            const OdomCounters& H = *c->h_C.p;
+            for (int o = 0; o < 2; ++o) {
+                stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
+                stats->lm_iters[o] = H.lm_iters[o], stats->lm_success[o] = H.lm_success[o];
+                stats->cost_init[o] = H.cost_init[o], stats->cost_final[o] = H.cost_final[o];
+            }
+        }
+    }
+    return SCAL_OK;
+}
+
+}  // namespace
+
+extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat,
+                              int n_flat, const float* less_flat, int n_less_flat, double* q_lc, double* t_lc, double* q_w, double* t_w,
+                              scal_odom_stats* stats) {
+    if (!c || !q_lc || !t_lc || !q_w || !t_w || n_sharp < 0 || n_less_sharp < 0 || n_flat < 0 || n_less_flat < 0 || (n_sharp && !sharp) ||
+        (n_less_sharp && !less_sharp) || (n_flat && !flat) || (n_less_flat && !less_flat)) {
+        set_error("scal_odom_step: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_sharp + n_flat > c->slot_cap || n_sharp > c->slot_cap || n_flat > c->slot_cap || n_less_sharp > c->feat_cap || n_less_flat > c->cap) {
+        set_error("scal_odom_step: cloud larger than the context capacity (sharp+flat <= %d, lessSharp <= %d, lessFlat <= %d)", c->slot_cap,
+                  c->feat_cap, c->cap);
+        return SCAL_E_TOO_MANY;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    OdomCounters& H = *c->h_C.p;
+    // keep the device-resident n_corner_last / n_surf_last, refresh the rest
+    const size_t head = offsetof(OdomCounters, n_corner_last);
+    H.n_sharp = n_sharp, H.n_flat = n_flat;
+    SCAL_HIP(hipMemcpyAsync(c->d_C.p, &H, head, hipMemcpyHostToDevice, s));
+    struct Tail {
+        int n_slots, n_live, enable;
+    } tail{0, 0, 1};
+    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_slots, &tail, sizeof tail, hipMemcpyHostToDevice, s));
+    int nls[2] = {n_less_sharp, n_less_flat};
+    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_less_sharp, nls, sizeof nls, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    auto up = [&](const float* src, int n, OSoA& dst) -> int {
+        if (n > 0) {
+            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            launch_deinterleave(s, c->aos.p, n, dst.v());
+        }
+        return SCAL_OK;
+    };
+    SCAL_TRY(up(sharp, n_sharp, c->sharp));
+    SCAL_TRY(up(flat, n_flat, c->flat));
+    SCAL_TRY(up(less_sharp, n_less_sharp, c->less_sharp));
+    SCAL_TRY(up(less_flat, n_less_flat, c->less_flat));
+    return odom_run(c, q_lc, t_lc, q_w, t_w, stats);
+}
+
+extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, double* q_lc, double* t_lc, double* q_w, double* t_w,
+                                       scal_odom_stats* stats) {
+    if (!c || !feat || !q_lc || !t_lc || !q_w || !t_w) {
+        set_error("scal_odom_step_features: null argument");
+        return SCAL_E_ARG;
+    }
+    FeatDeviceView v = features_view(feat);
+    if (v.device != c->cfg.device) {
+        set_error("features context lives on device %d, odometry context on %d", v.device, c->cfg.device);
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    struct Tail {
+        int n_slots, n_live, enable;
+    } tail{0, 0, 1};
+    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_slots, &tail, sizeof tail, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(hipEventRecord(c->ev, v.stream));
+    SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
+    OdomCounters* C = c->d_C.p;
+    const int nb_slot = std::max(1, div_up(c->slot_cap, 256)), nb_feat = std::max(1, div_up(c->feat_cap, 256));
+    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_slot), dim3(256), 0, s, v.sharp_xyzi, &v.P->n_sharp, c->sharp.v(), &C->n_sharp, c->slot_cap);
+    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_slot), dim3(256), 0, s, v.flat_xyzi, &v.P->n_flat, c->flat.v(), &C->n_flat, c->slot_cap);
+    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_feat), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp, c->less_sharp.v(), &C->n_less_sharp, c->feat_cap);
+    const int cap = std::min(c->cap, v.cap);
+    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat,
+                       c->less_flat.v(), &C->n_less_flat, c->cap);
+    return odom_run(c, q_lc, t_lc, q_w, t_w, stats);
+}

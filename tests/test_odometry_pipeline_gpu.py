@@ -1,0 +1,114 @@
+"""Stage B parity, the factor kernel against the oracle's autodiff, and the device-resident A->B->C->D pipeline."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_factor_kernel_vs_autodiff(O, S):
+    """k_lm_eval (analytic Jacobians, Huber, J^T J reduction) vs the oracle's forward-mode Jets + Ceres corrector."""
+    rng = np.random.default_rng(3)
+    n = 700
+    kind = rng.integers(0, 3, n).astype(np.int32)
+    cp = rng.uniform(-40, 40, (n, 3))
+    pa = rng.uniform(-40, 40, (n, 3))
+    pb = rng.uniform(-40, 40, (n, 3))
+    for i in range(n):
+        if kind[i] == 0:
+            pa[i] = cp[i] + rng.normal(0, 0.3, 3)
+            pb[i] = pa[i] + rng.normal(0, 0.2, 3)
+        elif kind[i] == 1:
+            pa[i] = cp[i] + rng.normal(0, 0.3, 3)
+            v = rng.normal(size=3)
+            pb[i] = v / np.linalg.norm(v)
+        else:
+            v = rng.normal(size=3)
+            pa[i] = v / np.linalg.norm(v)
+            pb[i] = [-(pa[i] @ cp[i]) + rng.normal(0, 0.2), 0, 0]
+    q = np.array([0.02, -0.01, 0.03, 0.999])  # deliberately not unit: the reference never normalises either
+    x = np.concatenate([q, [0.3, -0.2, 0.1]])
+    cost, g, H = S.factors_eval(kind, cp, pa, pb, x)
+    # oracle: per-block autodiff, plus-Jacobian, Huber corrector, sequential accumulation
+    P = np.array([[x[3], x[2], -x[1]], [-x[2], x[3], x[0]], [x[1], -x[0], x[3]], [-x[0], -x[1], -x[2]]])
+    c0, g0, H0 = 0.0, np.zeros(6), np.zeros((6, 6))
+    a = 0.1
+    for i in range(n):
+        r, J = O.factor_eval(int(kind[i]), cp[i], np.concatenate([pa[i], pb[i]]), x)
+        Jl = np.concatenate([J[:, :4] @ P, J[:, 4:]], axis=1)
+        s = float(r @ r)
+        if s > a * a:
+            rho0, rho1 = 2 * a * np.sqrt(s) - a * a, a / np.sqrt(s)
+        else:
+            rho0, rho1 = s, 1.0
+        c0 += 0.5 * rho0
+        g0 += rho1 * (Jl.T @ r)
+        H0 += rho1 * (Jl.T @ Jl)
+    assert abs(cost - c0) <= 1e-10 * c0
+    assert np.abs(g - g0).max() <= 1e-9 * np.abs(g0).max()
+    assert np.abs(H - H0).max() <= 1e-9 * np.abs(H0).max()
+
+
+def _stage_a(O, scans):
+    out = []
+    for xyz in scans:
+        f = O.features(xyz, O.HDL64, 5.0)
+        c = f["cloud"]
+        out.append(dict(sharp=c[f["sharp"]], less_sharp=c[f["less_sharp"]], flat=c[f["flat"]], less_flat=f["less_flat"], cloud=c))
+    return out
+
+
+def test_odometry_stream(O, S, hdl64_stream):
+    fa = _stage_a(O, [hdl64_stream(k) for k in range(8)])
+    oo = O.Odometry()
+    go = S.LaserOdometry(max_points=200000)
+    worst = 0.0
+    for k, f in enumerate(fa):
+        a = oo.step(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        b = go.step(f["sharp"], f["less_sharp"], f["flat"], f["less_flat"])
+        so, sg = a[4], b[4]
+        assert list(sg.n_edge) == list(so.n_edge) and list(sg.n_plane) == list(so.n_plane), (k, list(sg.n_edge), list(so.n_edge), list(sg.n_plane), list(so.n_plane))
+        assert list(sg.lm_iters) == list(so.lm_iters), k
+        for o in range(2):
+            assert abs(sg.cost_init[o] - so.cost_init[o]) <= 1e-9 * max(1.0, so.cost_init[o]), k
+        d = max(np.abs(a[i] - b[i]).max() for i in range(4))
+        worst = max(worst, d)
+        assert d <= 1e-7, (k, d)
+    print("worst odometry pose difference:", worst)
+    go.close()
+
+
+def test_device_resident_pipeline(O, S, hdl64_stream):
+    """A -> B -> C with every intermediate left in HBM (scal_*_step_features) must equal the host-array path."""
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
+    od_dev = S.LaserOdometry(max_points=200000)
+    mp_dev = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    od_host = S.LaserOdometry(max_points=200000)
+    mp_host = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    oo, om = O.Odometry(), O.Mapper(0.4, 0.8)
+    for k in range(6):
+        xyz = hdl64_stream(k)
+        f = reg.laserCloudHandler(xyz)  # leaves the device-resident results in the context too
+        qlc, tlc, qw, tw, st = od_dev.step_features(reg)
+        qm, tm, sm = mp_dev.process_features(reg, qw, tw)
+        c = f["cloud"]
+        h = od_host.step(c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
+        qh, th, sh, _ = mp_host.process(c[f["less_sharp"]], f["less_flat"], c, h[2], h[3])
+        assert np.array_equal(qw, h[2]) and np.array_equal(tw, h[3]), k
+        assert np.array_equal(qm, qh) and np.array_equal(tm, th), k
+        # and both equal the oracle chain on the same scan
+        fo = O.features(xyz, O.HDL64, 5.0)
+        co = fo["cloud"]
+        a = oo.step(co[fo["sharp"]], co[fo["less_sharp"]], co[fo["flat"]], fo["less_flat"])
+        qo, to, so, _ = om.step(co[fo["less_sharp"]], fo["less_flat"], co, a[2], a[3])
+        assert max(np.abs(qm - qo).max(), np.abs(tm - to).max()) <= 1e-6, k
+    for x in (reg, od_dev, mp_dev, od_host, mp_host):
+        x.close()
+
+
+def test_odometry_capacity_error(S):
+    go = S.LaserOdometry(max_points=1000)
+    z = np.zeros((5, 4), np.float32)
+    with pytest.raises(S.ScalError) as e:
+        go.step(z, z, z, np.zeros((2000, 4), np.float32))
+    assert e.value.code == S.E_TOO_MANY
+    go.close()
