@@ -41,6 +41,13 @@ const char* scal_last_error(void);
 /* number of visible HIP devices, -1 if the runtime cannot initialise */
 int scal_device_count(void);
 const char* scal_version(void);
+/* Optional per-kernel timing (HIP events on the launching stream), used by bench.py's roofline leg.
+ * No counterpart in the reference: its TicToc phase timers print nothing. */
+int scal_prof_enable(int on);
+int scal_prof_filter(const char* kernel_name); /* time only this kernel (NULL/"" = all instrumented kernels) */
+int scal_prof_reset(void);
+int scal_prof_read(const char* kernel_name, double* total_ms, long* count);
+int scal_prof_names(char* buf, int cap);
 
 /* ------------------------------------------------------------------ stage A: feature extraction
  * Replaces laserCloudHandler, src/scanRegistration.cpp:134-421 (NaN/range filter, ring id + relative
@@ -130,6 +137,14 @@ int scal_sc_insert_cloud_device(scal_sc_t* ctx, const float* d_x, const float* d
 /* saveScancontextAndKeys(desc): 20x60 doubles, column-major */
 int scal_sc_insert_descriptor(scal_sc_t* ctx, const double* desc_colmajor);
 int scal_sc_get_descriptor(scal_sc_t* ctx, int idx, double* desc_colmajor, float* ringkey20);
+/* keyframe cloud of a features context on the same device (its ordered full-resolution cloud, which is what
+ * /velodyne_cloud_registered_local carries) -> VoxelGrid 0.4 m (laserPosegraphOptimization.cpp:629-631, :890-891)
+ * -> makeAndSaveScancontextAndKeys (:639), nothing leaves the GPU. */
+int scal_sc_insert_features(scal_sc_t* ctx, scal_features_t* feat);
+/* same front end but the 20x60 descriptor is only written to d_desc (device memory, 1200 doubles, column-major)
+ * and NOT inserted: the sharded search exchanges descriptors first. */
+int scal_sc_make_features(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
+int scal_sc_insert_descriptor_device(scal_sc_t* ctx, const double* d_desc_colmajor);
 /* makeScancontext only (no insert) */
 int scal_sc_make_descriptor(scal_sc_t* ctx, const float* xyzi, int n, double* desc_colmajor);
 /* detectLoopClosureID(): query = newest keyframe; reproduces the >=31 gate, the 30-query tree period,
@@ -150,6 +165,8 @@ typedef struct {
     int pad;
 } scal_sc_cand;
 int scal_sc_shard_query(scal_sc_t* ctx, const double* query_desc_colmajor, int global_size_at_rebuild, scal_sc_cand out[3]);
+/* batched form on device pointers: d_queries [nq][1200] doubles, d_out [nq][3] records; synchronous */
+int scal_sc_shard_query_device(scal_sc_t* ctx, const double* d_queries, int nq, int global_size_at_rebuild, scal_sc_cand* d_out);
 int scal_sc_merge_candidates(const scal_sc_cand* gathered, int n_records, double dist_thres, scal_sc_result* res);
 
 /* ------------------------------------------------------------------ stage C: scan-to-map

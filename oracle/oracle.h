@@ -42,25 +42,6 @@ int orc_features_run(const OrcFeatureConfig* cfg, const float* xyz, int n, int s
 
 int orc_voxel_grid(const float* xyzi, int n, float leaf, int order_mode, float* out_xyzi, int* n_out, int* guard_hit);
 
-/* ---- synthetic scans ---- */
-typedef struct {
-    int sensor;        /* ORC_VLP16 / ORC_HDL64 / ORC_OS1_64 / ORC_HDL32 */
-    uint64_t seed;     /* world + noise seed */
-    int n_boxes, n_cyl;
-    double region[4];  /* xmin xmax ymin ymax of the object field */
-    double noise_sigma;
-    int threads;
-} OrcSynthConfig;
-void* orc_world_create(const OrcSynthConfig* cfg);
-void orc_world_destroy(void* w);
-/* trajectory pose of scan k (10 Hz, 10 m/s arc, yaw rate 0.1 rad/s, +-1 deg roll/pitch wobble): q xyzw, t */
-void orc_world_pose(void* w, int k, double* q_xyzw, double* t);
-/* ray-cast scan k; out_xyz capacity from orc_world_max_points(); returns number of points */
-int orc_world_max_points(void* w);
-int orc_world_scan(void* w, int k, float* out_xyz);
-/* same, from an explicit pose */
-int orc_world_scan_pose(void* w, const double* q_xyzw, const double* t, uint64_t noise_seed, float* out_xyz);
-
 /* ---- stage D: ScanContext ---- */
 typedef struct {
     double max_radius;   /* PC_MAX_RADIUS */

@@ -33,11 +33,6 @@ class FeatureOut(C.Structure):
                 ("n_less_flat", C.c_int), ("n_ties", C.c_int)]
 
 
-class SynthConfig(C.Structure):
-    _fields_ = [("sensor", C.c_int), ("seed", C.c_uint64), ("n_boxes", C.c_int), ("n_cyl", C.c_int),
-                ("region", C.c_double * 4), ("noise_sigma", C.c_double), ("threads", C.c_int)]
-
-
 class SCConfig(C.Structure):
     _fields_ = [("max_radius", C.c_double), ("dist_thres", C.c_double), ("float_math", C.c_int), ("cr_libm", C.c_int)]
 
@@ -70,13 +65,6 @@ def lib():
         L = C.CDLL(path)
         L.orc_features_run.argtypes = [C.POINTER(FeatureConfig), _f32p, C.c_int, C.c_int, C.POINTER(FeatureOut)]
         L.orc_voxel_grid.argtypes = [_f32p, C.c_int, C.c_float, C.c_int, _f32p, _i32p, _i32p]
-        L.orc_world_create.restype = C.c_void_p
-        L.orc_world_create.argtypes = [C.POINTER(SynthConfig)]
-        L.orc_world_destroy.argtypes = [C.c_void_p]
-        L.orc_world_pose.argtypes = [C.c_void_p, C.c_int, _f64p, _f64p]
-        L.orc_world_max_points.argtypes = [C.c_void_p]
-        L.orc_world_scan.argtypes = [C.c_void_p, C.c_int, _f32p]
-        L.orc_world_scan_pose.argtypes = [C.c_void_p, _f64p, _f64p, C.c_uint64, _f32p]
         L.orc_sc_create.restype = C.c_void_p
         L.orc_sc_create.argtypes = [C.POINTER(SCConfig)]
         L.orc_sc_destroy.argtypes = [C.c_void_p]
@@ -156,38 +144,6 @@ def voxel_grid(xyzi, leaf, order_mode=1):
     guard = C.c_int(0)
     lib().orc_voxel_grid(_p(xyzi, _f32p), n, C.c_float(leaf), order_mode, _p(out, _f32p), C.byref(n_out), C.byref(guard))
     return out[:n_out.value].copy(), guard.value
-
-
-# ---------------------------------------------------------------------------------------------- synthetic scans
-class World:
-    def __init__(self, sensor, seed, n_boxes=200, n_cyl=400, region=(-120.0, 220.0, -120.0, 260.0), noise_sigma=0.02, threads=0):
-        cfg = SynthConfig(sensor, seed, n_boxes, n_cyl, (C.c_double * 4)(*region), noise_sigma, threads)
-        self.h = lib().orc_world_create(C.byref(cfg))
-        self.sensor = sensor
-        self.cap = lib().orc_world_max_points(self.h)
-
-    def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_world_destroy(self.h)
-            self.h = None
-
-    def pose(self, k):
-        q = np.zeros(4)
-        t = np.zeros(3)
-        lib().orc_world_pose(self.h, k, _p(q, _f64p), _p(t, _f64p))
-        return q, t
-
-    def scan(self, k):
-        buf = np.zeros((self.cap, 3), np.float32)
-        n = lib().orc_world_scan(self.h, k, _p(buf, _f32p))
-        return buf[:n].copy()
-
-    def scan_pose(self, q, t, noise_seed):
-        buf = np.zeros((self.cap, 3), np.float32)
-        q = _f64(q)
-        t = _f64(t)
-        n = lib().orc_world_scan_pose(self.h, _p(q, _f64p), _p(t, _f64p), noise_seed, _p(buf, _f32p))
-        return buf[:n].copy()
 
 
 # ---------------------------------------------------------------------------------------------- stage D

@@ -41,7 +41,155 @@ int select_device(int device) {
     return SCAL_OK;
 }
 
+namespace {
+std::mutex g_stream_mu;
+struct DevStream {
+    hipStream_t s = nullptr;
+    int refs = 0;
+};
+DevStream g_streams[64];
+}  // namespace
+
+int acquire_stream(int device, hipStream_t* out) {
+    if (device < 0 || device >= 64) {
+        set_error("device ordinal %d out of range", device);
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    DevStream& d = g_streams[device];
+    if (!d.s) {
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            d.s = nullptr;
+            return SCAL_E_HIP;
+        }
+    }
+    d.refs++;
+    *out = d.s;
+    return SCAL_OK;
+}
+
+void release_stream(int device) {
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    DevStream& d = g_streams[device];
+    if (d.refs > 0 && --d.refs == 0 && d.s) {
+        (void)hipSetDevice(device);
+        (void)hipStreamSynchronize(d.s);
+        (void)hipStreamDestroy(d.s);
+        d.s = nullptr;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- event profiling
+namespace {
+struct ProfEntry {
+    std::string name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    long count = 0;
+};
+std::mutex g_prof_mu;
+std::vector<ProfEntry> g_prof;
+std::vector<hipEvent_t> g_event_pool;
+bool g_prof_on = false;
+std::string g_prof_filter;  // empty = every instrumented kernel
+
+hipEvent_t take_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void drain_entry(ProfEntry& p);
+void drain_locked() {
+    for (auto& p : g_prof) drain_entry(p);
+}
+void drain_entry(ProfEntry& p) {
+    {
+        for (auto& ev : p.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+                p.total_ms += ms;
+                p.count++;
+            }
+            g_event_pool.push_back(ev.first);
+            g_event_pool.push_back(ev.second);
+        }
+        p.pending.clear();
+    }
+}
+}  // namespace
+
+ProfScope::ProfScope(const char* name, hipStream_t stream) : slot(-1), s(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_filter.empty() && g_prof_filter != name) return;
+    for (size_t i = 0; i < g_prof.size(); ++i)
+        if (g_prof[i].name == name) slot = static_cast<int>(i);
+    if (slot < 0) {
+        g_prof.push_back(ProfEntry());
+        g_prof.back().name = name;
+        slot = static_cast<int>(g_prof.size()) - 1;
+    }
+    if (g_prof[slot].pending.size() >= 8) drain_entry(g_prof[slot]);  // keep few events outstanding
+    hipEvent_t a = take_event(), b = take_event();
+    g_prof[slot].pending.push_back({a, b});
+    (void)hipEventRecord(a, s);
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].pending.back().second, s);
+}
+
 }  // namespace scal
+
+extern "C" int scal_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    scal::g_prof_on = on != 0;
+    return SCAL_OK;
+}
+extern "C" int scal_prof_filter(const char* kernel_name) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    scal::g_prof_filter = kernel_name ? kernel_name : "";
+    return SCAL_OK;
+}
+extern "C" int scal_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    scal::drain_locked();
+    for (auto& p : scal::g_prof) p.total_ms = 0, p.count = 0;
+    return SCAL_OK;
+}
+extern "C" int scal_prof_read(const char* name, double* total_ms, long* count) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    scal::drain_locked();
+    for (auto& p : scal::g_prof)
+        if (p.name == name) {
+            if (total_ms) *total_ms = p.total_ms;
+            if (count) *count = p.count;
+            return SCAL_OK;
+        }
+    if (total_ms) *total_ms = 0;
+    if (count) *count = 0;
+    return SCAL_OK;
+}
+extern "C" int scal_prof_names(char* buf, int cap) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    std::string all;
+    for (auto& p : scal::g_prof) all += p.name + ";";
+    if (buf && cap > 0) {
+        std::strncpy(buf, all.c_str(), cap - 1);
+        buf[cap - 1] = 0;
+    }
+    return static_cast<int>(all.size());
+}
 
 extern "C" const char* scal_last_error(void) { return scal::g_err; }
 extern "C" int scal_device_count(void) {

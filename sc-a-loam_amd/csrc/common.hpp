@@ -30,6 +30,10 @@ void set_error(const char* fmt, ...);
 
 // selects the device and verifies it is a gfx950 part: the product path must fail loudly otherwise
 int select_device(int device);
+// All contexts of one device share ONE stream: the stages of a scan are strictly dependent (A -> B -> C, D after A), so
+// separate queues buy no overlap, and a single in-order queue needs no cross-stream events.  Reference counted.
+int acquire_stream(int device, hipStream_t* out);
+void release_stream(int device);
 
 template <class T>
 struct DevBuf {
@@ -92,5 +96,14 @@ struct PinBuf {
 };
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Optional per-kernel timing with HIP events on the stream the kernel is launched on (bench.py's roofline leg).
+// Disabled by default: a ProfScope is then a single branch.
+struct ProfScope {
+    int slot;
+    hipStream_t s;
+    ProfScope(const char* name, hipStream_t stream);
+    ~ProfScope();
+};
 
 }  // namespace scal

@@ -685,7 +685,7 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     A(c->d_P.alloc(1));
     A(c->h_P.alloc(1));
     if (rc == SCAL_OK && hipMemset(c->d_P.p, 0, sizeof(FeatParams)) != hipSuccess) rc = SCAL_E_HIP;
-    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -709,7 +709,7 @@ extern "C" void scal_features_destroy(scal_features_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+        release_stream(c->cfg.device);
     }
     delete c;
 }
@@ -731,8 +731,11 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     const int nb256 = max(1, div_up(n, 256));
     hipLaunchKernelGGL(k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p);
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
+    {
+    ProfScope ps("k_ring", s);
     hipLaunchKernelGGL(k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
                        c->d_gap.p, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->sx.p, c->sy.p, c->sz.p, c->si.p);
+    }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p);
     hipLaunchKernelGGL(k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,

@@ -596,6 +596,7 @@ struct scal_map {
     DevBuf<double> d_x0;
     DevBuf<int> d_nfull;
     PinBuf<MapCounters> h_C;
+    PinBuf<int> h_misc;
     PinBuf<LMState> h_st;
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
 };
@@ -636,8 +637,8 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
-    A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
-    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) rc = SCAL_E_HIP;
+    A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4));
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         // the cell counters obey a zero invariant: every step clears exactly the cells it touched
@@ -659,7 +660,7 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+        release_stream(c->cfg.device);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
@@ -736,8 +737,11 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     const int assoc_blocks = std::max(1, div_up(c->slot_cap, 128));
     for (int outer = 0; outer < 2; ++outer) {
         hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, C, outer);
+        {
+        ProfScope ps("k_assoc", s);
         hipLaunchKernelGGL(k_assoc, dim3(assoc_blocks), dim3(128), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p, c->grid[0].start.p,
                            c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, outer, F);
+        }
         hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->solve_on, &C->n_live);
         hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
         hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);
@@ -818,7 +822,8 @@ int reset_counters(scal_map* c, int n_corner, int n_surf, int n_full) {
     z.n_corner_in = n_corner, z.n_surf_in = n_surf;
     *c->h_C.p = z;
     SCAL_HIP(hipMemcpyAsync(c->d_C.p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, c->stream));
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, &n_full, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    c->h_misc.p[0] = n_full;
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, c->stream));
     return SCAL_OK;
 }
 

@@ -259,7 +259,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
-    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         if (hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
@@ -281,7 +281,7 @@ extern "C" void scal_odom_destroy(scal_odom_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+        release_stream(c->cfg.device);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
@@ -313,8 +313,11 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
         const int slot_blocks = std::max(1, div_up(c->slot_cap, 256));
         for (int outer = 0; outer < 2; ++outer) {  // :278
             hipLaunchKernelGGL(k_odom_outer_begin, dim3(1), dim3(1), 0, s, C, outer, c->slot_cap);
+            {
+            ProfScope ps("k_odom_assoc", s);
             hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
                                c->surf_last.cv(), st, C, outer, F);
+            }
             hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->enable, &C->n_live);
             hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
             hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);

@@ -109,7 +109,10 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         hipLaunchKernelGGL(k_rs_hist, dim3(nb_cap), dim3(256), 0, s, ka, d_n, shift, hist.p);
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, hist.p, d_n, TILE, 256, static_cast<int*>(nullptr));
+        {
+        ProfScope ps("k_rs_scatter", s);
         hipLaunchKernelGGL(k_rs_scatter, dim3(nb_cap), dim3(256), 0, s, ka, va, d_n, shift, hist.p, kb, vb);
+        }
         std::swap(ka, kb);
         std::swap(va, vb);
     }

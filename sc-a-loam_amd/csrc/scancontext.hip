@@ -15,6 +15,8 @@
 // sums, (s0+s2)+(s1+s3) — see oracle/scancontext.cpp.
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "voxel_dev.hpp"
+#include "features_dev.hpp"
 #include <cmath>
 #include <cfloat>
 
@@ -407,6 +409,12 @@ struct scal_sc {
     DevBuf<double> d_dist;
     DevBuf<int> d_shift;
     size_t pair_cap = 0;
+    // keyframe downsampling for scal_sc_insert_features (lazy)
+    VoxelFilter vf;
+    DevBuf<float> dsx, dsy, dsz, dsw;
+    DevBuf<int> d_nds;
+    int vf_cap = 0;
+    hipEvent_t ev = nullptr;
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
     bool owns(int g) const { return cfg.n_shards <= 1 || (g % cfg.n_shards) == cfg.shard; }
 };
@@ -437,7 +445,7 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->block_best.alloc((size_t)3 * div_up(c->cap, 256) + 3));
     A(c->d_rec.alloc(4));
     A(c->h_rec.alloc(4));
-    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -454,8 +462,9 @@ extern "C" void scal_sc_destroy(scal_sc_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+        release_stream(c->cfg.device);
     }
+    if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
 }
 
@@ -465,6 +474,13 @@ extern "C" int scal_sc_size(scal_sc_t* c) {
     return c->n_global;
 }
 
+// the staged descriptor/keys become keyframe n_global; stored only when this shard owns that index
+static int commit_staged(scal_sc* c) {
+    hipStream_t s = c->stream;
+    SCAL_TRY(commit_staged(c));
+    return SCAL_OK;
+}
+
 // build the descriptor of a cloud into the query staging slot; when this shard owns the new global index, also
 // into its database slot
 static int make_into(scal_sc* c, const float* px, const float* py, const float* pz, int stride, const int* d_n, int n_host, bool insert) {
@@ -472,22 +488,7 @@ static int make_into(scal_sc* c, const float* px, const float* py, const float* 
     hipLaunchKernelGGL(k_sc_make, dim3(1), dim3(1024), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->qdesc.p,
                        c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_HIP(hipGetLastError());
-    if (insert) {
-        const int g = c->n_global;
-        if (c->owns(g)) {
-            if (c->n_local >= c->cap) {
-                set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
-                return SCAL_E_CAPACITY;
-            }
-            const size_t sl = c->n_local;
-            SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-            SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-            SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-            SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
-            c->n_local++;
-        }
-        c->n_global++;
-    }
+    if (insert) SCAL_TRY(commit_staged(c));
     return SCAL_OK;
 }
 
@@ -548,20 +549,98 @@ extern "C" int scal_sc_insert_descriptor(scal_sc_t* c, const double* desc) {
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->qdesc.p, desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
-    const int g = c->n_global;
-    if (c->owns(g)) {
-        if (c->n_local >= c->cap) {
-            set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
-            return SCAL_E_CAPACITY;
-        }
-        const size_t sl = c->n_local;
-        SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
-        c->n_local++;
+    SCAL_TRY(commit_staged(c));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* n_cap) {
+    FeatDeviceView v = features_view(feat);
+    if (v.device != c->cfg.device) {
+        set_error("features context lives on device %d, ScanContext on %d", v.device, c->cfg.device);
+        return SCAL_E_ARG;
     }
-    c->n_global++;
+    if (c->vf_cap < v.cap) {
+        SCAL_TRY(c->vf.init(v.cap));
+        SCAL_TRY(c->dsx.alloc(v.cap));
+        SCAL_TRY(c->dsy.alloc(v.cap));
+        SCAL_TRY(c->dsz.alloc(v.cap));
+        SCAL_TRY(c->dsw.alloc(v.cap));
+        SCAL_TRY(c->d_nds.alloc(2));
+        c->vf_cap = v.cap;
+    }
+    if (!c->ev) SCAL_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    SCAL_HIP(hipEventRecord(c->ev, v.stream));
+    SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); 12 bits per axis = 1.6 km extent
+    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, 0.4f, 12, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
+    *d_n = c->d_nds.p;
+    *n_cap = v.cap;
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_insert_features(scal_sc_t* c, scal_features_t* feat) {
+    if (!c || !feat) {
+        set_error("scal_sc_insert_features: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int* d_n;
+    int cap;
+    SCAL_TRY(ds_features(c, feat, &d_n, &cap));
+    return make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, true);
+}
+
+extern "C" int scal_sc_make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc) {
+    if (!c || !feat || !d_desc) {
+        set_error("scal_sc_make_features: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int* d_n;
+    int cap;
+    SCAL_TRY(ds_features(c, feat, &d_n, &cap));
+    SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, false));
+    SCAL_HIP(hipMemcpyAsync(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_insert_descriptor_device(scal_sc_t* c, const double* d_desc) {
+    if (!c || !d_desc) {
+        set_error("scal_sc_insert_descriptor_device: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_desc, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_TRY(commit_staged(c));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_shard_query_device(scal_sc_t* c, const double* d_queries, int nq, int global_size_at_rebuild, scal_sc_cand* d_out) {
+    if (!c || !d_queries || !d_out || nq < 0) {
+        set_error("scal_sc_shard_query_device: bad argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const int nb = std::max(1, div_up(c->n_local, 256));
+    for (int q = 0; q < nq; ++q) {
+        SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_queries + (size_t)q * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+        hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard,
+                           global_size_at_rebuild - 30, c->block_best.p);
+        hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
+                           c->qnorm.p, 1, reinterpret_cast<SCRec*>(d_out) + 3 * (size_t)q);
+    }
+    SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
 }

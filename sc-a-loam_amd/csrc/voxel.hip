@@ -191,7 +191,7 @@ extern "C" int scal_voxel_create(int max_points, int device, scal_voxel_t** out)
     A(c->ix.alloc(max_points)); A(c->iy.alloc(max_points)); A(c->iz.alloc(max_points)); A(c->iw.alloc(max_points));
     A(c->ox.alloc(max_points)); A(c->oy.alloc(max_points)); A(c->oz.alloc(max_points)); A(c->ow.alloc(max_points));
     A(c->d_n.alloc(2));
-    if (rc == SCAL_OK && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (rc == SCAL_OK && acquire_stream(c->device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -208,7 +208,7 @@ extern "C" void scal_voxel_destroy(scal_voxel_t* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamDestroy(c->stream);
+        release_stream(c->device);
     }
     delete c;
 }

@@ -75,13 +75,14 @@ class OdomStats(C.Structure):
 
 # every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "scal_last_error", "scal_device_count", "scal_version",
+    "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names",
     "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_fetch",
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_distance_pairs",
-    "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates",
+    "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
+    "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features",
     "scal_factors_eval",
@@ -126,6 +127,14 @@ def lib():
     L.scal_sc_distance_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _i32p]
     L.scal_sc_shard_query.argtypes = [vp, _f64p, C.c_int, C.POINTER(SCCand)]
     L.scal_sc_merge_candidates.argtypes = [C.POINTER(SCCand), C.c_int, C.c_double, C.POINTER(SCResult)]
+    L.scal_sc_insert_features.argtypes = [vp, vp]
+    L.scal_sc_make_features.argtypes = [vp, vp, vp]
+    L.scal_sc_insert_descriptor_device.argtypes = [vp, vp]
+    L.scal_sc_shard_query_device.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.scal_prof_enable.argtypes = [C.c_int]
+    L.scal_prof_filter.argtypes = [C.c_char_p]
+    L.scal_prof_read.argtypes = [C.c_char_p, _f64p, C.POINTER(C.c_long)]
+    L.scal_prof_names.argtypes = [C.c_char_p, C.c_int]
     L.scal_map_create.argtypes = [C.POINTER(MapConfig), C.POINTER(vp)]
     L.scal_map_destroy.argtypes = [vp]
     L.scal_map_destroy.restype = None
@@ -165,6 +174,30 @@ def device_count():
     return lib().scal_device_count()
 
 
+def prof_enable(on, kernel=None):
+    lib().scal_prof_filter(kernel.encode() if kernel else None)
+    lib().scal_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    lib().scal_prof_reset()
+
+
+def prof_read_all():
+    """{kernel name: (total_ms, launches)} measured with HIP events on the launching stream."""
+    buf = C.create_string_buffer(4096)
+    lib().scal_prof_names(buf, 4096)
+    out = {}
+    for name in buf.value.decode().split(";"):
+        if not name:
+            continue
+        ms = C.c_double(0)
+        cnt = C.c_long(0)
+        lib().scal_prof_read(name.encode(), C.byref(ms), C.byref(cnt))
+        out[name] = (ms.value, cnt.value)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- stage A
 class ScanRegistration:
     """Mirror of the reference's scanRegistration node state (scan_line, lidar_type, minimum_range rosparams,
@@ -184,9 +217,9 @@ class ScanRegistration:
                        less_flat=np.zeros((m, 4), np.float32))
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().scal_features_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_features_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -231,9 +264,9 @@ class VoxelGrid:
         self.cap = max_points
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().scal_voxel_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_voxel_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -256,9 +289,9 @@ class SCManager:
         _check(lib().scal_sc_create(C.byref(self.cfg), C.byref(self.h)))
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().scal_sc_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_sc_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -284,6 +317,19 @@ class SCManager:
         k = np.zeros(20, np.float32)
         _check(lib().scal_sc_get_descriptor(self.h, idx, _p(d, _f64p), _p(k, _f32p)))
         return d.reshape(60, 20).T.copy(), k
+
+    def insert_features(self, feat):
+        """keyframe cloud of a ScanRegistration context -> VoxelGrid(0.4) -> makeAndSaveScancontextAndKeys, all on the GPU"""
+        _check(lib().scal_sc_insert_features(self.h, feat.h))
+
+    def make_features(self, feat, d_desc_ptr):
+        _check(lib().scal_sc_make_features(self.h, feat.h, d_desc_ptr))
+
+    def insert_descriptor_device(self, d_desc_ptr):
+        _check(lib().scal_sc_insert_descriptor_device(self.h, d_desc_ptr))
+
+    def shard_query_device(self, d_queries_ptr, nq, global_size_at_rebuild, d_out_ptr):
+        _check(lib().scal_sc_shard_query_device(self.h, d_queries_ptr, nq, global_size_at_rebuild, d_out_ptr))
 
     def detectLoopClosureID(self):
         r = SCResult()
@@ -332,9 +378,9 @@ class LaserMapping:
         _check(lib().scal_map_create(C.byref(self.cfg), C.byref(self.h)))
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().scal_map_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_map_destroy(self.h)
+        self.h = None
 
     __del__ = close
 
@@ -384,9 +430,9 @@ class LaserOdometry:
         _check(lib().scal_odom_create(C.byref(self.cfg), C.byref(self.h)))
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().scal_odom_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_odom_destroy(self.h)
+        self.h = None
 
     __del__ = close
 

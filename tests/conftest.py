@@ -13,6 +13,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "sc-a-loam_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tools", "synth"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -42,13 +43,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
-def worlds(O):
+def worlds():
+    import scansynth
     cache = {}
 
     def get(sensor, seed):
         key = (sensor, seed)
         if key not in cache:
-            cache[key] = O.World(sensor, seed)
+            cache[key] = scansynth.World(sensor, seed)
         return cache[key]
     return get
 

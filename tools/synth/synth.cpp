@@ -1,15 +1,57 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_common.hpp).
+// Synthetic input generator (NOT part of the oracle and NOT part of the product path).
 //
 // Seeded procedural world + ray-cast LiDAR sensor models: no dataset exists
 // offline (KITTI / MulRan are not in the container), so every workload is generated here, bit-identically
 // for a given seed.  World frame: ground plane z = 0, sensor at height h, x forward, y left.
 // Points are emitted firing by firing with clockwise azimuth, which matches the reference's
 // `ori = -atan2(y, x)` convention (scanRegistration.cpp:143-146, :221).
-#include "orc_common.hpp"
-#include "oracle.h"
+#include "synth.h"
 #include <omp.h>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
 
-namespace orc {
+namespace synth {
+
+struct V3 {
+    double x, y, z;
+};
+struct Quat {
+    double x, y, z, w;
+};
+static inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+static inline V3 rotate(const Quat& q, V3 v) {
+    V3 u{q.x, q.y, q.z};
+    V3 uv = cross(u, v);
+    uv = {uv.x + uv.x, uv.y + uv.y, uv.z + uv.z};
+    V3 t = cross(u, uv);
+    return {(v.x + q.w * uv.x) + t.x, (v.y + q.w * uv.y) + t.y, (v.z + q.w * uv.z) + t.z};
+}
+static inline Quat qmul(const Quat& a, const Quat& b) {
+    return {a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+// splitmix64
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    double uniform() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+    double uniform(double a, double b) { return a + (b - a) * uniform(); }
+    double normal() {
+        double u1 = uniform();
+        if (u1 < 1e-300) u1 = 1e-300;
+        double u2 = uniform();
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+};
+
 
 struct Box {
     double x0, x1, y0, y1, h;
@@ -19,7 +61,7 @@ struct Cyl {
 };
 
 struct World {
-    OrcSynthConfig cfg;
+    SynthConfig cfg;
     std::vector<Box> boxes;
     std::vector<Cyl> cyls;
     std::vector<double> elev;  // beam elevations [rad], firing order
@@ -53,19 +95,19 @@ static double dist_to_path(const World& w, double x, double y) {
     return best;
 }
 
-static World* make_world(const OrcSynthConfig& c) {
+static World* make_world(const SynthConfig& c) {
     World* w = new World();
     w->cfg = c;
     switch (c.sensor) {
-        case ORC_VLP16:
+        case SYN_VLP16:
             for (int i = 0; i < 16; ++i) w->elev.push_back((-15.0 + 2.0 * i) * M_PI / 180.0);
             w->n_az = 1800, w->max_range = 100.0, w->height = 1.0;
             break;
-        case ORC_HDL32:
+        case SYN_HDL32:
             for (int i = 0; i < 32; ++i) w->elev.push_back((10.0 + 2.0 / 3.0 - (4.0 / 3.0) * i) * M_PI / 180.0);
             w->n_az = 1800, w->max_range = 100.0, w->height = 1.7;
             break;
-        case ORC_HDL64:
+        case SYN_HDL64:
             for (int i = 0; i < 32; ++i) w->elev.push_back((2.0 - i / 3.0) * M_PI / 180.0);
             for (int i = 0; i < 32; ++i) w->elev.push_back((-8.83 - 0.5 * i) * M_PI / 180.0);
             w->n_az = 1900, w->max_range = 120.0, w->height = 1.73;
@@ -177,31 +219,31 @@ static int cast_scan(const World& w, const Quat& q, const V3& t, uint64_t noise_
     return m;
 }
 
-}  // namespace orc
+}  // namespace synth
 
 extern "C" {
-void* orc_world_create(const OrcSynthConfig* cfg) { return orc::make_world(*cfg); }
-void orc_world_destroy(void* w) { delete static_cast<orc::World*>(w); }
-void orc_world_pose(void* w, int k, double* q, double* t) {
-    orc::Quat qq;
-    orc::V3 tt;
-    static_cast<orc::World*>(w)->pose(k, qq, tt);
+void* syn_world_create(const SynthConfig* cfg) { return synth::make_world(*cfg); }
+void syn_world_destroy(void* w) { delete static_cast<synth::World*>(w); }
+void syn_world_pose(void* w, int k, double* q, double* t) {
+    synth::Quat qq;
+    synth::V3 tt;
+    static_cast<synth::World*>(w)->pose(k, qq, tt);
     q[0] = qq.x, q[1] = qq.y, q[2] = qq.z, q[3] = qq.w;
     t[0] = tt.x, t[1] = tt.y, t[2] = tt.z;
 }
-int orc_world_max_points(void* w) {
-    auto* W = static_cast<orc::World*>(w);
+int syn_world_max_points(void* w) {
+    auto* W = static_cast<synth::World*>(w);
     return W->n_az * static_cast<int>(W->elev.size());
 }
-int orc_world_scan(void* w, int k, float* out_xyz) {
-    auto* W = static_cast<orc::World*>(w);
-    orc::Quat q;
-    orc::V3 t;
+int syn_world_scan(void* w, int k, float* out_xyz) {
+    auto* W = static_cast<synth::World*>(w);
+    synth::Quat q;
+    synth::V3 t;
     W->pose(k, q, t);
-    return orc::cast_scan(*W, q, t, W->cfg.seed + 1000003ull * (k + 1), out_xyz);
+    return synth::cast_scan(*W, q, t, W->cfg.seed + 1000003ull * (k + 1), out_xyz);
 }
-int orc_world_scan_pose(void* w, const double* q, const double* t, uint64_t noise_seed, float* out_xyz) {
-    auto* W = static_cast<orc::World*>(w);
-    return orc::cast_scan(*W, {q[0], q[1], q[2], q[3]}, {t[0], t[1], t[2]}, noise_seed, out_xyz);
+int syn_world_scan_pose(void* w, const double* q, const double* t, uint64_t noise_seed, float* out_xyz) {
+    auto* W = static_cast<synth::World*>(w);
+    return synth::cast_scan(*W, {q[0], q[1], q[2], q[3]}, {t[0], t[1], t[2]}, noise_seed, out_xyz);
 }
 }
