@@ -418,6 +418,25 @@ struct Mapper {
 }  // namespace orc
 
 extern "C" {
+void orc_eig3_sym(const double* A9, double* w3, double* V9) { orc::eig3_sym(A9, w3, V9); }
+void orc_plane_fit_5x3(const double* A15, const double* b5, double* x3) { orc::colpiv_qr_solve_5x3(A15, b5, x3); }
+int orc_ceres_solve(int n, const int* kind, const double* cp, const double* pa, const double* pb, double* x7, double* cost_trace, int* n_trace,
+                    int* termination) {
+    std::vector<orc::Factor> F(n);
+    for (int i = 0; i < n; ++i) {
+        F[i].kind = kind[i];
+        F[i].cp = {cp[3 * i], cp[3 * i + 1], cp[3 * i + 2]};
+        F[i].a = {pa[3 * i], pa[3 * i + 1], pa[3 * i + 2]};
+        F[i].b = {pb[3 * i], pb[3 * i + 1], pb[3 * i + 2]};
+    }
+    orc::LMSummary S;
+    orc::ceres_solve(F, x7, &S);
+    int m = static_cast<int>(std::min<size_t>(S.cost_trace.size(), 6));
+    for (int i = 0; i < m; ++i) cost_trace[i] = S.cost_trace[i];
+    *n_trace = m;
+    *termination = S.termination;
+    return S.iterations;
+}
 void* orc_map_create(const OrcMapConfig* cfg) { return new orc::Mapper(*cfg); }
 void orc_map_destroy(void* h) { delete static_cast<orc::Mapper*>(h); }
 int orc_map_step(void* h, const float* corner_last, int n_corner, const float* surf_last, int n_surf, const float* full_res,

@@ -112,6 +112,13 @@ int orc_odom_step(void* h, const float* sharp, int n_sharp, const float* less_sh
 void orc_factor_eval(int kind, const double* cp, const double* params, const double* x7, double* residual3,
                      double* jac3x7);
 
+/* third-party sub-steps exposed so that tests can cross-check them against numpy/scipy */
+void orc_eig3_sym(const double* A9, double* w3, double* V9);            /* Eigen::SelfAdjointEigenSolver stand-in */
+void orc_plane_fit_5x3(const double* A15, const double* b5, double* x3); /* colPivHouseholderQr().solve stand-in */
+/* ceres::Solve stand-in on explicit factor arrays ([n] kinds, [n][3] cp/pa/pb); x7 in/out; returns iterations */
+int orc_ceres_solve(int n, const int* kind, const double* cp, const double* pa, const double* pb, double* x7,
+                    double* cost_trace /*[6]*/, int* n_trace, int* termination);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,9 @@ def lib():
         L.orc_odom_step.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p,
                                     _f64p, C.POINTER(OdomStats)]
         L.orc_factor_eval.argtypes = [C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p]
+        L.orc_eig3_sym.argtypes = [_f64p, _f64p, _f64p]
+        L.orc_plane_fit_5x3.argtypes = [_f64p, _f64p, _f64p]
+        L.orc_ceres_solve.argtypes = [C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p, _i32p, _i32p]
         _lib = L
     return _lib
 
@@ -296,3 +299,31 @@ def factor_eval(kind, cp, params6, x7):
     lib().orc_factor_eval(kind, _p(cp, _f64p), _p(pr, _f64p), _p(x, _f64p), _p(r, _f64p), _p(J, _f64p))
     nr = 3 if kind == 0 else 1
     return r[:nr], J[:nr]
+
+
+def eig3_sym(A):
+    A = _f64(A).reshape(9)
+    w = np.zeros(3)
+    V = np.zeros(9)
+    lib().orc_eig3_sym(_p(A, _f64p), _p(w, _f64p), _p(V, _f64p))
+    return w, V.reshape(3, 3)
+
+
+def plane_fit(A5x3, b5):
+    A = _f64(A5x3).reshape(15)
+    b = _f64(b5)
+    x = np.zeros(3)
+    lib().orc_plane_fit_5x3(_p(A, _f64p), _p(b, _f64p), _p(x, _f64p))
+    return x
+
+
+def ceres_solve(kind, cp, pa, pb, x7):
+    kind = np.ascontiguousarray(kind, np.int32)
+    cp, pa, pb = _f64(cp), _f64(pa), _f64(pb)
+    x = _f64(x7).copy()
+    trace = np.zeros(6)
+    nt = C.c_int(0)
+    term = C.c_int(0)
+    it = lib().orc_ceres_solve(kind.shape[0], _p(kind, _i32p), _p(cp, _f64p), _p(pa, _f64p), _p(pb, _f64p), _p(x, _f64p), _p(trace, _f64p),
+                               C.byref(nt), C.byref(term))
+    return x, it, trace[:nt.value], term.value

@@ -1,0 +1,86 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/scaloam_hip.h declares, fails loudly
+without a device (no CPU fallback), and does not link or reference the oracle."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "scaloam_hip.h")
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(scal_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(S):
+    syms = _declared_symbols()
+    assert len(syms) >= 40
+    L = S.lib()
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    # and the Python binding's own list is in sync with the header
+    assert sorted(S.EXPORTED_SYMBOLS) == syms
+
+
+def test_no_cpu_fallback_and_oracle_is_not_linked(S):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the no-device behaviour is exercised on CPU-only hosts")
+    assert S.device_count() <= 0
+    for ctor in (lambda: S.ScanRegistration(S.HDL64, 5.0), lambda: S.SCManager(), lambda: S.LaserMapping(), lambda: S.LaserOdometry(),
+                 lambda: S.VoxelGrid()):
+        with pytest.raises(S.ScalError) as e:
+            ctor()
+        assert e.value.code == S.E_NO_DEVICE
+    with pytest.raises(S.ScalError) as e:
+        S.factors_eval(np.zeros(1, np.int32), np.zeros((1, 3)), np.ones((1, 3)), np.zeros((1, 3)), np.array([0, 0, 0, 1.0, 0, 0, 0]))
+    assert e.value.code == S.E_NO_DEVICE
+
+
+def test_product_does_not_depend_on_oracle(S):
+    out = subprocess.run(["ldd", S.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "scansynth" not in out
+    blob = open(S.LIB_PATH, "rb").read()
+    assert b"liboracle" not in blob and b"orc_features_run" not in blob
+    # nothing under the package imports the oracle
+    for dp, _, fs in os.walk(os.path.join(ROOT, "sc-a-loam_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_py" not in src and '#include "oracle' not in src and "orc_" not in src, os.path.join(dp, f)
+
+
+def test_argument_validation_without_device(S):
+    """Config errors are reported before any device work (reference behaviours mapped in include/scaloam_hip.h)."""
+    with pytest.raises(S.ScalError) as e:
+        S.ScanRegistration(S.HDL64, 5.0, n_scans=48)
+    assert e.value.code == S.E_SCAN_LINE
+    with pytest.raises(S.ScalError) as e:
+        S.ScanRegistration(S.VLP16, 0.1, n_scans=64)
+    assert e.value.code == S.E_LIDAR_TYPE
+    with pytest.raises(S.ScalError) as e:
+        S.ScanRegistration(S.HDL64, 5.0, max_points=400001)
+    assert e.value.code == S.E_ARG
+
+
+def test_merge_candidates_host_logic(S):
+    """scal_sc_merge_candidates is pure host code: three smallest key distances overall, evaluated in that order with
+    a strict '<' on the SC distance (Scancontext.cpp:385-400), threshold -> loop id (:406-408), yaw = shift * 6 deg."""
+    def cand(kd, idx, sd, sh):
+        return S.SCCand(kd, idx, sd, sh, 0)
+    recs = [cand(0.9, 40, 0.30, 5), cand(0.1, 7, 0.25, 59), cand(3.4e38, -1, 1e7, 0),
+            cand(0.5, 12, 0.25, 3), cand(0.7, 90, 0.05, 1), cand(3.4e38, -1, 1e7, 0)]
+    r = S.merge_candidates(recs, 0.4)
+    assert list(r["cand"]) == [7, 12, 90]          # 0.1, 0.5, 0.7 - the 0.9 candidate is cut
+    assert r["nn_idx"] == 90 and r["loop_id"] == 90 and abs(r["min_dist"] - 0.05) < 1e-15
+    assert abs(r["yaw"] - np.float32(np.float32(6.0) * np.pi / 180.0)) < 1e-7
+    r = S.merge_candidates(recs, 0.01)
+    assert r["loop_id"] == -1 and r["nn_idx"] == 90
+    r = S.merge_candidates([cand(0.2, 3, 0.3, 2), cand(0.2, 1, 0.3, 4)], 0.5)
+    assert list(r["cand"][:2]) == [1, 3] and r["nn_idx"] == 1 and r["nn_shift"] == 4  # ties: lower index, first wins
