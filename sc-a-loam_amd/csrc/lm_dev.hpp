@@ -357,4 +357,113 @@ static __global__ void k_lm_reset(LMState* st, const int* __restrict__ d_enable,
     }
 }
 
+
+// The whole solve of one outer iteration in ONE workgroup: evaluate at x, step, then up to four (evaluate candidate,
+// step) rounds.  Residual blocks are strided over 1024 threads, the 28 partial sums are reduced with wave shuffles and a
+// fixed-order LDS stage (bitwise reproducible for a given block count), and the trust-region state lives in LDS, so
+// the <=5 evaluations need no kernel boundary and no global round trip between them.
+static __global__ void __launch_bounds__(1024) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st_g,
+                                                          const int* __restrict__ d_enable, const int* __restrict__ d_live) {
+    __shared__ double red[16][LM_NACC];
+    __shared__ double tot[LM_NACC];
+    __shared__ LMState S;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        S = *st_g;
+        S.radius = 1e4, S.decrease_factor = 2.0;
+        S.iteration = 0, S.done = 0, S.successful = 0, S.started = 0, S.termination = 0;
+        S.x_cost = 0, S.cost_init = 0, S.cost_final = 0, S.mcc = 0;
+        S.enabled = d_enable ? *d_enable : 1;
+        if (d_live && *d_live == 0) S.done = 1, S.termination = 4;  // no residual blocks: parameters stay untouched
+    }
+    __syncthreads();
+    const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
+    for (int phase = 0; phase < 6; ++phase) {
+        if (!S.enabled || S.done) break;  // uniform: S is in LDS and only thread 0 writes it between barriers
+        double xl[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) xl[k] = phase == 0 ? S.x[k] : S.cand[k];
+        double acc[LM_NACC];
+#pragma unroll
+        for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
+        for (int i = tid; i < n; i += 1024) {
+            if (f.valid[i]) {
+                const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
+                const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
+                const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
+                factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LM_NACC; ++k) {
+            const double v = wave_sum(acc[k]);
+            if (lane_id() == 0) red[wave_id()][k] = v;
+        }
+        __syncthreads();
+        if (tid < LM_NACC) {
+            double s = 0.0;
+            for (int w = 0; w < 16; ++w) s += red[w][tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            LMState* st = &S;
+            auto grad_max_norm = [&]() {
+                double neg[6], proj[7], m = 0.0;
+                for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
+                quat_plus(st->x, neg, proj);
+                for (int k = 0; k < 7; ++k) m = fmax(m, fabs(st->x[k] - proj[k]));
+                return m;
+            };
+            if (phase == 0) {
+                st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
+                for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+                for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+                for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));
+                double xn = 0.0;
+                for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+                st->x_norm = sqrt(xn);
+                st->started = 1;
+                if (grad_max_norm() <= gradient_tolerance)
+                    st->done = 1, st->termination = 1;
+                else
+                    lm_compute_candidate(st);
+            } else {
+                const double candidate_cost = tot[0];
+                double sn = 0.0;
+                for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
+                if (sqrt(sn) <= parameter_tolerance * (st->x_norm + parameter_tolerance)) {
+                    st->done = 1, st->termination = 2;
+                } else if (fabs(st->x_cost - candidate_cost) <= function_tolerance * st->x_cost) {
+                    st->done = 1, st->termination = 3;
+                } else {
+                    const double relative_decrease = (st->x_cost - candidate_cost) / st->mcc;
+                    bool stop = false;
+                    if (relative_decrease > min_relative_decrease) {
+                        for (int k = 0; k < 7; ++k) st->x[k] = st->cand[k];
+                        double xn = 0.0;
+                        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+                        st->x_norm = sqrt(xn);
+                        st->x_cost = candidate_cost, st->cost_final = candidate_cost;
+                        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+                        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+                        st->successful++;
+                        const double t = 2.0 * relative_decrease - 1.0;
+                        st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                        st->decrease_factor = 2.0;
+                        if (grad_max_norm() <= gradient_tolerance) st->done = 1, st->termination = 1, stop = true;
+                    } else {
+                        st->radius = st->radius / st->decrease_factor;
+                        st->decrease_factor *= 2.0;
+                    }
+                    if (!stop) lm_compute_candidate(st);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *st_g = S;
+}
+
 }  // namespace scal

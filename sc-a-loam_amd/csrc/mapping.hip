@@ -139,42 +139,92 @@ struct Knn5 {
     float px[5], py[5], pz[5];
 };
 
-// exact 5 nearest map points of q among the 27 cells around it; ascending (distance, map index)
-__device__ __forceinline__ void knn5(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g, float qx,
-                                     float qy, float qz, Knn5& r) {
+// Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE:
+// lanes 0..26 each own a neighbour cell (one round trip for the 27 (count, start) pairs), the candidates are written
+// into a per-wave LDS list as 64-bit (f32 distance bits, map index) keys, and five wave-argmin rounds pick the result.
+// Every lane returns the same Knn5.
+constexpr int KNN_CHUNK = 256;
+__device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g,
+                                          float qx, float qy, float qz, unsigned long long* skey, int* spos, Knn5& r) {
+    const int lane = lane_id();
+    unsigned long long bk[5];
+    int bp[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) r.d[k] = 3.4e38f, r.id[k] = 0x7fffffff, r.px[k] = r.py[k] = r.pz[k] = 0.f;
+    for (int k = 0; k < 5; ++k) bk[k] = ~0ull, bp[k] = -1;
     const int cx = static_cast<int>(floorf(qx)) - mp.ox, cy = static_cast<int>(floorf(qy)) - mp.oy, cz = static_cast<int>(floorf(qz)) - mp.oz;
+    int my_cnt = 0, my_start = 0;
     // a query further than one cell outside the grid has no map point within 1 m
-    if (cx < -1 || cx > GX || cy < -1 || cy > GY || cz < -1 || cz > GZ) return;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, GX - 1);
-    const int y0 = max(cy - 1, 0), y1 = min(cy + 1, GY - 1);
-    const int z0 = max(cz - 1, 0), z1 = min(cz + 1, GZ - 1);
-    for (int zz = z0; zz <= z1; ++zz)
-        for (int yy = y0; yy <= y1; ++yy)
-            for (int xx = x0; xx <= x1; ++xx) {
-                const int c = xx + GX * (yy + GY * zz);
-                const int n = cnt[c];
-                if (n == 0) continue;
-                const int s = start[c];
-                for (int t = s; t < s + n; ++t) {
-                    const float px = g.x[t], py = g.y[t], pz = g.z[t];
-                    // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
-                    const float dx = qx - px, dy = qy - py, dz = qz - pz;
-                    float dist = dx * dx;
-                    dist += dy * dy;
-                    dist += dz * dz;
-                    const int id = g.idx[t];
-                    if (dist < r.d[4] || (dist == r.d[4] && id < r.id[4])) {
-                        int k = 4;
-                        while (k > 0 && (r.d[k - 1] > dist || (r.d[k - 1] == dist && r.id[k - 1] > id))) {
-                            r.d[k] = r.d[k - 1], r.id[k] = r.id[k - 1], r.px[k] = r.px[k - 1], r.py[k] = r.py[k - 1], r.pz[k] = r.pz[k - 1];
-                            --k;
-                        }
-                        r.d[k] = dist, r.id[k] = id, r.px[k] = px, r.py[k] = py, r.pz[k] = pz;
-                    }
-                }
+    const bool inside = !(cx < -1 || cx > GX || cy < -1 || cy > GY || cz < -1 || cz > GZ);
+    if (inside && lane < 27) {
+        const int xx = cx + (lane % 3) - 1, yy = cy + ((lane / 3) % 3) - 1, zz = cz + (lane / 9) - 1;
+        if (xx >= 0 && xx < GX && yy >= 0 && yy < GY && zz >= 0 && zz < GZ) {
+            const int c = xx + GX * (yy + GY * zz);
+            my_cnt = cnt[c];
+            if (my_cnt) my_start = start[c];
+        }
+    }
+    const int incl = wave_inclusive_scan(my_cnt);
+    const int off = incl - my_cnt;
+    const int T = __shfl(incl, 63, 64);
+    for (int base = 0; base < T; base += KNN_CHUNK) {
+        for (int k = 0; k < my_cnt; ++k) {
+            const int j = off + k - base;
+            if (j >= 0 && j < KNN_CHUNK) {
+                const int t = my_start + k;
+                // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
+                const float dx = qx - g.x[t], dy = qy - g.y[t], dz = qz - g.z[t];
+                float dist = dx * dx;
+                dist += dy * dy;
+                dist += dz * dz;
+                skey[j] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(g.idx[t]);
+                spos[j] = t;
             }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const int m = min(KNN_CHUNK, T - base);
+        unsigned long long k0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = lane + 64 * u;
+            k0[u] = j < m ? skey[j] : ~0ull;
+        }
+        for (int round = 0; round < 5; ++round) {
+            unsigned long long mine = k0[0];
+            int mu = 0;
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+                if (k0[u] < mine) mine = k0[u], mu = u;
+            const unsigned long long best = wave_min_u64(mine);
+            if (best == ~0ull) break;
+            const uint64_t own = __ballot(mine == best);
+            const int owner = __ffsll(static_cast<long long>(own)) - 1;
+            const int pos = __shfl(spos[min(lane + 64 * mu, KNN_CHUNK - 1)], owner, 64);
+            if (lane == owner) k0[mu] = ~0ull;
+            // insert (best, pos) into the running ascending list
+            if (best < bk[4]) {
+                int k = 4;
+                while (k > 0 && bk[k - 1] > best) {
+                    bk[k] = bk[k - 1], bp[k] = bp[k - 1];
+                    --k;
+                }
+                bk[k] = best, bp[k] = pos;
+            } else {
+                break;  // chunk keys come out ascending: nothing smaller is left in this chunk
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (bp[k] >= 0) {
+            r.d[k] = __uint_as_float(static_cast<unsigned>(bk[k] >> 32));
+            r.id[k] = static_cast<int>(bk[k] & 0xffffffffu);
+            r.px[k] = g.x[bp[k]], r.py[k] = g.y[bp[k]], r.pz[k] = g.z[bp[k]];
+        } else {
+            r.d[k] = 3.4e38f, r.id[k] = 0x7fffffff, r.px[k] = r.py[k] = r.pz[k] = 0.f;
+        }
+    }
 }
 
 // symmetric 3x3 eigen-decomposition by cyclic Jacobi (stands in for Eigen::SelfAdjointEigenSolver, :606);
@@ -305,13 +355,15 @@ __device__ __forceinline__ void associate_to_map(const double* x7, float px, flo
 }
 
 // slots [0, n_corner_stack): edge candidates; [n_corner_stack, n_corner_stack + n_surf_stack): plane candidates
-__global__ void __launch_bounds__(128) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
+__global__ void __launch_bounds__(256) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
                                                GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
                                                const LMState* __restrict__ st, MapCounters* C, int outer, FactorSoA f) {
+    __shared__ unsigned long long skey[4][KNN_CHUNK];
+    __shared__ int spos[4][KNN_CHUNK];
     if (!C->solve_on) return;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc + ns) return;
+    const int i = blockIdx.x * 4 + wave_id();  // one wave per stack point
+    if (i >= nc + ns || i >= f.cap) return;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
@@ -322,9 +374,9 @@ __global__ void __launch_bounds__(128) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp,
     associate_to_map(x7, ox, oy, oz, sel);
     Knn5 nn;
     if (is_edge)
-        knn5(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], nn);
+        knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
     else
-        knn5(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], nn);
+        knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
     int valid = 0;
     double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
     if (static_cast<double>(nn.d[4]) < 1.0) {  // :585 / :653
@@ -367,16 +419,16 @@ __global__ void __launch_bounds__(128) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp,
             }
         }
     }
-    f.valid[i] = valid;
-    f.kind[i] = is_edge ? 0 : 2;
-    f.cp[i] = ox, f.cp[f.cap + i] = oy, f.cp[2 * f.cap + i] = oz;
-    f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
-    f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
-    const uint64_t be = __ballot(valid && is_edge), bp = __ballot(valid && !is_edge);
-    if (lane_id() == 0) {
-        if (be) atomicAdd(&C->n_edge[outer], __popcll(be));
-        if (bp) atomicAdd(&C->n_plane[outer], __popcll(bp));
-        if (be | bp) atomicAdd(&C->n_live, __popcll(be | bp));
+    if (lane_id() == 0) {  // every lane computed the same block; lane 0 publishes it
+        f.valid[i] = valid;
+        f.kind[i] = is_edge ? 0 : 2;
+        f.cp[i] = ox, f.cp[f.cap + i] = oy, f.cp[2 * f.cap + i] = oz;
+        f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
+        f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
+        if (valid) {
+            atomicAdd(is_edge ? &C->n_edge[outer] : &C->n_plane[outer], 1);
+            atomicAdd(&C->n_live, 1);
+        }
     }
 }
 
@@ -733,22 +785,15 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     }
     // two outer iterations (:563)
     FactorSoA F = c->factors();
-    const int slot_blocks = std::max(1, div_up(c->slot_cap, 256));
-    const int assoc_blocks = std::max(1, div_up(c->slot_cap, 128));
+    const int assoc_blocks = std::max(1, div_up(c->slot_cap, 4));
     for (int outer = 0; outer < 2; ++outer) {
         hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, C, outer);
         {
         ProfScope ps("k_assoc", s);
-        hipLaunchKernelGGL(k_assoc, dim3(assoc_blocks), dim3(128), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p, c->grid[0].start.p,
+        hipLaunchKernelGGL(k_assoc, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p, c->grid[0].start.p,
                            c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, outer, F);
         }
-        hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->solve_on, &C->n_live);
-        hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
-        hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);
-        for (int it = 0; it < 4; ++it) {
-            hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 1, c->partials.p);
-            hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 1);
-        }
+        hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(1024), 0, s, F, &C->n_slots, st, &C->solve_on, &C->n_live);
         hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
     }
     // restore the zero invariant of the cell counters

@@ -39,9 +39,74 @@ __device__ __forceinline__ unsigned long long make_key(float d, unsigned seq) {
     return (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | seq;
 }
 
+constexpr int NN_QT = 64;      // queries per block
+constexpr int NN_TC = 2048;    // target points per block (staged through LDS)
+
+// TransformToStart (:111-129): q_last_curr * p + t_last_curr in f64, stored to f32
+__device__ __forceinline__ void transform_to_start(const double* x7, float ox, float oy, float oz, float* o) {
+    double r[3];
+    quat_rotate(x7, static_cast<double>(ox), static_cast<double>(oy), static_cast<double>(oz), r);
+    o[0] = static_cast<float>(r[0] + 1.0 * x7[4]);
+    o[1] = static_cast<float>(r[1] + 1.0 * x7[5]);
+    o[2] = static_cast<float>(r[2] + 1.0 * x7[6]);
+}
+
+// Exact NN(1), tiled: block (qt, ch) scans target chunk ch (2048 points staged in LDS, read as wave-wide broadcasts)
+// for 64 queries; thread (q = tid % 64, part = tid / 64) covers a quarter of the chunk.  The per-(query, chunk) minima
+// are (f32 distance bits, target index) keys; k_odom_assoc takes the minimum over chunks.
+__global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st,
+                                                 const OdomCounters* __restrict__ C, int slot_cap, int nch, unsigned long long* __restrict__ part) {
+    __shared__ float tx[NN_TC], ty[NN_TC], tz[NN_TC];
+    __shared__ unsigned long long red[4][NN_QT];
+    if (!C->enable) return;
+    const int ns = C->n_sharp, nf = C->n_flat;
+    // a tile never mixes sharp and flat queries: tiles are laid out per class
+    const int sharp_tiles = (ns + NN_QT - 1) / NN_QT;
+    const bool is_edge = static_cast<int>(blockIdx.x) < sharp_tiles;
+    const int qbase = is_edge ? blockIdx.x * NN_QT : (blockIdx.x - sharp_tiles) * NN_QT;
+    const int nq = is_edge ? ns : nf;
+    if (qbase >= nq) return;
+    const CSoA4& Q = is_edge ? sharp : flat;
+    const CSoA4& T = is_edge ? CL : SL;
+    const int nT = is_edge ? C->n_corner_last : C->n_surf_last;
+    const int t0 = blockIdx.y * NN_TC;
+    if (t0 >= nT) return;
+    const int tn = min(NN_TC, nT - t0);
+    for (int i = threadIdx.x; i < tn; i += 256) tx[i] = T.x[t0 + i], ty[i] = T.y[t0 + i], tz[i] = T.z[t0 + i];
+    __syncthreads();
+    const int ql = threadIdx.x & 63, partq = threadIdx.x >> 6;
+    const int qi = qbase + ql;
+    unsigned long long best = ~0ull;
+    if (qi < nq) {
+        double x7[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+        float sel[3];
+        transform_to_start(x7, Q.x[qi], Q.y[qi], Q.z[qi], sel);
+        const int per = (tn + 3) / 4;
+        const int b0 = partq * per, b1 = min(tn, b0 + per);
+        for (int t = b0; t < b1; ++t) {
+            const float dx = sel[0] - tx[t], dy = sel[1] - ty[t], dz = sel[2] - tz[t];
+            float d = dx * dx;  // FLANN L2_Simple<float>
+            d += dy * dy;
+            d += dz * dz;
+            const unsigned long long k = make_key(d, static_cast<unsigned>(t0 + t));
+            best = k < best ? k : best;
+        }
+    }
+    red[partq][ql] = best;
+    __syncthreads();
+    if (partq == 0 && qi < nq) {
+        unsigned long long b = red[0][ql];
+        for (int p = 1; p < 4; ++p) b = red[p][ql] < b ? red[p][ql] : b;
+        const int slot = is_edge ? qi : ns + qi;
+        if (slot < slot_cap) part[(size_t)slot * nch + blockIdx.y] = b;
+    }
+}
+
 // one wave per query
 __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st, OdomCounters* C,
-                                                    int outer, FactorSoA f) {
+                                                    int outer, FactorSoA f, int nch, const unsigned long long* __restrict__ part) {
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
     const int q = blockIdx.x * 4 + wave_id();
@@ -56,19 +121,15 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
     const float ox = Q.x[j], oy = Q.y[j], oz = Q.z[j];
-    // TransformToStart: q_last_curr * p + t_last_curr in f64, stored to f32 (:120-127)
-    double r[3];
-    quat_rotate(x7, static_cast<double>(ox), static_cast<double>(oy), static_cast<double>(oz), r);
-    const float sx = static_cast<float>(r[0] + 1.0 * x7[4]), sy = static_cast<float>(r[1] + 1.0 * x7[5]), sz = static_cast<float>(r[2] + 1.0 * x7[6]);
+    float sel[3];
+    transform_to_start(x7, ox, oy, oz, sel);
+    const float sx = sel[0], sy = sel[1], sz = sel[2];
 
-    // ---- NN(1): exact argmin of FLANN's L2_Simple<float>
+    // ---- NN(1): minimum over the per-chunk minima of k_odom_nn (exact argmin of FLANN's L2_Simple<float>, ties -> lower index)
     unsigned long long best = ~0ull;
-    for (int t = lane; t < nT; t += 64) {
-        const float dx = sx - T.x[t], dy = sy - T.y[t], dz = sz - T.z[t];
-        float d = dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        const unsigned long long k = make_key(d, static_cast<unsigned>(t));
+    const int used = (nT + NN_TC - 1) / NN_TC;
+    for (int ch = lane; ch < used; ch += 64) {
+        const unsigned long long k = part[(size_t)q * nch + ch];
         best = k < best ? k : best;
     }
     best = wave_min_u64(best);
@@ -230,6 +291,8 @@ struct scal_odom {
     OSoA corner_last, surf_last;              // previous scan (kd-tree inputs, :567-568)
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<unsigned long long> nn_part;
+    int nch = 1;
     DevBuf<LMState> d_st;
     DevBuf<OdomCounters> d_C;
     PinBuf<OdomCounters> h_C;
@@ -258,6 +321,8 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->fvalid.alloc(c->slot_cap)); A(c->fkind.alloc(c->slot_cap));
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
+    c->nch = std::max(1, div_up(c->cap, NN_TC));
+    A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
@@ -310,21 +375,20 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     FactorSoA F = c->factors();
     const bool solve = c->systemInited;  // first frame: no optimisation (:267-271)
     if (solve) {
-        const int slot_blocks = std::max(1, div_up(c->slot_cap, 256));
         for (int outer = 0; outer < 2; ++outer) {  // :278
             hipLaunchKernelGGL(k_odom_outer_begin, dim3(1), dim3(1), 0, s, C, outer, c->slot_cap);
             {
-            ProfScope ps("k_odom_assoc", s);
-            hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
-                               c->surf_last.cv(), st, C, outer, F);
+                ProfScope ps("k_odom_nn", s);
+                // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
+                hipLaunchKernelGGL(k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                                   c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
             }
-            hipLaunchKernelGGL(k_lm_reset, dim3(1), dim3(1), 0, s, st, &C->enable, &C->n_live);
-            hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 0, c->partials.p);
-            hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 0);
-            for (int it = 0; it < 4; ++it) {
-                hipLaunchKernelGGL(k_lm_eval, dim3(slot_blocks), dim3(256), 0, s, F, &C->n_slots, st, 1, c->partials.p);
-                hipLaunchKernelGGL(k_lm_step, dim3(1), dim3(64), 0, s, st, c->partials.p, &C->n_slots, c->slot_cap, 1);
+            {
+                ProfScope ps("k_odom_assoc", s);
+                hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p);
             }
+            hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(1024), 0, s, F, &C->n_slots, st, &C->enable, &C->n_live);
             hipLaunchKernelGGL(k_odom_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
         }
     }

@@ -477,7 +477,20 @@ extern "C" int scal_sc_size(scal_sc_t* c) {
 // the staged descriptor/keys become keyframe n_global; stored only when this shard owns that index
 static int commit_staged(scal_sc* c) {
     hipStream_t s = c->stream;
-    SCAL_TRY(commit_staged(c));
+    const int g = c->n_global;
+    if (c->owns(g)) {
+        if (c->n_local >= c->cap) {
+            set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
+            return SCAL_E_CAPACITY;
+        }
+        const size_t sl = c->n_local;
+        SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
+        SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
+        c->n_local++;
+    }
+    c->n_global++;
     return SCAL_OK;
 }
 

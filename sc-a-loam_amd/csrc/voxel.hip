@@ -22,6 +22,7 @@ __global__ void k_vox_reset(VoxMeta* m) {
 }
 
 __global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restrict__ d_n, VoxMeta* m) {
+    __shared__ unsigned s_lo[3][4], s_hi[3][4];
     const int n = *d_n;
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -37,10 +38,15 @@ __global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restric
             lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
             hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
         }
-        if (lane_id() == 0) {
-            atomicMin(&m->umin[a], lo[a]);
-            atomicMax(&m->umax[a], hi[a]);
-        }
+        if (lane_id() == 0) s_lo[a][wave_id()] = lo[a], s_hi[a][wave_id()] = hi[a];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {  // one atomic pair per block and axis
+        const int a = threadIdx.x;
+        const unsigned l = min(min(s_lo[a][0], s_lo[a][1]), min(s_lo[a][2], s_lo[a][3]));
+        const unsigned h = max(max(s_hi[a][0], s_hi[a][1]), max(s_hi[a][2], s_hi[a][3]));
+        if (l != 0xffffffffu) atomicMin(&m->umin[a], l);
+        if (h != 0u) atomicMax(&m->umax[a], h);
     }
 }
 
@@ -132,7 +138,7 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, float leaf, int bi
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
     const int nb = max(1, div_up(cap, 256));
     hipLaunchKernelGGL(k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
-    hipLaunchKernelGGL(k_vox_bbox, dim3(min(nb, 1024)), dim3(256), 0, s, in, d_n, meta.p);
+    hipLaunchKernelGGL(k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
     hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, bits, meta.p, keys.p, vals.p);
     unsigned long long* sk;
     int* sv;

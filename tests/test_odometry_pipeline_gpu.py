@@ -112,3 +112,29 @@ def test_odometry_capacity_error(S):
         go.step(z, z, z, np.zeros((2000, 4), np.float32))
     assert e.value.code == S.E_TOO_MANY
     go.close()
+
+
+def test_sc_insert_features_matches_host_path(O, S, hdl64_stream):
+    """scal_sc_insert_features (ordered cloud -> VoxelGrid 0.4 -> descriptor, all on the GPU) vs the oracle chain, and the
+    detector on top of it."""
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
+    sc = S.SCManager(dist_thres=0.4)
+    osc = O.SCManager(dist_thres=0.4)
+    rng = np.random.default_rng(3)
+    for i in range(40):
+        d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+        sc.saveScancontextAndKeys(d)
+        osc.saveScancontextAndKeys(d)
+    for k in range(4):
+        f = reg.laserCloudHandler(hdl64_stream(k))
+        sc.insert_features(reg)
+        ds, _ = O.voxel_grid(f["cloud"], 0.4)
+        osc.makeAndSaveScancontextAndKeys(ds)
+        dg, kg = sc.get(40 + k)
+        do, ko = osc.get(40 + k)
+        assert np.array_equal(dg, do) and np.array_equal(kg.view(np.uint32), ko.view(np.uint32)), k
+        rg, ro = sc.detectLoopClosureID(), osc.detectLoopClosureID()
+        assert rg["loop_id"] == ro["loop_id"] and rg["nn_idx"] == ro["nn_idx"] and abs(rg["min_dist"] - ro["min_dist"]) <= 1e-12
+    assert sc.size() == 44
+    reg.close()
+    sc.close()
