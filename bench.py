@@ -29,7 +29,6 @@ for p in ("oracle", os.path.join("sc-a-loam_amd", "python"), os.path.join("tools
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-DOMINANT_KERNEL = "k_assoc"  # see DESIGN.md section "Roofline": scan-to-map association (kNN + fit), launched 2x per scan
 
 
 def parse():
@@ -96,7 +95,7 @@ def main():
         d_rec = torch.zeros(world * 3 * 24, dtype=torch.uint8, device="cuda")
         all_rec = torch.zeros(world, world * 3 * 24, dtype=torch.uint8, device="cuda")
     sc_state = dict(counter=0, size_at_rebuild=0, n_global=a.sc_db)
-    stats = dict(loops=0, blocks=0, stack_pts=0, solved=0)
+    stats = dict(loops=0, blocks=0, stack_pts=0, solved=0, map_pts=0)
 
     def step(k):
         reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
@@ -128,6 +127,7 @@ def main():
         stats["blocks"] += mst.n_edge[0] + mst.n_plane[0] + mst.n_edge[1] + mst.n_plane[1]
         stats["stack_pts"] += mst.n_corner_stack + mst.n_surf_stack
         stats["solved"] += mst.solved
+        stats["map_pts"] += mst.n_map_corner_total + mst.n_map_surf_total
         return qm, tm
 
     def fence():
@@ -150,6 +150,12 @@ def main():
     dt = time.perf_counter() - t0
     S.prof_enable(False)
     prof = S.prof_read_all()
+    # sizes of one representative scan (outside the timed region) for the algorithmic-byte formulas
+    reg.run_device(d_scans[W + K - 1].data_ptr(), npts[W + K - 1], 3)
+    fz = reg.fetch()
+    counts = dict(n_in=npts[W + K - 1], n_kept=fz["n_kept"], n_sharp=len(fz["sharp"]), n_less_sharp=len(fz["less_sharp"]), n_flat=len(fz["flat"]),
+                  n_less_flat=fz["less_flat"].shape[0], stack_pts=stats["stack_pts"] / max(1, K), blocks=stats["blocks"] / max(1, 2 * K),
+                  map_pts=stats["map_pts"] / max(1, K))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,20 +164,8 @@ def main():
     out = None
     if rank == 0:
         value = world * K / dt
-        # ---- roofline of the dominant kernel (HBM bound): algorithmic bytes per launch / measured launch time
-        # k_assoc, per launch (one outer iteration): every stack point (16 B) + its 5 neighbours (5 x 16 B) read,
-        # one residual block written (72 B edge / 56 B plane)  [SURVEY.md section 8d, stage C association term]
-        ms, cnt = prof.get(DOMINANT_KERNEL, (0.0, 0))
-        roofline = None
-        if cnt:
-            avg_s = ms / cnt * 1e-3
-            pts_per_launch = stats["stack_pts"] / max(1, K)          # stack points associated per launch
-            blocks_per_launch = stats["blocks"] / max(1, 2 * K)      # residual blocks written per launch
-            alg_bytes = pts_per_launch * 16.0 * 6.0 + blocks_per_launch * 64.0
-            ach = alg_bytes / avg_s / 1e9
-            roofline = {"bound": "hbm", "kernel": DOMINANT_KERNEL, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": cnt,
-                        "algorithmic_bytes_per_launch": alg_bytes}
+        # ---- roofline of the dominant kernel (HBM bound): algorithmic bytes per launch / measured average launch time
+        roofline = roofline_of(prof, K, counts)
         cpu = None
         if world == 1 and a.cpu_sample > 0:
             cpu = cpu_baseline(scans[: min(total, a.cpu_sample)], a.sc_db)
@@ -194,6 +188,38 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return out
+
+
+def roofline_of(prof, K, c):
+    """Pick the kernel with the largest total time in the timed region (HIP events on its stream) and price it against
+    the HBM roofline with ALGORITHMIC bytes per launch (SURVEY.md section 8d per-unit figures; DESIGN.md "Kernels")."""
+    if not prof:
+        return None
+    M = c["stack_pts"]
+    per_launch_bytes = {
+        # stage A selection: ordered cloud xyzi + curvature read once, picked / lessFlat points written once
+        "k_ring": 20.0 * c["n_kept"] + 16.0 * (c["n_sharp"] + c["n_less_sharp"] + c["n_flat"] + c["n_less_flat"]),
+        # one radix pass moves every (key, value) pair once: 12 B read + 12 B written; mean pair count over the sorts of a scan
+        "k_rs_scatter": 24.0 * (3 * c["n_kept"] + 3 * c["n_less_flat"] + 4 * (c["map_pts"] + M)) / 10.0,
+        # one evaluation reads every residual block once (72 B edge / 56 B plane-norm parameters + 8 B kind/valid)
+        "k_lm_iter": 80.0 * M,
+        # association: each stack point (16 B) and its 5 neighbours (5 x 16 B); fit: 5 neighbours in, one block out
+        "k_assoc_knn": 16.0 * M * 6.0,
+        "k_assoc_fit": 16.0 * M * 5.0 + 64.0 * c["blocks"],
+        # odometry NN: target clouds read once, queries once, one 8 B partial per (query, chunk)
+        "k_odom_nn": 12.0 * (c["n_less_sharp"] + c["n_less_flat"]) + 16.0 * (c["n_sharp"] + c["n_flat"]),
+        "k_odom_assoc": 16.0 * (c["n_sharp"] + c["n_flat"]) * (1.0 + 5.0 * c["n_less_flat"] / 51.0 / 16.0),
+        "k_vox_small": 16.0 * c["n_less_sharp"] * 2.0,
+    }
+    name = max(prof, key=lambda k: prof[k][0])
+    ms, cnt = prof[name]
+    if not cnt or name not in per_launch_bytes:
+        return None
+    avg_s = ms / cnt * 1e-3
+    ach = per_launch_bytes[name] / avg_s / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": per_launch_bytes[name],
+            "share_of_step": ms / K, "all_kernels_ms_per_step": {k: v[0] / K for k, v in sorted(prof.items())}}
 
 
 def cpu_baseline(scans, sc_db):

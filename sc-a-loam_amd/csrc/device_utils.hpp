@@ -98,6 +98,78 @@ __device__ __forceinline__ void block_bitonic_sort_u64(unsigned long long* s, in
     }
 }
 
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    const unsigned lo = static_cast<unsigned>(__shfl_xor(static_cast<int>(v & 0xffffffffu), mask, 64));
+    const unsigned hi = static_cast<unsigned>(__shfl_xor(static_cast<int>(v >> 32), mask, 64));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+
+// Bitonic stages k = 2 .. 512 on 512 keys held by ONE wave, 8 per lane, element index = r*64 + lane (r = 0..7).
+// No LDS, no barrier: partners closer than 64 are exchanged with lane shuffles, the others live in the same lane.
+// The direction of every compare follows the global network: ascending iff ((global_base + index) & k) == 0, so the
+// chunk can be one 512-block of a larger bitonic sort that continues in LDS from k = 1024.
+__device__ __forceinline__ void wave_bitonic_sort512(unsigned long long (&v)[8], int global_base) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int k = 2; k <= 512; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int rr = j >> 6;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if ((r & rr) == 0) {
+                        const bool up = ((global_base + r * 64 + lane) & k) == 0;
+                        const unsigned long long a = v[r], b = v[r | rr];
+                        if ((a > b) == up) v[r] = b, v[r | rr] = a;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const unsigned long long a = v[r];
+                    const unsigned long long p = shfl_xor_u64(a, j);
+                    const bool up = ((global_base + r * 64 + lane) & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const unsigned long long mn = a < p ? a : p, mx = a < p ? p : a;
+                    v[r] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+// Bitonic sort of n_pow2 (>= 512, power of two) uint64 keys in LDS: every 512-chunk is first sorted in registers by one
+// wave (no barriers), then only the merge stages k >= 1024 run through LDS with block barriers.
+__device__ __forceinline__ void block_bitonic_sort_u64_fast(unsigned long long* s, int n_pow2) {
+    const int nw = blockDim.x >> 6, w = wave_id(), lane = lane_id();
+    for (int c = w; c * 512 < n_pow2; c += nw) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = s[c * 512 + r * 64 + lane];
+        wave_bitonic_sort512(v, c * 512);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s[c * 512 + r * 64 + lane] = v[r];
+    }
+    __syncthreads();
+    const int half = n_pow2 >> 1;
+    for (int k = 1024; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < half; t += blockDim.x) {
+                const int i = 2 * t - (t & (j - 1));
+                const int ixj = i + j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = s[i], b = s[ixj];
+                if ((a > b) == up) {
+                    s[i] = b;
+                    s[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // lanes of the wave whose `digit` equals mine (among `valid` lanes); BITS ballots.
 template <int BITS>
 __device__ __forceinline__ uint64_t wave_match(uint32_t digit, bool valid) {

@@ -268,22 +268,23 @@ __global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, 
     gap[i] = g;
 }
 
-// mark the +-5 neighbours of ring-relative index `li` as picked (:332-355); executed by wave 0
-__device__ __forceinline__ void suppress_neighbours(unsigned char* picked, const unsigned char* __restrict__ gap, int gidx, int li, int lane) {
-    // forward: l = 1..5 stops at the first gap between (ind+l-1, ind+l) => gap[ind+l-1]
+// mark the +-5 neighbours of ring-relative index `li` as picked (:332-355); executed by wave 0.
+// flags[] lives in LDS: bit 0 = cloudNeighborPicked, bit 1 = "the squared gap to the NEXT point exceeds 0.05".
+__device__ __forceinline__ void suppress_neighbours(unsigned char* flags, int li, int lane) {
+    // forward: l = 1..5 stops at the first gap between (ind+l-1, ind+l) => gap bit of ind+l-1
     bool g = false;
-    if (lane >= 1 && lane <= 5) g = gap[gidx + lane - 1] != 0;
+    if (lane >= 1 && lane <= 5) g = (flags[li + lane - 1] & 2) != 0;
     uint64_t gm = __ballot(g) >> 1;  // bit k-1 set <=> step l=k is blocked
     int nf = gm ? (__ffsll(static_cast<long long>(gm)) - 1) : 5;
     nf = min(nf, 5);
-    if (lane >= 1 && lane <= nf) picked[li + lane] = 1;
-    // backward: l = -1..-5 stops at the first gap between (ind+l, ind+l+1) => gap[ind+l]
+    // backward: l = -1..-5 stops at the first gap between (ind+l, ind+l+1) => gap bit of ind+l
     bool gb = false;
-    if (lane >= 1 && lane <= 5) gb = gap[gidx - lane] != 0;
+    if (lane >= 1 && lane <= 5) gb = (flags[li - lane] & 2) != 0;
     uint64_t gbm = __ballot(gb) >> 1;
     int nbk = gbm ? (__ffsll(static_cast<long long>(gbm)) - 1) : 5;
     nbk = min(nbk, 5);
-    if (lane >= 1 && lane <= nbk) picked[li - lane] = 1;
+    if (lane >= 1 && lane <= nf) flags[li + lane] |= 1;
+    if (lane >= 1 && lane <= nbk) flags[li - lane] |= 1;
 }
 
 __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const float* __restrict__ x, const float* __restrict__ y,
@@ -311,26 +312,60 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         if (tid == 0) atomicExch(&P->error, SCAL_E_CAPACITY);
         return;
     }
-    for (int t = tid; t < cnt + 16; t += blockDim.x) picked[t] = 0;
+    for (int t = tid; t < cnt + 16; t += blockDim.x) picked[t] = (t < cnt && gap[rs + t]) ? 2 : 0;
     __syncthreads();
 
+    // segment bounds (:297-298)
+    int seg_sp[6], seg_L[6];
+    int maxL = 0;
+#pragma unroll
     for (int j = 0; j < 6; ++j) {
-        const int sp = start + (end - start) * j / 6;             // :297
-        const int ep = start + (end - start) * (j + 1) / 6 - 1;   // :298
-        const int L = ep - sp + 1;
-        const int Lp = max(2, next_pow2(L));
-        for (int t = tid; t < Lp; t += blockDim.x) {
-            unsigned long long k = ~0ull;
-            if (t < L) k = (static_cast<unsigned long long>(__float_as_uint(curv[sp + t])) << 32) | static_cast<unsigned>(sp + t - rs);
-            keys[t] = k;  // curvature >= 0, so its bit pattern orders like the float; ties fall back to the index
+        seg_sp[j] = start + (end - start) * j / 6;
+        seg_L[j] = start + (end - start) * (j + 1) / 6 - 1 - seg_sp[j] + 1;
+        maxL = max(maxL, seg_L[j]);
+    }
+    const bool fast = maxL <= 512;  // every segment fits one wave's registers (8 keys per lane)
+    if (fast) {
+        // six waves sort the six segments concurrently in registers (:290-302), keys land in LDS at j*512
+        if (wv < 6) {
+            const int sp = seg_sp[wv], L = seg_L[wv];
+            unsigned long long v[8];
+            bool tie = false;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int t = r * 64 + lane;
+                v[r] = t < L ? ((static_cast<unsigned long long>(__float_as_uint(curv[sp + t])) << 32) | static_cast<unsigned>(sp + t - rs)) : ~0ull;
+            }
+            wave_bitonic_sort512(v, 0);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) keys[wv * 512 + r * 64 + lane] = v[r];
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            for (int t = lane; t + 1 < L; t += 64) tie |= (keys[wv * 512 + t] >> 32) == (keys[wv * 512 + t + 1] >> 32);
+            if (__ballot(tie) && lane == 0) atomicAdd(&P->n_tied, 1);
         }
         __syncthreads();
-        block_bitonic_sort_u64(keys, Lp);
-        bool tie = false;
-        for (int t = tid; t + 1 < L; t += blockDim.x) tie |= (keys[t] >> 32) == (keys[t + 1] >> 32);
-        if (__syncthreads_or(tie) && tid == 0) atomicAdd(&P->n_tied, 1);
+    }
+    for (int j = 0; j < 6; ++j) {
+        const int sp = seg_sp[j];
+        const int L = seg_L[j];
+        unsigned long long* skeys = keys + (fast ? j * 512 : 0);
+        if (!fast) {
+            const int Lp = max(2, next_pow2(L));
+            for (int t = tid; t < Lp; t += blockDim.x) {
+                unsigned long long k = ~0ull;
+                if (t < L) k = (static_cast<unsigned long long>(__float_as_uint(curv[sp + t])) << 32) | static_cast<unsigned>(sp + t - rs);
+                keys[t] = k;  // curvature >= 0, so its bit pattern orders like the float; ties fall back to the index
+            }
+            __syncthreads();
+            block_bitonic_sort_u64(keys, Lp);
+            bool tie = false;
+            for (int t = tid; t + 1 < L; t += blockDim.x) tie |= (keys[t] >> 32) == (keys[t + 1] >> 32);
+            if (__syncthreads_or(tie) && tid == 0) atomicAdd(&P->n_tied, 1);
+        }
 
         if (wv == 0) {
+            const unsigned long long* keys = skeys;  // this segment's sorted keys
             const int seg = r * 6 + j;
             // ---- sharp / lessSharp: largest curvature first (:304-357)
             int largestPickedNum = 0, n_sh = 0, n_ls = 0;
@@ -343,7 +378,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
                 const int li = static_cast<int>(k & 0xffffffffu);
                 const float c = __uint_as_float(static_cast<unsigned>(k >> 32));
                 const bool big = valid && static_cast<double>(c) > 0.1;
-                const bool ok = big && picked[li] == 0;
+                const bool ok = big && (picked[li] & 1) == 0;
                 const uint64_t okm = __ballot(ok);
                 const uint64_t stopm = __ballot(valid && !big);  // sorted: nothing after this can pass c > 0.1
                 const int first_stop = stopm ? __ffsll(static_cast<long long>(stopm)) - 1 : 64;
@@ -372,8 +407,8 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
                     done = true;
                     break;
                 }
-                if (lane == 0) picked[pli] = 1;
-                suppress_neighbours(picked, gap, rs + pli, pli, lane);
+                if (lane == 0) picked[pli] |= 1;
+                suppress_neighbours(picked, pli, lane);
                 __builtin_amdgcn_wave_barrier();
                 base += first_ok + 1;
             }
@@ -387,7 +422,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
                 const int li = static_cast<int>(k & 0xffffffffu);
                 const float c = __uint_as_float(static_cast<unsigned>(k >> 32));
                 const bool small = valid && static_cast<double>(c) < 0.1;
-                const bool ok = small && picked[li] == 0;
+                const bool ok = small && (picked[li] & 1) == 0;
                 const uint64_t okm = __ballot(ok);
                 const uint64_t stopm = __ballot(valid && !small);
                 const int first_stop = stopm ? __ffsll(static_cast<long long>(stopm)) - 1 : 64;
@@ -404,8 +439,8 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
                 }
                 smallestPickedNum++;
                 if (smallestPickedNum >= 4) break;  // the 4th is appended but neither marked nor suppressing (:371-375)
-                if (lane == 0) picked[pli] = 1;
-                suppress_neighbours(picked, gap, rs + pli, pli, lane);
+                if (lane == 0) picked[pli] |= 1;
+                suppress_neighbours(picked, pli, lane);
                 __builtin_amdgcn_wave_barrier();
                 base += first_ok + 1;
             }
@@ -498,7 +533,10 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         }
     }
     __syncthreads();
-    block_bitonic_sort_u64(keys, Mp);
+    if (Mp >= 512)
+        block_bitonic_sort_u64_fast(keys, Mp);
+    else
+        block_bitonic_sort_u64(keys, Mp);
     // heads of voxel runs -> output slots
     const int per2 = (m + blockDim.x - 1) / blockDim.x;
     const int c0 = min(m, tid * per2), c1 = min(m, c0 + per2);

@@ -16,6 +16,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_utils.hpp"
+#include "common.hpp"
+#include <cstdlib>
 
 namespace scal {
 
@@ -37,7 +39,8 @@ struct LMState {
     int iteration, done, successful, started, enabled;
     int termination;  // 0 max iterations, 1 gradient, 2 parameter, 3 function, 4 no residual blocks
     double cost_init, cost_final;
-    int n_blocks_live[3];
+    int ticket;  // arrival counter of k_lm_iter
+    int pad_[2];
 };
 
 __device__ __forceinline__ void quat_plus(const double* x, const double* delta, double* o) {
@@ -103,56 +106,69 @@ __device__ __forceinline__ void factor_accumulate(int kind, const double* cp, co
         for (int c = 0; c < 3; ++c) JL[r][c] = A[r][0] * P[0][c] + A[r][1] * P[1][c] + A[r][2] * P[2][c] + bq[r] * P[3][c];
         JL[r][3] = r == 0, JL[r][4] = r == 1, JL[r][5] = r == 2;
     }
-    double res[3], J[3][6];
-    int nr;
+    // One residual row -> (g, H); HuberLoss(0.1): rho = s | 2a sqrt(s) - a^2, rho' = 1 | a/sqrt(s); rho'' <= 0 => rows
+    // scaled by sqrt(rho').  Everything below is straight-line code with compile-time indices: no private-memory spills.
+    const double huber_a = 0.1, huber_b = huber_a * huber_a;  // HuberLoss(a): b_ = a*a = 0.010000000000000002
+    auto huber = [&](double s, double& rho0, double& rho1) {
+        if (s > huber_b) {
+            const double rt = sqrt(s);
+            rho0 = 2.0 * huber_a * rt - huber_b;
+            rho1 = fmax(2.2250738585072014e-308, huber_a / rt);
+        } else {
+            rho0 = s, rho1 = 1.0;
+        }
+    };
+    auto add_row = [&](const double* Jr, double res, double rho1) {
+        int k = 7;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            acc[1 + a] += rho1 * Jr[a] * res;
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[k++] += rho1 * Jr[a] * Jr[b];
+        }
+    };
     if (kind == 0) {  // r = (lp-a) x (lp-b) / |a-b| ; dr/dlp = [b-a]x / |a-b|
         const double ax = lp[0] - pa[0], ay = lp[1] - pa[1], az = lp[2] - pa[2];
         const double bx = lp[0] - pb[0], by = lp[1] - pb[1], bz = lp[2] - pb[2];
         const double dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
         const double den = sqrt(dx * dx + dy * dy + dz * dz);
-        res[0] = (ay * bz - az * by) / den, res[1] = (az * bx - ax * bz) / den, res[2] = (ax * by - ay * bx) / den;
+        const double r0 = (ay * bz - az * by) / den, r1 = (az * bx - ax * bz) / den, r2 = (ax * by - ay * bx) / den;
         const double ex = -dx / den, ey = -dy / den, ez = -dz / den;  // (b - a)/den
+        double J0[6], J1[6], J2[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            J[0][c] = -ez * JL[1][c] + ey * JL[2][c];
-            J[1][c] = ez * JL[0][c] - ex * JL[2][c];
-            J[2][c] = -ey * JL[0][c] + ex * JL[1][c];
+            J0[c] = -ez * JL[1][c] + ey * JL[2][c];
+            J1[c] = ez * JL[0][c] - ex * JL[2][c];
+            J2[c] = -ey * JL[0][c] + ex * JL[1][c];
         }
-        nr = 3;
+        double s = 0;
+        s += r0 * r0;
+        s += r1 * r1;
+        s += r2 * r2;
+        double rho0, rho1;
+        huber(s, rho0, rho1);
+        acc[0] += 0.5 * rho0;
+        add_row(J0, r0, rho1);
+        add_row(J1, r1, rho1);
+        add_row(J2, r2, rho1);
     } else {
-        double nx, ny, nz;
+        double nx, ny, nz, r0;
         if (kind == 1) {  // (lp - j) . n
             nx = pb[0], ny = pb[1], nz = pb[2];
-            res[0] = (lp[0] - pa[0]) * nx + (lp[1] - pa[1]) * ny + (lp[2] - pa[2]) * nz;
+            r0 = (lp[0] - pa[0]) * nx + (lp[1] - pa[1]) * ny + (lp[2] - pa[2]) * nz;
         } else {  // n . lp + d
             nx = pa[0], ny = pa[1], nz = pa[2];
-            res[0] = (nx * lp[0] + ny * lp[1] + nz * lp[2]) + pb[0];
+            r0 = (nx * lp[0] + ny * lp[1] + nz * lp[2]) + pb[0];
         }
+        double J0[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) J[0][c] = nx * JL[0][c] + ny * JL[1][c] + nz * JL[2][c];
-        nr = 1;
-    }
-    double s = 0;
-    for (int r = 0; r < nr; ++r) s += res[r] * res[r];
-    // HuberLoss(0.1): rho = s | 2a sqrt(s) - a^2 ; rho' = 1 | a / sqrt(s); rho'' <= 0 => scale rows by sqrt(rho')
-    double rho0, rho1;
-    const double huber_a = 0.1, huber_b = huber_a * huber_a;  // HuberLoss(a): b_ = a*a = 0.010000000000000002
-    if (s > huber_b) {
-        const double rt = sqrt(s);
-        rho0 = 2.0 * huber_a * rt - huber_b;
-        rho1 = fmax(2.2250738585072014e-308, 0.1 / rt);
-    } else {
-        rho0 = s, rho1 = 1.0;
-    }
-    acc[0] += 0.5 * rho0;
-    for (int r = 0; r < nr; ++r) {
-        int k = 7;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            acc[1 + a] += rho1 * J[r][a] * res[r];
-#pragma unroll
-            for (int b = a; b < 6; ++b) acc[k++] += rho1 * J[r][a] * J[r][b];
-        }
+        for (int c = 0; c < 6; ++c) J0[c] = nx * JL[0][c] + ny * JL[1][c] + nz * JL[2][c];
+        double s = 0;
+        s += r0 * r0;
+        double rho0, rho1;
+        huber(s, rho0, rho1);
+        acc[0] += 0.5 * rho0;
+        add_row(J0, r0, rho1);
     }
 }
 
@@ -196,9 +212,12 @@ __device__ __forceinline__ int hidx(int a, int b) {  // index into upper-triangu
 // solve (Hs + diag(d2)) y = gs by Cholesky; returns false when not positive definite / not finite
 __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, const double* gs, double* y) {
     double L[6][6];
+#pragma unroll
     for (int i = 0; i < 6; ++i)
+#pragma unroll
         for (int j = 0; j <= i; ++j) {
             double s = Hs[hidx(j, i)] + (i == j ? d2[i] : 0.0);
+#pragma unroll
             for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
             if (i == j) {
                 if (!(s > 0.0)) return false;
@@ -208,16 +227,21 @@ __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, 
             }
         }
     double z[6];
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = gs[i];
+#pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i][k] * z[k];
         z[i] = s / L[i][i];
     }
+#pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = z[i];
+#pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
         y[i] = s / L[i][i];
     }
+#pragma unroll
     for (int i = 0; i < 6; ++i)
         if (!isfinite(y[i])) return false;
     return true;
@@ -233,10 +257,13 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
         }
         st->iteration++;
         double Hs[21], gs[6], d2[6];
+#pragma unroll
         for (int a = 0; a < 6; ++a) {
             gs[a] = st->g[a] * st->scale[a];
+#pragma unroll
             for (int b = a; b < 6; ++b) Hs[hidx(a, b)] = st->H[hidx(a, b)] * st->scale[a] * st->scale[b];
         }
+#pragma unroll
         for (int a = 0; a < 6; ++a) d2[a] = fmin(fmax(Hs[hidx(a, a)], 1e-6), 1e32) / st->radius;
         double y[6];
         bool ok = chol_solve6(Hs, d2, gs, y);
@@ -244,9 +271,11 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
         if (ok) {
             // model_cost_change = -(J s).(r + J s/2) with s = -y  =  y.gs - y^T Hs y / 2
             double yg = 0.0, yhy = 0.0;
+#pragma unroll
             for (int a = 0; a < 6; ++a) {
                 yg += y[a] * gs[a];
                 double row = 0.0;
+#pragma unroll
                 for (int b = 0; b < 6; ++b) row += Hs[a <= b ? hidx(a, b) : hidx(b, a)] * y[b];
                 yhy += y[a] * row;
             }
@@ -259,6 +288,7 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
             continue;
         }
         double delta[6];
+#pragma unroll
         for (int a = 0; a < 6; ++a) delta[a] = -y[a] * st->scale[a];
         st->mcc = mcc;
         quat_plus(st->x, delta, st->cand);
@@ -266,20 +296,89 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
     }
 }
 
-// One wave.  phase 0: partials hold the evaluation at x (iteration zero).  phase 1: at the candidate.
-static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double* __restrict__ partials, const int* __restrict__ d_nslots, int cap,
-                                                int phase) {
+// One LM round per launch: every block evaluates its share of the residual blocks at the current point (phase 0: the
+// accepted point, phase 1: the candidate) and publishes 28 partial sums; the LAST block to arrive (agent-scope release on
+// the producers, ticket atomic, agent-scope acquire on the consumer: cdna_hip_programming.md Guideline 16) sums the
+// partials in block order (bitwise reproducible) and advances Ceres' trust-region state machine.  No block ever waits,
+// so there is nothing to deadlock; a finished solve turns the remaining launches into no-ops.
+static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase,
+                                                        const int* __restrict__ d_enable, const int* __restrict__ d_live,
+                                                        double* partials, int dbg_mode) {
+    __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
-    if (!st->enabled || st->done) return;
-    const int n = d_nslots ? min(*d_nslots, cap) : cap;
-    const int nb = (n + 255) / 256;
-    if (threadIdx.x < LM_NACC) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += partials[b * LM_NACC + threadIdx.x];  // fixed order
-        tot[threadIdx.x] = s;
+    __shared__ int s_last;
+    const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
+    const int nb = max(1, (n + 255) / 256);
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    const int tid = threadIdx.x;
+    int enabled, done;
+    if (phase == 0) {  // (re)arm: the state of the previous solve is stale, only x carries over
+        enabled = d_enable ? *d_enable : 1;
+        done = (d_live && *d_live == 0) ? 1 : 0;  // no residual blocks: Ceres returns the parameters untouched
+    } else {
+        enabled = st->enabled, done = st->done;
+    }
+    if (!enabled || done) {
+        if (phase == 0 && blockIdx.x == 0 && tid == 0) {
+            st->enabled = enabled, st->done = 1, st->termination = 4, st->iteration = 0, st->successful = 0;
+            st->cost_init = 0, st->cost_final = 0, st->ticket = 0;
+        }
+        return;
+    }
+    const double* x = phase ? st->cand : st->x;
+    double xl[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) xl[k] = x[k];
+    double acc[LM_NACC];
+#pragma unroll
+    for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
+    const int i = blockIdx.x * 256 + tid;
+    if (dbg_mode != 2 && i < n && f.valid[i]) {
+        const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
+        const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
+        const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
+        factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+    }
+#pragma unroll
+    for (int k = 0; k < LM_NACC; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane_id() == 0) red[wave_id()][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (dbg_mode == 1) return;
+    if (tid < LM_NACC) partials[blockIdx.x * LM_NACC + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = atomicAdd(&st->ticket, 1);
+        s_last = ticket == nb - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < LM_NACC) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partials[b * LM_NACC + tid];  // plain loads behind the acquire; fixed order
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    // the tail works on a register/stack copy of the state: one global read and one global write instead of a chain
+    // of dependent global accesses
+    LMState* const st_global = st;
+    LMState L = *st_global;
+    st = &L;
+    struct WriteBack {
+        LMState* g;
+        LMState* l;
+        __device__ ~WriteBack() { *g = *l; }
+    } write_back{st_global, &L};
+    st->ticket = 0;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
     auto grad_max_norm = [&]() {
         double neg[6], proj[7], m = 0.0;
@@ -289,16 +388,16 @@ static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double
         return m;
     };
     if (phase == 0) {
-        st->x_cost = tot[0];
-        st->cost_init = tot[0];
-        st->cost_final = tot[0];
+        st->radius = 1e4, st->decrease_factor = 2.0;
+        st->iteration = 0, st->done = 0, st->successful = 0, st->started = 1, st->termination = 0, st->mcc = 0;
+        st->enabled = 1;
+        st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
         for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
         for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
         for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));  // Jacobi scaling, iteration 0 only
         double xn = 0.0;
         for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
         st->x_norm = sqrt(xn);
-        st->started = 1;
         if (grad_max_norm() <= gradient_tolerance) {
             st->done = 1, st->termination = 1;
             return;
@@ -306,7 +405,6 @@ static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double
         lm_compute_candidate(st);
         return;
     }
-    // candidate evaluated
     const double candidate_cost = tot[0];
     double sn = 0.0;
     for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
@@ -324,14 +422,12 @@ static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double
         double xn = 0.0;
         for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
         st->x_norm = sqrt(xn);
-        st->x_cost = candidate_cost;
-        st->cost_final = candidate_cost;
+        st->x_cost = candidate_cost, st->cost_final = candidate_cost;
         for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
         for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
         st->successful++;
         const double t = 2.0 * relative_decrease - 1.0;
-        st->radius = st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-        st->radius = fmin(1e16, st->radius);
+        st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
         st->decrease_factor = 2.0;
         if (grad_max_norm() <= gradient_tolerance) {
             st->done = 1, st->termination = 1;
@@ -344,126 +440,14 @@ static __global__ void __launch_bounds__(64) k_lm_step(LMState* st, const double
     lm_compute_candidate(st);
 }
 
-// (re)arm the solver at the pose currently in st->x.  enabled = 0 turns the whole chain into no-ops.
-static __global__ void k_lm_reset(LMState* st, const int* __restrict__ d_enable, const int* __restrict__ d_live_count) {
-    if (threadIdx.x != 0) return;
-    st->radius = 1e4, st->decrease_factor = 2.0;
-    st->iteration = 0, st->done = 0, st->successful = 0, st->started = 0, st->termination = 0;
-    st->x_cost = 0, st->cost_init = 0, st->cost_final = 0, st->mcc = 0;
-    st->enabled = d_enable ? *d_enable : 1;
-    if (d_live_count && *d_live_count == 0) {
-        // no residual blocks: Ceres finds no non-constant parameter block and returns the input unchanged
-        st->done = 1, st->termination = 4;
+// host helper: the fixed chain of one solve (1 + 4 launches)
+inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, const int* d_live, double* partials) {
+    const int nb = (f.cap + 255) / 256 > 0 ? (f.cap + 255) / 256 : 1;
+    for (int phase = 0; phase < 5; ++phase) {
+        ProfScope ps("k_lm_iter", s);
+        static const int dbg_mode = getenv("SCAL_LM_DBG") ? atoi(getenv("SCAL_LM_DBG")) : 0;  // timing diagnostics only
+        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, d_enable, d_live, partials, dbg_mode);
     }
-}
-
-
-// The whole solve of one outer iteration in ONE workgroup: evaluate at x, step, then up to four (evaluate candidate,
-// step) rounds.  Residual blocks are strided over 1024 threads, the 28 partial sums are reduced with wave shuffles and a
-// fixed-order LDS stage (bitwise reproducible for a given block count), and the trust-region state lives in LDS, so
-// the <=5 evaluations need no kernel boundary and no global round trip between them.
-static __global__ void __launch_bounds__(1024) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st_g,
-                                                          const int* __restrict__ d_enable, const int* __restrict__ d_live) {
-    __shared__ double red[16][LM_NACC];
-    __shared__ double tot[LM_NACC];
-    __shared__ LMState S;
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        S = *st_g;
-        S.radius = 1e4, S.decrease_factor = 2.0;
-        S.iteration = 0, S.done = 0, S.successful = 0, S.started = 0, S.termination = 0;
-        S.x_cost = 0, S.cost_init = 0, S.cost_final = 0, S.mcc = 0;
-        S.enabled = d_enable ? *d_enable : 1;
-        if (d_live && *d_live == 0) S.done = 1, S.termination = 4;  // no residual blocks: parameters stay untouched
-    }
-    __syncthreads();
-    const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
-    for (int phase = 0; phase < 6; ++phase) {
-        if (!S.enabled || S.done) break;  // uniform: S is in LDS and only thread 0 writes it between barriers
-        double xl[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) xl[k] = phase == 0 ? S.x[k] : S.cand[k];
-        double acc[LM_NACC];
-#pragma unroll
-        for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
-        for (int i = tid; i < n; i += 1024) {
-            if (f.valid[i]) {
-                const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
-                const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
-                const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
-                factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < LM_NACC; ++k) {
-            const double v = wave_sum(acc[k]);
-            if (lane_id() == 0) red[wave_id()][k] = v;
-        }
-        __syncthreads();
-        if (tid < LM_NACC) {
-            double s = 0.0;
-            for (int w = 0; w < 16; ++w) s += red[w][tid];
-            tot[tid] = s;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            LMState* st = &S;
-            auto grad_max_norm = [&]() {
-                double neg[6], proj[7], m = 0.0;
-                for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
-                quat_plus(st->x, neg, proj);
-                for (int k = 0; k < 7; ++k) m = fmax(m, fabs(st->x[k] - proj[k]));
-                return m;
-            };
-            if (phase == 0) {
-                st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
-                for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
-                for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
-                for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));
-                double xn = 0.0;
-                for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
-                st->x_norm = sqrt(xn);
-                st->started = 1;
-                if (grad_max_norm() <= gradient_tolerance)
-                    st->done = 1, st->termination = 1;
-                else
-                    lm_compute_candidate(st);
-            } else {
-                const double candidate_cost = tot[0];
-                double sn = 0.0;
-                for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
-                if (sqrt(sn) <= parameter_tolerance * (st->x_norm + parameter_tolerance)) {
-                    st->done = 1, st->termination = 2;
-                } else if (fabs(st->x_cost - candidate_cost) <= function_tolerance * st->x_cost) {
-                    st->done = 1, st->termination = 3;
-                } else {
-                    const double relative_decrease = (st->x_cost - candidate_cost) / st->mcc;
-                    bool stop = false;
-                    if (relative_decrease > min_relative_decrease) {
-                        for (int k = 0; k < 7; ++k) st->x[k] = st->cand[k];
-                        double xn = 0.0;
-                        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
-                        st->x_norm = sqrt(xn);
-                        st->x_cost = candidate_cost, st->cost_final = candidate_cost;
-                        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
-                        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
-                        st->successful++;
-                        const double t = 2.0 * relative_decrease - 1.0;
-                        st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                        st->decrease_factor = 2.0;
-                        if (grad_max_norm() <= gradient_tolerance) st->done = 1, st->termination = 1, stop = true;
-                    } else {
-                        st->radius = st->radius / st->decrease_factor;
-                        st->decrease_factor *= 2.0;
-                    }
-                    if (!stop) lm_compute_candidate(st);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0) *st_g = S;
 }
 
 }  // namespace scal

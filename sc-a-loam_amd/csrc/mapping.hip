@@ -33,6 +33,7 @@ namespace scal {
 constexpr int CW = 21, CH = 21, CD = 11;       // laserCloudWidth/Height/Depth (:77-79)
 constexpr int GX = 250, GY = 250, GZ = 150;    // 1 m cells over the 5x5x3 valid cubes
 constexpr int GCELLS = GX * GY * GZ;
+constexpr unsigned long long MAP_NOMERGE = 127ull;
 
 struct MapParams {
     int cenW, cenH, cenD;       // laserCloudCenWidth/Height/Depth after this scan's shifts
@@ -200,18 +201,19 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
             const uint64_t own = __ballot(mine == best);
             const int owner = __ffsll(static_cast<long long>(own)) - 1;
             const int pos = __shfl(spos[min(lane + 64 * mu, KNN_CHUNK - 1)], owner, 64);
-            if (lane == owner) k0[mu] = ~0ull;
-            // insert (best, pos) into the running ascending list
-            if (best < bk[4]) {
-                int k = 4;
-                while (k > 0 && bk[k - 1] > best) {
-                    bk[k] = bk[k - 1], bp[k] = bp[k - 1];
-                    --k;
-                }
-                bk[k] = best, bp[k] = pos;
-            } else {
-                break;  // chunk keys come out ascending: nothing smaller is left in this chunk
+            if (lane == owner) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u == mu) k0[u] = ~0ull;  // compile-time indices: the candidate list stays in registers
             }
+            if (!(best < bk[4])) break;  // chunk keys come out ascending: nothing smaller is left in this chunk
+            // insert (best, pos) into the running ascending list, branch-free and statically indexed
+            const bool c0 = best < bk[0], c1 = best < bk[1], c2 = best < bk[2], c3 = best < bk[3];
+            bk[4] = c3 ? bk[3] : best, bp[4] = c3 ? bp[3] : pos;
+            bk[3] = c2 ? bk[2] : (c3 ? best : bk[3]), bp[3] = c2 ? bp[2] : (c3 ? pos : bp[3]);
+            bk[2] = c1 ? bk[1] : (c2 ? best : bk[2]), bp[2] = c1 ? bp[1] : (c2 ? pos : bp[2]);
+            bk[1] = c0 ? bk[0] : (c1 ? best : bk[1]), bp[1] = c0 ? bp[0] : (c1 ? pos : bp[1]);
+            bk[0] = c0 ? best : bk[0], bp[0] = c0 ? pos : bp[0];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -354,16 +356,27 @@ __device__ __forceinline__ void associate_to_map(const double* x7, float px, flo
     o[2] = static_cast<float>(r[2] + x7[6]);
 }
 
+struct NNBuf {
+    float* px;  // [5][cap] neighbour coordinates, ascending (distance, map index)
+    float* py;
+    float* pz;
+    float* d5;  // [cap] squared distance of the 5th neighbour
+    int cap;
+};
+
 // slots [0, n_corner_stack): edge candidates; [n_corner_stack, n_corner_stack + n_surf_stack): plane candidates
-__global__ void __launch_bounds__(256) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
-                                               GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
-                                               const LMState* __restrict__ st, MapCounters* C, int outer, FactorSoA f) {
+// k_assoc_knn: one WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
+// many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
+// so it wants every lane busy with a different point).
+__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
+                                                   GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
+                                                   const LMState* __restrict__ st, const MapCounters* __restrict__ C, NNBuf nb) {
     __shared__ unsigned long long skey[4][KNN_CHUNK];
     __shared__ int spos[4][KNN_CHUNK];
     if (!C->solve_on) return;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const int i = blockIdx.x * 4 + wave_id();  // one wave per stack point
-    if (i >= nc + ns || i >= f.cap) return;
+    const int i = blockIdx.x * 4 + wave_id();
+    if (i >= nc + ns || i >= nb.cap) return;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
@@ -377,61 +390,86 @@ __global__ void __launch_bounds__(256) k_assoc(CSoA4 cs, CSoA4 ss, MapParams mp,
         knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
     else
         knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
+    const int lane = lane_id();
+    if (lane < 5) {
+        nb.px[lane * nb.cap + i] = nn.px[lane];
+        nb.py[lane * nb.cap + i] = nn.py[lane];
+        nb.pz[lane * nb.cap + i] = nn.pz[lane];
+    }
+    if (lane == 0) nb.d5[i] = nn.d[4];
+}
+
+__global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, MapCounters* C, int outer, FactorSoA f) {
+    if (!C->solve_on) return;
+    const int nc = C->n_corner_stack, ns = C->n_surf_stack;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int valid = 0;
-    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
-    if (static_cast<double>(nn.d[4]) < 1.0) {  // :585 / :653
-        if (is_edge) {
-            double cx = 0, cy = 0, cz = 0;
+    bool is_edge = false;
+    if (i < nc + ns && i < f.cap) {
+        is_edge = i < nc;
+        const int j = is_edge ? i : i - nc;
+        const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
+        double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
+        if (static_cast<double>(nb.d5[i]) < 1.0) {  // :585 / :653
+            float px[5], py[5], pz[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) cx = cx + nn.px[k], cy = cy + nn.py[k], cz = cz + nn.pz[k];  // :594
-            cx = cx / 5.0, cy = cy / 5.0, cz = cz / 5.0;
-            double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
+            for (int k = 0; k < 5; ++k) px[k] = nb.px[k * nb.cap + i], py[k] = nb.py[k * nb.cap + i], pz[k] = nb.pz[k * nb.cap + i];
+            if (is_edge) {
+                double cx = 0, cy = 0, cz = 0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {  // raw scatter sum, not divided (:599-604)
-                const double zx = nn.px[k] - cx, zy = nn.py[k] - cy, zz = nn.pz[k] - cz;
-                m00 = m00 + zx * zx, m01 = m01 + zx * zy, m02 = m02 + zx * zz;
-                m11 = m11 + zy * zy, m12 = m12 + zy * zz, m22 = m22 + zz * zz;
-            }
-            double w1, w2, dir[3];
-            eig3_largest(m00, m01, m02, m11, m12, m22, &w1, &w2, dir);
-            if (w2 > 3 * w1) {  // :612
-                valid = 1;
-                pa[0] = 0.1 * dir[0] + cx, pa[1] = 0.1 * dir[1] + cy, pa[2] = 0.1 * dir[2] + cz;     // :616
-                pb[0] = -0.1 * dir[0] + cx, pb[1] = -0.1 * dir[1] + cy, pb[2] = -0.1 * dir[2] + cz;  // :617
-            }
-        } else {
-            double A[5][3], b[5];
+                for (int k = 0; k < 5; ++k) cx = cx + px[k], cy = cy + py[k], cz = cz + pz[k];  // :594
+                cx = cx / 5.0, cy = cy / 5.0, cz = cz / 5.0;
+                double m00 = 0, m01 = 0, m02 = 0, m11 = 0, m12 = 0, m22 = 0;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) A[k][0] = nn.px[k], A[k][1] = nn.py[k], A[k][2] = nn.pz[k], b[k] = -1.0;
-            double nv[3];
-            colpiv_qr_5x3(A, b, nv);
-            const double nrm = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-            const double d = 1 / nrm;  // negative_OA_dot_norm (:665)
-            nv[0] /= nrm, nv[1] /= nrm, nv[2] /= nrm;
-            bool ok = true;
+                for (int k = 0; k < 5; ++k) {  // raw scatter sum, not divided (:599-604)
+                    const double zx = px[k] - cx, zy = py[k] - cy, zz = pz[k] - cz;
+                    m00 = m00 + zx * zx, m01 = m01 + zx * zy, m02 = m02 + zx * zz;
+                    m11 = m11 + zy * zy, m12 = m12 + zy * zz, m22 = m22 + zz * zz;
+                }
+                double w1, w2, dir[3];
+                eig3_largest(m00, m01, m02, m11, m12, m22, &w1, &w2, dir);
+                if (w2 > 3 * w1) {  // :612
+                    valid = 1;
+                    pa[0] = 0.1 * dir[0] + cx, pa[1] = 0.1 * dir[1] + cy, pa[2] = 0.1 * dir[2] + cz;     // :616
+                    pb[0] = -0.1 * dir[0] + cx, pb[1] = -0.1 * dir[1] + cy, pb[2] = -0.1 * dir[2] + cz;  // :617
+                }
+            } else {
+                double A[5][3], b[5];
 #pragma unroll
-            for (int k = 0; k < 5; ++k)
-                if (fabs(nv[0] * nn.px[k] + nv[1] * nn.py[k] + nv[2] * nn.pz[k] + d) > 0.2) ok = false;  // :673-676
-            if (ok && nrm == nrm) {
-                valid = 1;
-                pa[0] = nv[0], pa[1] = nv[1], pa[2] = nv[2];
-                pb[0] = d;
+                for (int k = 0; k < 5; ++k) A[k][0] = px[k], A[k][1] = py[k], A[k][2] = pz[k], b[k] = -1.0;
+                double nv[3];
+                colpiv_qr_5x3(A, b, nv);
+                const double nrm = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                const double d = 1 / nrm;  // negative_OA_dot_norm (:665)
+                nv[0] /= nrm, nv[1] /= nrm, nv[2] /= nrm;
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (fabs(nv[0] * px[k] + nv[1] * py[k] + nv[2] * pz[k] + d) > 0.2) ok = false;  // :673-676
+                if (ok && nrm == nrm) {
+                    valid = 1;
+                    pa[0] = nv[0], pa[1] = nv[1], pa[2] = nv[2];
+                    pb[0] = d;
+                }
             }
         }
-    }
-    if (lane_id() == 0) {  // every lane computed the same block; lane 0 publishes it
         f.valid[i] = valid;
         f.kind[i] = is_edge ? 0 : 2;
         f.cp[i] = ox, f.cp[f.cap + i] = oy, f.cp[2 * f.cap + i] = oz;
         f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
         f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
-        if (valid) {
-            atomicAdd(is_edge ? &C->n_edge[outer] : &C->n_plane[outer], 1);
-            atomicAdd(&C->n_live, 1);
-        }
+    }
+    const uint64_t be = __ballot(valid && is_edge), bp = __ballot(valid && !is_edge);
+    if (lane_id() == 0) {
+        if (be) atomicAdd(&C->n_edge[outer], __popcll(be));
+        if (bp) atomicAdd(&C->n_plane[outer], __popcll(bp));
+        if (be | bp) atomicAdd(&C->n_live, __popcll(be | bp));
     }
 }
 
+__global__ void k_keep_error(const VoxMeta* m, MapCounters* C) {
+    if (m->error) C->error = m->error;
+}
 __global__ void k_counts_after_stack(MapCounters* C, int cap) {
     C->n_slots = min(C->n_corner_stack + C->n_surf_stack, cap);
 }
@@ -451,7 +489,7 @@ __global__ void k_set_pose(LMState* st, const double* x7) {
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
 // appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
-//   key layout: [cube index 13 bits][no-merge 1][vz 9][vy 9][vx 9]; dropped points get ~0
+//   key layout (36 sorted bits = 4 passes): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
 __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA4 stack, const int* __restrict__ d_nstack, const LMState* __restrict__ st,
                                                      MapParams mp, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
                                                      int* __restrict__ vals, MapCounters* C, int cls) {
@@ -485,10 +523,10 @@ __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA
     if (I < 0 || I >= CW || J < 0 || J >= CH || K < 0 || K >= CD) {
         k = ~0ull;  // outside the 21x21x11 window: cleared slab (:346-347 ...) or rejected insert (:753-759)
     } else {
-        const unsigned long long cidx = static_cast<unsigned long long>(I + CW * J + CW * CH * K);
         if (abs(I - mp.cI) <= 2 && abs(J - mp.cJ) <= 2 && abs(K - mp.cK) <= 1) {
-            // voxel coordinates relative to one cell below the cube's lower face; lexicographic (vz,vy,vx) order equals
-            // PCL's idx order inside the cube
+            // slot of the cube inside the 5x5x3 valid set, then voxel coordinates relative to one cell below the cube's
+            // lower face; lexicographic (vz,vy,vx) order equals PCL's idx order inside the cube
+            const unsigned long long slot = static_cast<unsigned long long>((I - mp.cI + 2) + 5 * (J - mp.cJ + 2) + 25 * (K - mp.cK + 1));
             const int bx = static_cast<int>(floorf((50.0f * ai - 26.0f) * inv_leaf));
             const int by = static_cast<int>(floorf((50.0f * aj - 26.0f) * inv_leaf));
             const int bz = static_cast<int>(floorf((50.0f * ak - 26.0f) * inv_leaf));
@@ -496,16 +534,17 @@ __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA
                 vz = static_cast<int>(floorf(z * inv_leaf)) - bz;
             if (vx < 0 || vx > 511 || vy < 0 || vy > 511 || vz < 0 || vz > 511) C->error = SCAL_E_CAPACITY;
             vx = min(max(vx, 0), 511), vy = min(max(vy, 0), 511), vz = min(max(vz, 0), 511);
-            k = (cidx << 28) | (static_cast<unsigned long long>(vz) << 18) | (static_cast<unsigned long long>(vy) << 9) | static_cast<unsigned long long>(vx);
+            k = (slot << 27) | (static_cast<unsigned long long>(vz) << 18) | (static_cast<unsigned long long>(vy) << 9) | static_cast<unsigned long long>(vx);
         } else {
-            k = (cidx << 28) | (1ull << 27);  // cube not re-filtered this scan: keep every point, arrival order
+            k = MAP_NOMERGE << 27;  // cube not re-filtered this scan: keep every point; one shared key + stable sort = arrival order
         }
     }
     keys[i] = k;
     vals[i] = i;
 }
 
-__global__ void __launch_bounds__(256) k_map_heads(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
+__global__ void __launch_bounds__(256) k_map_heads(SortedPairs sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
+    const unsigned long long* keys = sp.keys[sorted_sel(sp)];
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
@@ -514,15 +553,17 @@ __global__ void __launch_bounds__(256) k_map_heads(const unsigned long long* __r
     int head = 0;
     if (i < n) {
         const unsigned long long k = keys[i];
-        head = (k != ~0ull) && ((k & (1ull << 27)) || i == 0 || keys[i - 1] != k);
+        head = (k != ~0ull) && (((k >> 27) == MAP_NOMERGE) || i == 0 || keys[i - 1] != k);
     }
     int total;
     block_exclusive_scan(head, s, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(256) k_map_reduce(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                                    const int* __restrict__ d_n, const int* __restrict__ blockoff, MapCloud in, MapCloud out) {
+__global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, MapCloud in,
+                                                    MapCloud out) {
+    const unsigned long long* keys = sp.keys[sorted_sel(sp)];
+    const int* vals = sp.vals[sorted_sel(sp)];
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
@@ -532,13 +573,13 @@ __global__ void __launch_bounds__(256) k_map_reduce(const unsigned long long* __
     unsigned long long k = 0;
     if (i < n) {
         k = keys[i];
-        head = (k != ~0ull) && ((k & (1ull << 27)) || i == 0 || keys[i - 1] != k);
+        head = (k != ~0ull) && (((k >> 27) == MAP_NOMERGE) || i == 0 || keys[i - 1] != k);
     }
     int total;
     const int rank = block_exclusive_scan(head, s, &total);
     if (!head) return;
     const int o = blockoff[blockIdx.x] + rank;
-    if (k & (1ull << 27)) {
+    if ((k >> 27) == MAP_NOMERGE) {
         const int g = vals[i];
         out.x[o] = in.x[g], out.y[o] = in.y[g], out.z[o] = in.z[g], out.w[o] = in.w[g], out.cube[o] = in.cube[g];
         return;
@@ -643,6 +684,8 @@ struct scal_map {
     DevBuf<int> vals, blockcnt;
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<float> nnx, nny, nnz, nnd5;
+    NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
     DevBuf<MapCounters> d_C;
     DevBuf<double> d_x0;
@@ -687,6 +730,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->sorter.init(c->map_cap));
     A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
+    A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
     A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4));
@@ -735,7 +779,8 @@ void h_rot(const double* q, const double* v, double* o) {
 }
 
 // everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C
-int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, double* q_out, double* t_out, scal_map_stats* stats) {
+int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, int n_corner_bound, int n_surf_bound, double* q_out,
+             double* t_out, scal_map_stats* stats) {
     hipStream_t s = c->stream;
     // transformAssociateToMap (:143-147)
     double x0[8] = {0};
@@ -769,8 +814,13 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st, c->d_x0.p);
 
     // stack downsample (:543-551); 12 bits per axis: up to 4096 cells of the leaf size
-    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, c->cfg.line_res, 12, c->corner_stack.v(), &C->n_corner_stack));
-    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, c->cfg.plane_res, 12, c->surf_stack.v(), &C->n_surf_stack));
+    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack.v(), &C->n_corner_stack));
+    if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
+        // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
+        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
+    }
+    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack.v(), &C->n_surf_stack));
+    hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
     hipLaunchKernelGGL(k_counts_after_stack, dim3(1), dim3(1), 0, s, C, c->slot_cap);
 
     // cell grids over the valid cubes
@@ -789,11 +839,18 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     for (int outer = 0; outer < 2; ++outer) {
         hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, C, outer);
         {
-        ProfScope ps("k_assoc", s);
-        hipLaunchKernelGGL(k_assoc, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p, c->grid[0].start.p,
-                           c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, outer, F);
+            ProfScope ps("k_assoc_knn", s);
+            hipLaunchKernelGGL(k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p,
+                               c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, c->nnbuf());
         }
-        hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(1024), 0, s, F, &C->n_slots, st, &C->solve_on, &C->n_live);
+        {
+            ProfScope ps("k_assoc_fit", s);
+            hipLaunchKernelGGL(k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), c->nnbuf(),
+                               C, outer, F);
+        }
+        {
+                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, &C->n_live, c->partials.p);
+        }
         hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
     }
     // restore the zero invariant of the cell counters
@@ -813,12 +870,11 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
         hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
                            c->keys.p, c->vals.p, C, k);
-        unsigned long long* sk;
-        int* sv;
-        SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], 0, 48, &sk, &sv));
-        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sk, &C->n_total[k], c->blockcnt.p);
+        SortedPairs sp;
+        SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
+        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
         launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
-        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sk, sv, &C->n_total[k], c->blockcnt.p, in, outc);
+        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
         M.cur ^= 1;
     }
     if (have_full) {
@@ -903,7 +959,7 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     SCAL_TRY(up(corner_last, n_corner, c->corner_in));
     SCAL_TRY(up(surf_last, n_surf, c->surf_in));
     if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
-    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, q_w_curr, t_w_curr, stats));
+    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, n_corner, n_surf, q_w_curr, t_w_curr, stats));
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
         SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
@@ -940,7 +996,7 @@ extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, cons
                        c->surf_in.v(), &C->n_surf_in, c->scan_cap);
     hipLaunchKernelGGL(k_copy_soa, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->full_in.v(),
                        c->d_nfull.p, c->scan_cap);
-    return run_step(c, q_wodom, t_wodom, true, q_w_curr, t_w_curr, stats);
+    return run_step(c, q_wodom, t_wodom, true, ls_cap, cap, q_w_curr, t_w_curr, stats);
 }
 
 extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int cap) {

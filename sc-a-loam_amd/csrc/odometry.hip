@@ -388,7 +388,9 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
                 hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p);
             }
-            hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(1024), 0, s, F, &C->n_slots, st, &C->enable, &C->n_live);
+            {
+                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, &C->n_live, c->partials.p);
+            }
             hipLaunchKernelGGL(k_odom_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
         }
     }

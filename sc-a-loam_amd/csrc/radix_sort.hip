@@ -1,8 +1,10 @@
-// Stable LSD radix sort (8-bit digits) for gfx950.  Three kernels per pass:
-//   k_rs_hist     per-block digit histogram (LDS atomics)            -> hist[digit][block]
-//   k_scan        one-block exclusive scan over the digit-major histogram
-//   k_rs_scatter  stable scatter: per wave, items are ranked with ballot-based digit matching (8 ballots give
-//                 the set of lanes holding the same digit), per-wave digit counters live in LDS
+// Stable LSD radix sort (9-bit digits) for gfx950.  Two kernels per pass:
+//   k_rs_hist     per-block digit histogram (LDS atomics) -> hist[digit][block]
+//   k_rs_scatter  every block first derives its own scatter bases from the histogram matrix (sum of the earlier blocks'
+//                 counts per digit + exclusive prefix of the digit totals, 512 x nb L2-resident words - cheaper than a
+//                 separate scan launch while nb is small), then scatters stably: per wave, items are ranked with
+//                 ballot-based digit matching (9 ballots give the lanes holding the same digit), per-wave digit
+//                 counters live in LDS.
 // The element handled by (wave w, item j, lane l) of a block is base + w*ITEMS*64 + j*64 + l, so (w, j, l) order is
 // arrival order and equal keys keep their relative order.
 #include "radix_sort.hpp"
@@ -12,23 +14,28 @@ namespace scal {
 
 constexpr int RS_ITEMS = RadixSort::ITEMS;
 constexpr int RS_TILE = RadixSort::TILE;
+constexpr int RS_DIGIT = RadixSort::DIGIT;
+constexpr int RS_BINS = RadixSort::BINS;
+
+__device__ __forceinline__ bool pass_active(const int* d_used_bits, int shift) { return d_used_bits == nullptr || shift < *d_used_bits; }
 
 __global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int shift,
-                                                 int* __restrict__ hist) {
+                                                 const int* __restrict__ d_used_bits, int* __restrict__ hist) {
+    if (!pass_active(d_used_bits, shift)) return;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
     if (static_cast<int>(blockIdx.x) >= nb) return;
-    __shared__ int h[256];
-    h[threadIdx.x] = 0;
+    __shared__ int h[RS_BINS];
+    for (int i = threadIdx.x; i < RS_BINS; i += 256) h[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE;
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int e = base + j * 256 + threadIdx.x;
-        if (e < n) atomicAdd(&h[(keys[e] >> shift) & 0xff], 1);
+        if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1);
     }
     __syncthreads();
-    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+    for (int i = threadIdx.x; i < RS_BINS; i += 256) hist[i * nb + blockIdx.x] = h[i];
 }
 
 __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int* __restrict__ d_n, int tile, int bins, int* __restrict__ d_total) {
@@ -50,14 +57,35 @@ __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int
 }
 
 __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                                    const int* __restrict__ d_n, int shift, const int* __restrict__ hist,
-                                                    unsigned long long* __restrict__ okeys, int* __restrict__ ovals) {
+                                                    const int* __restrict__ d_n, int shift, const int* __restrict__ d_used_bits,
+                                                    const int* __restrict__ hist, unsigned long long* __restrict__ okeys, int* __restrict__ ovals) {
+    if (!pass_active(d_used_bits, shift)) return;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
     if (static_cast<int>(blockIdx.x) >= nb) return;
-    __shared__ int cnt[4][256];
+    __shared__ int cnt[4][RS_BINS];
+    __shared__ int sbase[RS_BINS];
+    __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
-    for (int i = threadIdx.x; i < 1024; i += 256) (&cnt[0][0])[i] = 0;
+    // scatter base of digit d for this block = (exclusive prefix of the digit totals)[d] + sum_{b < block} hist[d][b]
+    int before[2], totals[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int d = 2 * threadIdx.x + u;
+        int bsum = 0, tsum = 0;
+        const int* row = hist + d * nb;
+        for (int b = 0; b < nb; ++b) {
+            const int v = row[b];
+            tsum += v;
+            if (b < static_cast<int>(blockIdx.x)) bsum += v;
+        }
+        before[u] = bsum, totals[u] = tsum;
+    }
+    int dummy;
+    const int pre = block_exclusive_scan(totals[0] + totals[1], smem, &dummy);
+    sbase[2 * threadIdx.x] = pre + before[0];
+    sbase[2 * threadIdx.x + 1] = pre + totals[0] + before[1];
+    for (int i = threadIdx.x; i < 4 * RS_BINS; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
     unsigned long long k[RS_ITEMS];
@@ -67,8 +95,8 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
         const int e = base + j * 64 + l;
         const bool valid = e < n;
         k[j] = valid ? keys[e] : 0ull;
-        const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & 0xffu;
-        const uint64_t m = wave_match<8>(d, valid);
+        const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (RS_BINS - 1);
+        const uint64_t m = wave_match<RS_DIGIT>(d, valid);
         int prev = 0;
         if (valid) prev = cnt[w][d];
         rk[j] = prev + __popcll(m & lanemask_lt());
@@ -81,10 +109,10 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int e = base + j * 64 + l;
         if (e < n) {
-            const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & 0xffu;
-            int pre = 0;
-            for (int ww = 0; ww < w; ++ww) pre += cnt[ww][d];
-            const int pos = hist[d * nb + blockIdx.x] + pre + rk[j];
+            const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (RS_BINS - 1);
+            int prew = 0;
+            for (int ww = 0; ww < w; ++ww) prew += cnt[ww][d];
+            const int pos = sbase[d] + prew + rk[j];
             okeys[pos] = k[j];
             ovals[pos] = vals[e];
         }
@@ -95,29 +123,28 @@ int RadixSort::init(int capacity) {
     cap = capacity;
     SCAL_TRY(keys_alt.alloc(cap));
     SCAL_TRY(vals_alt.alloc(cap));
-    SCAL_TRY(hist.alloc((size_t)256 * div_up(cap, TILE) + 256));
+    SCAL_TRY(hist.alloc((size_t)BINS * div_up(cap, TILE) + BINS));
     return SCAL_OK;
 }
 
-int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const int* d_n, int begin_bit, int end_bit,
-                    unsigned long long** out_keys, int** out_vals) {
-    unsigned long long* ka = keys;
-    unsigned long long* kb = keys_alt.p;
-    int* va = vals;
-    int* vb = vals_alt.p;
-    const int nb_cap = max(1, div_up(cap, TILE));
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb_cap), dim3(256), 0, s, ka, d_n, shift, hist.p);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, hist.p, d_n, TILE, 256, static_cast<int*>(nullptr));
+int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const int* d_n, int n_bound, int max_bits, const int* d_used_bits,
+                    SortedPairs* out) {
+    unsigned long long* kb[2] = {keys, keys_alt.p};
+    int* vb[2] = {vals, vals_alt.p};
+    const int nb = max(1, div_up(min(cap, max(n_bound, 1)), TILE));
+    int pass = 0;
+    for (int shift = 0; shift < max_bits; shift += DIGIT, ++pass) {
+        const int in = pass & 1, o = in ^ 1;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p);
         {
-        ProfScope ps("k_rs_scatter", s);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nb_cap), dim3(256), 0, s, ka, va, d_n, shift, hist.p, kb, vb);
+            ProfScope ps("k_rs_scatter", s);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o]);
         }
-        std::swap(ka, kb);
-        std::swap(va, vb);
     }
-    *out_keys = ka;
-    *out_vals = va;
+    out->keys[0] = kb[0], out->keys[1] = kb[1];
+    out->vals[0] = vb[0], out->vals[1] = vb[1];
+    out->d_used_bits = d_used_bits;
+    out->fixed_sel = d_used_bits ? -1 : (pass & 1);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

@@ -1,25 +1,41 @@
-// Device-wide stable LSD radix sort of (uint64 key, int32 value) pairs and a small exclusive-scan helper.
-// Counts live on the device (`d_n`): grids are sized for the capacity and surplus blocks exit, so a whole
-// kernel chain can be enqueued without a host round trip.
+// Device-wide stable LSD radix sort of (uint64 key, int32 value) pairs (9-bit digits) and a small exclusive-scan
+// helper.  Counts live on the device (`d_n`): grids are sized for the capacity and surplus blocks exit, so a whole
+// kernel chain can be enqueued without a host round trip.  The number of key bits actually in use may also live on the
+// device (`d_used_bits`): passes above it return immediately and the result buffer is selected by parity on the device.
 #pragma once
 #include "common.hpp"
 
 namespace scal {
 
+struct SortedPairs {
+    // result is in (keys[sel], vals[sel]) with sel = passes_executed & 1; passes_executed = ceil(used_bits / DIGIT)
+    unsigned long long* keys[2];
+    int* vals[2];
+    int fixed_sel;            // >= 0 when the number of executed passes is known on the host
+    const int* d_used_bits;   // else: device word holding the used bits
+};
+
 struct RadixSort {
+    static constexpr int DIGIT = 9;
+    static constexpr int BINS = 1 << DIGIT;
     static constexpr int ITEMS = 8;
     static constexpr int TILE = 256 * ITEMS;  // elements per block
     int cap = 0;
     DevBuf<unsigned long long> keys_alt;
     DevBuf<int> vals_alt;
-    DevBuf<int> hist;  // [256][nb_cap]
+    DevBuf<int> hist;  // [BINS][nb]
 
     int init(int capacity);
-    // Sorts the first *d_n pairs by bits [begin_bit, end_bit) of the key, ascending, stable.
-    // The sorted pairs end up in (*out_keys, *out_vals), which alias either the inputs or the internal buffers.
-    int sort(hipStream_t s, unsigned long long* keys, int* vals, const int* d_n, int begin_bit, int end_bit, unsigned long long** out_keys,
-             int** out_vals);
+    // Sorts the first *d_n pairs (*d_n <= n_bound, host-known) by bits [0, max_bits) of the key, ascending, stable.
+    // If d_used_bits is given, only ceil(*d_used_bits / DIGIT) passes do work.
+    int sort(hipStream_t s, unsigned long long* keys, int* vals, const int* d_n, int n_bound, int max_bits, const int* d_used_bits,
+             SortedPairs* out);
 };
+
+__device__ __forceinline__ int sorted_sel(const SortedPairs& p) {
+    if (p.fixed_sel >= 0) return p.fixed_sel;
+    return ((*p.d_used_bits + RadixSort::DIGIT - 1) / RadixSort::DIGIT) & 1;
+}
 
 // in-place exclusive scan of data[0 .. m) with m = bins * ceil(*d_n / tile), by one block; total -> *d_total (may be null)
 void launch_scan_inplace(hipStream_t s, int* data, const int* d_n, int tile, int bins, int* d_total);

@@ -585,8 +585,8 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
     if (!c->ev) SCAL_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
     SCAL_HIP(hipEventRecord(c->ev, v.stream));
     SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
-    // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); 12 bits per axis = 1.6 km extent
-    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, 0.4f, 12, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
+    // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
+    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
     *d_n = c->d_nds.p;
     *n_cap = v.cap;
     return SCAL_OK;

@@ -50,49 +50,63 @@ __global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restrict__ d_n, float inv, int bits, VoxMeta* m,
+__device__ __forceinline__ int bits_for(int cells) {  // smallest b with (1 << b) >= cells, at least 1
+    int b = 1;
+    while ((1 << b) < cells) ++b;
+    return b;
+}
+
+__global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restrict__ d_n, float inv, int max_bits, VoxMeta* m,
                                                   unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n && i != 0) return;
     float mn[3], mx[3];
-    int mb[3];
+    int mb[3], cells[3];
     long long d[3];
-    bool wide = false;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         mn[a] = ordered_to_float(m->umin[a]);
         mx[a] = ordered_to_float(m->umax[a]);
         d[a] = static_cast<long long>((mx[a] - mn[a]) * inv) + 1;
         mb[a] = static_cast<int>(floorf(mn[a] * inv));
-        const int xb = static_cast<int>(floorf(mx[a] * inv));
-        if (xb - mb[a] + 1 > (1 << bits)) wide = true;
+        cells[a] = static_cast<int>(floorf(mx[a] * inv)) - mb[a] + 1;
     }
-    const bool guard = d[0] * d[1] * d[2] > 2147483647ll;
+    const bool guard = n > 0 && d[0] * d[1] * d[2] > 2147483647ll;  // PCL: "leaf size is too small", output = input
+    int b0, b1, used;
+    if (guard) {
+        b0 = b1 = 0;
+        used = bits_for(max(n, 2));
+    } else {
+        b0 = bits_for(max(cells[0], 1)), b1 = bits_for(max(cells[1], 1));
+        used = b0 + b1 + bits_for(max(cells[2], 1));
+    }
     if (i == 0) {
         m->guard = guard ? 1 : 0;
-        if (!guard && wide) m->error = SCAL_E_CAPACITY;
+        m->b0 = b0, m->b1 = b1;
+        m->used_bits = n > 0 ? min(used, max_bits) : 0;
+        if (n > 0 && used > max_bits) m->error = SCAL_E_CAPACITY;
     }
+    if (i >= n) return;
     unsigned long long k;
     if (guard) {
         k = static_cast<unsigned long long>(i);  // every point is its own voxel, arrival order
     } else {
-        const unsigned long long mask = (1ull << bits) - 1ull;
-        const unsigned long long i0 = static_cast<unsigned long long>(static_cast<int>(floorf(in.x[i] * inv)) - mb[0]) & mask;
-        const unsigned long long i1 = static_cast<unsigned long long>(static_cast<int>(floorf(in.y[i] * inv)) - mb[1]) & mask;
-        const unsigned long long i2 = static_cast<unsigned long long>(static_cast<int>(floorf(in.z[i] * inv)) - mb[2]) & mask;
-        k = (i2 << (2 * bits)) | (i1 << bits) | i0;
+        const unsigned long long i0 = static_cast<unsigned long long>(static_cast<int>(floorf(in.x[i] * inv)) - mb[0]);
+        const unsigned long long i1 = static_cast<unsigned long long>(static_cast<int>(floorf(in.y[i] * inv)) - mb[1]);
+        const unsigned long long i2 = static_cast<unsigned long long>(static_cast<int>(floorf(in.z[i] * inv)) - mb[2]);
+        k = (i2 << (b0 + b1)) | (i1 << b0) | i0;  // idx = i0 + i1*dx + i2*dx*dy orders like (i2, i1, i0)
     }
     keys[i] = k;
     vals[i] = i;
 }
 
-__global__ void __launch_bounds__(256) k_vox_heads(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n,
-                                                   int* __restrict__ blockcnt) {
+__global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
     __shared__ int s[17];
+    const unsigned long long* keys = sp.keys[sorted_sel(sp)];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
     int total;
@@ -100,12 +114,14 @@ __global__ void __launch_bounds__(256) k_vox_heads(const unsigned long long* __r
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(256) k_vox_reduce(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                                    const int* __restrict__ d_n, const int* __restrict__ blockoff, CSoA4 in, SoA4 out) {
+__global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, CSoA4 in, SoA4 out) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
     __shared__ int s[17];
+    const int sel = sorted_sel(sp);
+    const unsigned long long* keys = sp.keys[sel];
+    const int* vals = sp.vals[sel];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
     int total;
@@ -124,6 +140,123 @@ __global__ void __launch_bounds__(256) k_vox_reduce(const unsigned long long* __
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
 
+// Whole filter for a cloud of <= VOX_SMALL points in ONE workgroup: bounding box, keys (14-bit voxel coordinates + arrival
+// index), LDS bitonic sort, run heads, ordered f32 centroids.  Replaces ~20 launches for the corner clouds.
+constexpr int VOX_SMALL = 8192;
+__global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restrict__ d_n, float inv, SoA4 out, int* __restrict__ d_n_out, VoxMeta* m) {
+    extern __shared__ __align__(16) unsigned long long skeys[];
+    __shared__ int s_scan[17];
+    __shared__ unsigned s_lo[3][16], s_hi[3][16];
+    __shared__ int s_mb[4];
+    const int n = min(*d_n, VOX_SMALL);
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (tid == 0) m->error = (*d_n > VOX_SMALL) ? SCAL_E_CAPACITY : 0, m->guard = 0;
+    if (n == 0) {
+        if (tid == 0) *d_n_out = 0;
+        return;
+    }
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    for (int i = tid; i < n; i += blockDim.x) {
+        const unsigned a = float_to_ordered(in.x[i]), b = float_to_ordered(in.y[i]), c = float_to_ordered(in.z[i]);
+        lo[0] = min(lo[0], a), hi[0] = max(hi[0], a);
+        lo[1] = min(lo[1], b), hi[1] = max(hi[1], b);
+        lo[2] = min(lo[2], c), hi[2] = max(hi[2], c);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
+            hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
+        }
+        if (lane == 0) s_lo[a][wv] = lo[a], s_hi[a][wv] = hi[a];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long d[3];
+        bool wide = false;
+        for (int a = 0; a < 3; ++a) {
+            unsigned l = s_lo[a][0], h = s_hi[a][0];
+            for (int q = 1; q < 16; ++q) l = min(l, s_lo[a][q]), h = max(h, s_hi[a][q]);
+            const float mn = ordered_to_float(l), mx = ordered_to_float(h);
+            d[a] = static_cast<long long>((mx - mn) * inv) + 1;
+            s_mb[a] = static_cast<int>(floorf(mn * inv));
+            if (static_cast<int>(floorf(mx * inv)) - s_mb[a] + 1 > 16383) wide = true;
+        }
+        const bool guard = d[0] * d[1] * d[2] > 2147483647ll;
+        s_mb[3] = guard ? 1 : 0;
+        m->guard = s_mb[3];
+        if (!guard && wide) m->error = SCAL_E_CAPACITY;
+    }
+    __syncthreads();
+    const bool guard = s_mb[3] != 0;
+    const int np2 = max(2, next_pow2(n));
+    for (int i = tid; i < np2; i += blockDim.x) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            if (guard) {
+                k = static_cast<unsigned long long>(i) << 14;
+            } else {
+                const unsigned long long i0 = static_cast<unsigned long long>(static_cast<int>(floorf(in.x[i] * inv)) - s_mb[0]) & 0x3fffu;
+                const unsigned long long i1 = static_cast<unsigned long long>(static_cast<int>(floorf(in.y[i] * inv)) - s_mb[1]) & 0x3fffu;
+                const unsigned long long i2 = static_cast<unsigned long long>(static_cast<int>(floorf(in.z[i] * inv)) - s_mb[2]) & 0x3fffu;
+                k = (i2 << 42) | (i1 << 28) | (i0 << 14);
+            }
+            k |= static_cast<unsigned long long>(i);  // arrival index (< 16384) keeps the order inside a voxel
+        }
+        skeys[i] = k;
+    }
+    __syncthreads();
+    if (np2 >= 512)
+        block_bitonic_sort_u64_fast(skeys, np2);
+    else
+        block_bitonic_sort_u64(skeys, np2);
+    // every thread owns 8 consecutive sorted positions; their points are gathered up front (independent loads) so the
+    // ordered f32 sums below run on registers; a run that continues past the thread's window finishes from memory
+    constexpr int PER = VOX_SMALL / 1024;
+    const int c0 = min(n, tid * PER), c1 = min(n, c0 + PER);
+    float px[PER], py[PER], pz[PER], pw[PER];
+    unsigned long long kk[PER];
+    int heads = 0;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int t = c0 + e;
+        kk[e] = t < c1 ? skeys[t] : ~0ull;
+        if (t < c1) {
+            const int g = static_cast<int>(kk[e] & 0x3fffu);
+            px[e] = in.x[g], py[e] = in.y[g], pz[e] = in.z[g], pw[e] = in.w[g];
+            heads += (t == 0) || ((kk[e] >> 14) != (skeys[t - 1] >> 14));
+        }
+    }
+    int n_out = 0;
+    int opos = block_exclusive_scan(heads, s_scan, &n_out);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int t = c0 + e;
+        if (t < c1 && ((t == 0) || ((kk[e] >> 14) != (skeys[t - 1] >> 14)))) {
+            const unsigned long long vk = kk[e] >> 14;
+            float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+            int cntv = 0;
+#pragma unroll
+            for (int e2 = 0; e2 < PER; ++e2) {  // members inside this thread's window (registers)
+                if (e2 >= e && c0 + e2 < c1 && (kk[e2] >> 14) == vk) ax += px[e2], ay += py[e2], az += pz[e2], aw += pw[e2], ++cntv;
+            }
+            int u = c1;
+            if (c0 + e + cntv == c1) {  // the run reaches the end of the window: continue from memory
+                while (u < n && (skeys[u] >> 14) == vk) {
+                    const int g = static_cast<int>(skeys[u] & 0x3fffu);
+                    ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
+                    ++u, ++cntv;
+                }
+            }
+            const float cntf = static_cast<float>(cntv);
+            out.x[opos] = ax / cntf, out.y[opos] = ay / cntf, out.z[opos] = az / cntf, out.w[opos] = aw / cntf;
+            ++opos;
+        }
+    }
+    if (tid == 0) *d_n_out = n_out;
+}
+
 int VoxelFilter::init(int capacity) {
     cap = capacity;
     SCAL_TRY(sorter.init(cap));
@@ -134,18 +267,31 @@ int VoxelFilter::init(int capacity) {
     return SCAL_OK;
 }
 
-int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, float leaf, int bits, SoA4 out, int* d_n_out) {
+int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out) {
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
-    const int nb = max(1, div_up(cap, 256));
+    if (n_bound <= VOX_SMALL) {
+        static bool attr_set = false;
+        const int lds = sizeof(unsigned long long) * VOX_SMALL;
+        if (!attr_set) {
+            SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vox_small), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        {
+            ProfScope ps("k_vox_small", s);
+            hipLaunchKernelGGL(k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p);
+        }
+        SCAL_HIP(hipGetLastError());
+        return SCAL_OK;
+    }
+    const int nb = max(1, div_up(min(cap, n_bound), 256));
     hipLaunchKernelGGL(k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
     hipLaunchKernelGGL(k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, bits, meta.p, keys.p, vals.p);
-    unsigned long long* sk;
-    int* sv;
-    SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, 0, 3 * bits, &sk, &sv));
-    hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, s, sk, d_n, blockcnt.p);
+    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p);
+    SortedPairs sp;
+    SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
+    hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
     launch_scan_inplace(s, blockcnt.p, d_n, 256, 1, d_n_out);
-    hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, s, sk, sv, d_n, blockcnt.p, in, out);
+    hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -237,7 +383,7 @@ extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, 
     SCAL_HIP(hipMemcpyAsync(c->d_n.p, &n, sizeof(int), hipMemcpyHostToDevice, s));
     SoA4 in{c->ix.p, c->iy.p, c->iz.p, c->iw.p}, o{c->ox.p, c->oy.p, c->oz.p, c->ow.p};
     launch_deinterleave(s, c->aos.p, n, in);
-    SCAL_TRY(c->vf.run(s, CSoA4{in.x, in.y, in.z, in.w}, c->d_n.p, leaf, 16, o, c->d_n.p + 1));
+    SCAL_TRY(c->vf.run(s, CSoA4{in.x, in.y, in.z, in.w}, c->d_n.p, n, leaf, 45, o, c->d_n.p + 1));
     launch_interleave(s, c->d_n.p + 1, n, CSoA4{o.x, o.y, o.z, o.w}, c->aos.p);
     VoxMeta hm;
     SCAL_HIP(hipMemcpyAsync(&hm, c->vf.meta.p, sizeof hm, hipMemcpyDeviceToHost, s));
@@ -245,7 +391,7 @@ extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, 
     SCAL_HIP(hipMemcpyAsync(&m, c->d_n.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
     if (hm.error) {
-        set_error("voxel grid needs more than 65536 cells along an axis");
+        set_error("voxel grid bounding box needs more than 45 key bits (or 16383 cells per axis on the small-cloud path)");
         return SCAL_E_CAPACITY;
     }
     SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));

@@ -10,6 +10,8 @@ struct VoxMeta {
     int error;                  // SCAL_E_CAPACITY when an axis needs more cells than the key layout holds
     int n_out;
     int guard;                  // PCL's "leaf size is too small" guard fired: output = input
+    int used_bits;              // key bits in use (device-adaptive: the sort skips the passes above them)
+    int b0, b1;                 // bit widths of the x and y voxel coordinates inside the key
 };
 
 struct SoA4 {
@@ -28,9 +30,11 @@ struct VoxelFilter {
     DevBuf<VoxMeta> meta;
 
     int init(int capacity);
-    // out must hold `cap` points.  bits_per_axis in [8,21]: cells per axis the sort key can address.
-    // d_n_out receives the number of centroids; meta.p->error is set on overflow.
-    int run(hipStream_t s, CSoA4 in, const int* d_n, float leaf, int bits_per_axis, SoA4 out, int* d_n_out);
+    // out must hold `cap` points.  The key packs the three voxel coordinates as tightly as the bounding box allows
+    // (computed on the device); max_bits bounds the passes the host enqueues (a multiple of 9 avoids waste).
+    // n_bound: host-known upper bound of *d_n; clouds of <= 8192 points take a single-workgroup LDS path.
+    // d_n_out receives the number of centroids; meta.p->error is set when the box needs more than max_bits.
+    int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out);
 };
 
 }  // namespace scal
