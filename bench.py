@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
     return ap.parse_args()
 
 
@@ -61,10 +62,24 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if a.backend != "nccl":
+        local = local % torch.cuda.device_count()  # rehearsal: several ranks may share a card
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+
+    def all_gather(out_t, in_t):
+        """RCCL all-gather on the device tensors; the gloo rehearsal path stages through the host."""
+        if a.backend == "nccl":
+            dist.all_gather_into_tensor(out_t, in_t)
+        else:
+            parts = [torch.zeros_like(in_t, device="cpu") for _ in range(world)]
+            dist.all_gather(parts, in_t.cpu())
+            out_t.copy_(torch.stack(parts).reshape(out_t.shape))
     import scaloam as S
     import scansynth
 
@@ -106,7 +121,7 @@ def main():
             r = sc.detectLoopClosureID()
         else:
             sc.make_features(reg, d_q.data_ptr())
-            dist.all_gather_into_tensor(all_q, d_q)
+            all_gather(all_q, d_q)
             torch.cuda.current_stream().synchronize()
             for rr in range(world):  # global insertion order: rank 0..N-1 of this step
                 sc.insert_descriptor_device(all_q[rr].data_ptr())
@@ -119,7 +134,7 @@ def main():
                 sc_state["counter"] += 1
                 limits.append(sc_state["size_at_rebuild"])
             sc.shard_query_device(all_q.data_ptr(), world, limits[rank], d_rec.data_ptr())
-            dist.all_gather_into_tensor(all_rec, d_rec)
+            all_gather(all_rec, d_rec)
             rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query
             cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
             r = S.merge_candidates(cands, 0.4)
@@ -157,7 +172,7 @@ def main():
                   n_less_flat=fz["less_flat"].shape[0], stack_pts=stats["stack_pts"] / max(1, K), blocks=stats["blocks"] / max(1, 2 * K),
                   map_pts=stats["map_pts"] / max(1, K))
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
