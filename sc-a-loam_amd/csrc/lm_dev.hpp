@@ -296,6 +296,81 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
     }
 }
 
+// Trust-region bookkeeping after one evaluation (TrustRegionMinimizer: IterationZero / candidate evaluation).
+__device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phase) {
+    st->ticket = 0;
+    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
+    auto grad_max_norm = [&]() {
+        double neg[6], proj[7], m = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
+        quat_plus(st->x, neg, proj);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) m = fmax(m, fabs(st->x[k] - proj[k]));
+        return m;
+    };
+    if (phase == 0) {
+        st->radius = 1e4, st->decrease_factor = 2.0;
+        st->iteration = 0, st->done = 0, st->successful = 0, st->started = 1, st->termination = 0, st->mcc = 0;
+        st->enabled = 1;
+        st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));  // Jacobi scaling, iteration 0 only
+        double xn = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+        st->x_norm = sqrt(xn);
+        if (grad_max_norm() <= gradient_tolerance) {
+            st->done = 1, st->termination = 1;
+            return;
+        }
+        lm_compute_candidate(st);
+        return;
+    }
+    const double candidate_cost = tot[0];
+    double sn = 0.0;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
+    if (sqrt(sn) <= parameter_tolerance * (st->x_norm + parameter_tolerance)) {
+        st->done = 1, st->termination = 2;
+        return;
+    }
+    if (fabs(st->x_cost - candidate_cost) <= function_tolerance * st->x_cost) {
+        st->done = 1, st->termination = 3;
+        return;
+    }
+    const double relative_decrease = (st->x_cost - candidate_cost) / st->mcc;
+    if (relative_decrease > min_relative_decrease) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) st->x[k] = st->cand[k];
+        double xn = 0.0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
+        st->x_norm = sqrt(xn);
+        st->x_cost = candidate_cost, st->cost_final = candidate_cost;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
+        st->successful++;
+        const double t = 2.0 * relative_decrease - 1.0;
+        st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+        st->decrease_factor = 2.0;
+        if (grad_max_norm() <= gradient_tolerance) {
+            st->done = 1, st->termination = 1;
+            return;
+        }
+    } else {
+        st->radius = st->radius / st->decrease_factor;
+        st->decrease_factor *= 2.0;
+    }
+    lm_compute_candidate(st);
+}
+
 // One LM round per launch: every block evaluates its share of the residual blocks at the current point (phase 0: the
 // accepted point, phase 1: the candidate) and publishes 28 partial sums; the LAST block to arrive (agent-scope release on
 // the producers, ticket atomic, agent-scope acquire on the consumer: cdna_hip_programming.md Guideline 16) sums the
@@ -304,6 +379,7 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase,
                                                         const int* __restrict__ d_enable, const int* __restrict__ d_live,
                                                         double* partials, int dbg_mode) {
+    __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
     __shared__ int s_last;
@@ -339,105 +415,55 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
         const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
         factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
     }
+    // wave reduction through LDS: 28 conflict-free stores per lane, then lane k sums row k in lane order (fixed order =>
+    // reproducible).  Six dependent cross-lane shuffle steps for each of 28 doubles were the slow part of this kernel.
+    {
+        const int w = wave_id(), l = lane_id();
 #pragma unroll
-    for (int k = 0; k < LM_NACC; ++k) {
-        const double v = wave_sum(acc[k]);
-        if (lane_id() == 0) red[wave_id()][k] = v;
+        for (int k = 0; k < LM_NACC; ++k) xch[w][k][l] = acc[k];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (l < LM_NACC) {
+            double sum = 0.0;
+#pragma unroll 8
+            for (int j = 0; j < 64; ++j) sum += xch[w][l][j];
+            red[w][l] = sum;
+        }
     }
     __syncthreads();
     if (dbg_mode == 1) return;
-    if (tid < LM_NACC) partials[blockIdx.x * LM_NACC + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+    // Hand-off without L2 write-back / invalidate fences (MI355X_MICROARCH.md "Valid forms"): EVERY store of the partials is
+    // a write-through (sc0 sc1) store, drained with vmcnt(0) before the block's ticket; EVERY load of them is an sc1 load.
+    if (tid < LM_NACC)
+        __hip_atomic_store(&partials[blockIdx.x * LM_NACC + tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = atomicAdd(&st->ticket, 1);
-        s_last = ticket == nb - 1;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
+    if (tid == 0) s_last = atomicAdd(&st->ticket, 1) == nb - 1;
     __syncthreads();
     if (!s_last) return;
-    if (tid < LM_NACC) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += partials[b * LM_NACC + tid];  // plain loads behind the acquire; fixed order
-        tot[tid] = s;
+    {   // sum the per-block partials: 8 groups of blocks in parallel (independent sc1 loads), combined in a fixed order
+        double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
+        const int k = tid & 31, g = tid >> 5;
+        if (k < LM_NACC) {
+            double sacc = 0.0;
+            for (int b = g; b < nb; b += 8) sacc += __hip_atomic_load(&partials[b * LM_NACC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gsum[0][k][g] = sacc;
+        }
+        __syncthreads();
+        if (tid < LM_NACC) {
+            double t8 = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < 8; ++gg) t8 += gsum[0][tid][gg];
+            tot[tid] = t8;
+        }
     }
     __syncthreads();
     if (tid != 0) return;
-    // the tail works on a register/stack copy of the state: one global read and one global write instead of a chain
-    // of dependent global accesses
-    LMState* const st_global = st;
-    LMState L = *st_global;
-    st = &L;
-    struct WriteBack {
-        LMState* g;
-        LMState* l;
-        __device__ ~WriteBack() { *g = *l; }
-    } write_back{st_global, &L};
-    st->ticket = 0;
-    const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
-    auto grad_max_norm = [&]() {
-        double neg[6], proj[7], m = 0.0;
-        for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
-        quat_plus(st->x, neg, proj);
-        for (int k = 0; k < 7; ++k) m = fmax(m, fabs(st->x[k] - proj[k]));
-        return m;
-    };
-    if (phase == 0) {
-        st->radius = 1e4, st->decrease_factor = 2.0;
-        st->iteration = 0, st->done = 0, st->successful = 0, st->started = 1, st->termination = 0, st->mcc = 0;
-        st->enabled = 1;
-        st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
-        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
-        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
-        for (int a = 0; a < 6; ++a) st->scale[a] = 1.0 / (1.0 + sqrt(st->H[hidx(a, a)]));  // Jacobi scaling, iteration 0 only
-        double xn = 0.0;
-        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
-        st->x_norm = sqrt(xn);
-        if (grad_max_norm() <= gradient_tolerance) {
-            st->done = 1, st->termination = 1;
-            return;
-        }
-        lm_compute_candidate(st);
-        return;
-    }
-    const double candidate_cost = tot[0];
-    double sn = 0.0;
-    for (int k = 0; k < 7; ++k) sn += (st->x[k] - st->cand[k]) * (st->x[k] - st->cand[k]);
-    if (sqrt(sn) <= parameter_tolerance * (st->x_norm + parameter_tolerance)) {
-        st->done = 1, st->termination = 2;
-        return;
-    }
-    if (fabs(st->x_cost - candidate_cost) <= function_tolerance * st->x_cost) {
-        st->done = 1, st->termination = 3;
-        return;
-    }
-    const double relative_decrease = (st->x_cost - candidate_cost) / st->mcc;
-    if (relative_decrease > min_relative_decrease) {
-        for (int k = 0; k < 7; ++k) st->x[k] = st->cand[k];
-        double xn = 0.0;
-        for (int k = 0; k < 7; ++k) xn += st->x[k] * st->x[k];
-        st->x_norm = sqrt(xn);
-        st->x_cost = candidate_cost, st->cost_final = candidate_cost;
-        for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
-        for (int k = 0; k < 21; ++k) st->H[k] = tot[7 + k];
-        st->successful++;
-        const double t = 2.0 * relative_decrease - 1.0;
-        st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-        st->decrease_factor = 2.0;
-        if (grad_max_norm() <= gradient_tolerance) {
-            st->done = 1, st->termination = 1;
-            return;
-        }
-    } else {
-        st->radius = st->radius / st->decrease_factor;
-        st->decrease_factor *= 2.0;
-    }
-    lm_compute_candidate(st);
+    // the serial tail runs on a local copy of the state (one global read, one global write)
+    LMState L = *st;
+    lm_tail(&L, tot, phase);
+    *st = L;
 }
 
 // host helper: the fixed chain of one solve (1 + 4 launches)
