@@ -40,7 +40,8 @@ struct LMState {
     int termination;  // 0 max iterations, 1 gradient, 2 parameter, 3 function, 4 no residual blocks
     double cost_init, cost_final;
     int ticket;  // arrival counter of k_lm_iter
-    int pad_[2];
+    int log_iters[2], log_success[2];  // per outer iteration, for the caller's statistics
+    double log_cost_init[2], log_cost_final[2];
 };
 
 __device__ __forceinline__ void quat_plus(const double* x, const double* delta, double* o) {
@@ -376,7 +377,7 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
 // the producers, ticket atomic, agent-scope acquire on the consumer: cdna_hip_programming.md Guideline 16) sums the
 // partials in block order (bitwise reproducible) and advances Ceres' trust-region state machine.  No block ever waits,
 // so there is nothing to deadlock; a finished solve turns the remaining launches into no-ops.
-static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase,
+static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase, int outer,
                                                         const int* __restrict__ d_enable, const int* __restrict__ d_live,
                                                         double* partials, int dbg_mode) {
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
@@ -398,6 +399,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
         if (phase == 0 && blockIdx.x == 0 && tid == 0) {
             st->enabled = enabled, st->done = 1, st->termination = 4, st->iteration = 0, st->successful = 0;
             st->cost_init = 0, st->cost_final = 0, st->ticket = 0;
+            st->log_iters[outer] = 0, st->log_success[outer] = 0, st->log_cost_init[outer] = 0, st->log_cost_final[outer] = 0;
         }
         return;
     }
@@ -463,16 +465,19 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
     // the serial tail runs on a local copy of the state (one global read, one global write)
     LMState L = *st;
     lm_tail(&L, tot, phase);
+    L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
+    L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
     *st = L;
 }
 
 // host helper: the fixed chain of one solve (1 + 4 launches)
-inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, const int* d_live, double* partials) {
+inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, const int* d_live, double* partials,
+                            int outer) {
     const int nb = (f.cap + 255) / 256 > 0 ? (f.cap + 255) / 256 : 1;
     for (int phase = 0; phase < 5; ++phase) {
         ProfScope ps("k_lm_iter", s);
         static const int dbg_mode = getenv("SCAL_LM_DBG") ? atoi(getenv("SCAL_LM_DBG")) : 0;  // timing diagnostics only
-        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, d_enable, d_live, partials, dbg_mode);
+        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, d_live, partials, dbg_mode);
     }
 }
 

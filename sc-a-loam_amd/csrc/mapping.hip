@@ -49,10 +49,8 @@ struct MapCounters {
     int cursor[2];                       // grid fill cursors
     int solve_on;                        // laserCloudCornerFromMapNum > 10 && SurfFromMapNum > 50 (:555)
     int n_slots;                         // residual-block slots = n_corner_stack + n_surf_stack
-    int n_live;                          // live residual blocks of the current outer iteration
+    int n_live[2];                       // live residual blocks per outer iteration
     int n_edge[2], n_plane[2];
-    int lm_iters[2], lm_success[2];
-    double cost_init[2], cost_final[2];
     int n_total[2];                      // map points to sort in the re-filter pass (old + new)
     int n_map_new[2];                    // map size after the re-filter
     int error;
@@ -463,28 +461,17 @@ __global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, 
     if (lane_id() == 0) {
         if (be) atomicAdd(&C->n_edge[outer], __popcll(be));
         if (bp) atomicAdd(&C->n_plane[outer], __popcll(bp));
-        if (be | bp) atomicAdd(&C->n_live, __popcll(be | bp));
+        if (be | bp) atomicAdd(&C->n_live[outer], __popcll(be | bp));
     }
 }
 
 __global__ void k_keep_error(const VoxMeta* m, MapCounters* C) {
     if (m->error) C->error = m->error;
 }
-__global__ void k_counts_after_stack(MapCounters* C, int cap) {
+// after both stack filters: propagate their verdict, fix the number of residual-block slots
+__global__ void k_after_stack(const VoxMeta* m, MapCounters* C, int cap) {
+    if (m->error) C->error = m->error;
     C->n_slots = min(C->n_corner_stack + C->n_surf_stack, cap);
-}
-__global__ void k_outer_begin(MapCounters* C, int outer) {
-    C->n_live = 0;
-    C->n_edge[outer] = 0, C->n_plane[outer] = 0;
-}
-__global__ void k_outer_end(MapCounters* C, const LMState* st, int outer) {
-    C->lm_iters[outer] = st->enabled ? st->iteration : 0;
-    C->lm_success[outer] = st->enabled ? st->successful : 0;
-    C->cost_init[outer] = st->enabled ? st->cost_init : 0.0;
-    C->cost_final[outer] = st->enabled ? st->cost_final : 0.0;
-}
-__global__ void k_set_pose(LMState* st, const double* x7) {
-    if (threadIdx.x < 7) st->x[threadIdx.x] = x7[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
@@ -692,6 +679,7 @@ struct scal_map {
     DevBuf<int> d_nfull;
     PinBuf<MapCounters> h_C;
     PinBuf<int> h_misc;
+    PinBuf<double> h_x0;
     PinBuf<LMState> h_st;
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
 };
@@ -733,7 +721,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
-    A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4));
+    A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4)); A(c->h_x0.alloc(8));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
@@ -810,8 +798,8 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
 
     MapCounters* C = c->d_C.p;
     LMState* st = c->d_st.p;
-    SCAL_HIP(hipMemcpyAsync(c->d_x0.p, x0, sizeof(double) * 7, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, s, st, c->d_x0.p);
+    for (int i = 0; i < 7; ++i) c->h_x0.p[i] = x0[i];
+    SCAL_HIP(hipMemcpyAsync(st->x, c->h_x0.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));  // LMState::x is the first member
 
     // stack downsample (:543-551); 12 bits per axis: up to 4096 cells of the leaf size
     SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack.v(), &C->n_corner_stack));
@@ -820,8 +808,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
     }
     SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack.v(), &C->n_surf_stack));
-    hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
-    hipLaunchKernelGGL(k_counts_after_stack, dim3(1), dim3(1), 0, s, C, c->slot_cap);
+    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, c->vf.meta.p, C, c->slot_cap);
 
     // cell grids over the valid cubes
     for (int k = 0; k < 2; ++k) {
@@ -837,7 +824,6 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, div_up(c->slot_cap, 4));
     for (int outer = 0; outer < 2; ++outer) {
-        hipLaunchKernelGGL(k_outer_begin, dim3(1), dim3(1), 0, s, C, outer);
         {
             ProfScope ps("k_assoc_knn", s);
             hipLaunchKernelGGL(k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p,
@@ -849,9 +835,8 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
                                C, outer, F);
         }
         {
-                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, &C->n_live, c->partials.p);
+                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, &C->n_live[outer], c->partials.p, outer);
         }
-        hipLaunchKernelGGL(k_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
     }
     // restore the zero invariant of the cell counters
     for (int k = 0; k < 2; ++k) {
@@ -908,8 +893,9 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         stats->n_corner_map = H.n_valid[0], stats->n_surf_map = H.n_valid[1];
         for (int o = 0; o < 2; ++o) {
             stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
-            stats->lm_iters[o] = H.lm_iters[o], stats->lm_success[o] = H.lm_success[o];
-            stats->cost_init[o] = H.cost_init[o], stats->cost_final[o] = H.cost_final[o];
+            const LMState& L = *c->h_st.p;
+            stats->lm_iters[o] = H.solve_on ? L.log_iters[o] : 0, stats->lm_success[o] = H.solve_on ? L.log_success[o] : 0;
+            stats->cost_init[o] = H.solve_on ? L.log_cost_init[o] : 0.0, stats->cost_final[o] = H.solve_on ? L.log_cost_final[o] : 0.0;
         }
         stats->solved = H.solve_on;
         stats->n_map_corner_total = H.n_map_new[0], stats->n_map_surf_total = H.n_map_new[1];

@@ -22,12 +22,12 @@
 namespace scal {
 
 struct OdomCounters {
-    int n_sharp, n_flat, n_corner_last, n_surf_last;
-    int n_slots, n_live, enable;
-    int n_edge[2], n_plane[2];
-    int lm_iters[2], lm_success[2];
-    double cost_init[2], cost_final[2];
-    int n_less_sharp, n_less_flat;
+    // persistent across scans (previous scan's clouds, device-resident)
+    int n_corner_last, n_surf_last;
+    // per scan: zeroed / refreshed at the start of every step (everything from n_sharp on)
+    int n_sharp, n_flat, n_less_sharp, n_less_flat;
+    int n_slots, enable;
+    int n_live[2], n_edge[2], n_plane[2];
 };
 
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
                                                     int outer, FactorSoA f, int nch, const unsigned long long* __restrict__ part) {
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
+    if (blockIdx.x == 0 && threadIdx.x == 0) C->n_slots = min(ns + nf, f.cap);  // read by the LM launches that follow
     const int q = blockIdx.x * 4 + wave_id();
     if (q >= ns + nf || q >= f.cap) return;
     const int lane = lane_id();
@@ -226,21 +227,11 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
         f.pb[q] = pb[0], f.pb[f.cap + q] = pb[1], f.pb[2 * f.cap + q] = pb[2];
         if (valid) {
             atomicAdd(is_edge ? &C->n_edge[outer] : &C->n_plane[outer], 1);
-            atomicAdd(&C->n_live, 1);
+            atomicAdd(&C->n_live[outer], 1);
         }
     }
 }
 
-__global__ void k_odom_outer_begin(OdomCounters* C, int outer, int cap) {
-    C->n_live = 0, C->n_edge[outer] = 0, C->n_plane[outer] = 0;
-    C->n_slots = min(C->n_sharp + C->n_flat, cap);
-}
-__global__ void k_odom_outer_end(OdomCounters* C, const LMState* st, int outer) {
-    C->lm_iters[outer] = st->enabled ? st->iteration : 0;
-    C->lm_success[outer] = st->enabled ? st->successful : 0;
-    C->cost_init[outer] = st->enabled ? st->cost_init : 0.0;
-    C->cost_final[outer] = st->enabled ? st->cost_final : 0.0;
-}
 __global__ void k_odom_init_pose(LMState* st) {
     st->x[0] = st->x[1] = st->x[2] = 0.0, st->x[3] = 1.0;  // para_q = {0,0,0,1}, para_t = {0,0,0} (:97-98)
     st->x[4] = st->x[5] = st->x[6] = 0.0;
@@ -376,7 +367,6 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     const bool solve = c->systemInited;  // first frame: no optimisation (:267-271)
     if (solve) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
-            hipLaunchKernelGGL(k_odom_outer_begin, dim3(1), dim3(1), 0, s, C, outer, c->slot_cap);
             {
                 ProfScope ps("k_odom_nn", s);
                 // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
@@ -389,9 +379,8 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p);
             }
             {
-                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, &C->n_live, c->partials.p);
+                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, &C->n_live[outer], c->partials.p, outer);
             }
-            hipLaunchKernelGGL(k_odom_outer_end, dim3(1), dim3(1), 0, s, C, st, outer);
         }
     }
     // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets
@@ -419,10 +408,11 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
         std::memset(stats, 0, sizeof *stats);
         if (solve) {
             const OdomCounters& H = *c->h_C.p;
+            const LMState& L = *c->h_st.p;
             for (int o = 0; o < 2; ++o) {
                 stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
-                stats->lm_iters[o] = H.lm_iters[o], stats->lm_success[o] = H.lm_success[o];
-                stats->cost_init[o] = H.cost_init[o], stats->cost_final[o] = H.cost_final[o];
+                stats->lm_iters[o] = L.log_iters[o], stats->lm_success[o] = L.log_success[o];
+                stats->cost_init[o] = L.log_cost_init[o], stats->cost_final[o] = L.log_cost_final[o];
             }
         }
     }
@@ -447,17 +437,14 @@ extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, c
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     OdomCounters& H = *c->h_C.p;
-    // keep the device-resident n_corner_last / n_surf_last, refresh the rest
-    const size_t head = offsetof(OdomCounters, n_corner_last);
-    H.n_sharp = n_sharp, H.n_flat = n_flat;
-    SCAL_HIP(hipMemcpyAsync(c->d_C.p, &H, head, hipMemcpyHostToDevice, s));
-    struct Tail {
-        int n_slots, n_live, enable;
-    } tail{0, 0, 1};
-    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_slots, &tail, sizeof tail, hipMemcpyHostToDevice, s));
-    int nls[2] = {n_less_sharp, n_less_flat};
-    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_less_sharp, nls, sizeof nls, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    // keep the device-resident n_corner_last / n_surf_last, refresh the per-scan part from pinned memory
+    OdomCounters fresh;
+    std::memset(&fresh, 0, sizeof fresh);
+    fresh.n_sharp = n_sharp, fresh.n_flat = n_flat, fresh.n_less_sharp = n_less_sharp, fresh.n_less_flat = n_less_flat, fresh.enable = 1;
+    H = fresh;
+    const size_t off = offsetof(OdomCounters, n_sharp);
+    SCAL_HIP(hipMemcpyAsync(reinterpret_cast<char*>(c->d_C.p) + off, reinterpret_cast<char*>(&H) + off, sizeof(OdomCounters) - off,
+                            hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, OSoA& dst) -> int {
         if (n > 0) {
             SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
@@ -485,13 +472,14 @@ extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, do
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    struct Tail {
-        int n_slots, n_live, enable;
-    } tail{0, 0, 1};
-    SCAL_HIP(hipMemcpyAsync(&c->d_C.p->n_slots, &tail, sizeof tail, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipStreamSynchronize(s));
-    SCAL_HIP(hipEventRecord(c->ev, v.stream));
-    SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
+    {
+        OdomCounters& H = *c->h_C.p;
+        std::memset(&H, 0, sizeof H);
+        H.enable = 1;
+        const size_t off = offsetof(OdomCounters, n_sharp);
+        SCAL_HIP(hipMemcpyAsync(reinterpret_cast<char*>(c->d_C.p) + off, reinterpret_cast<char*>(&H) + off, sizeof(OdomCounters) - off,
+                                hipMemcpyHostToDevice, s));
+    }
     OdomCounters* C = c->d_C.p;
     const int nb_slot = std::max(1, div_up(c->slot_cap, 256)), nb_feat = std::max(1, div_up(c->feat_cap, 256));
     hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_slot), dim3(256), 0, s, v.sharp_xyzi, &v.P->n_sharp, c->sharp.v(), &C->n_sharp, c->slot_cap);

@@ -7,8 +7,8 @@
 //   rkey   [cap][20]   f32 ring key (row means cast to float, Scancontext.cpp:62-66) — what the kd-tree indexes
 //   skey   [cap][60]   f64 sector key (column means)
 //   cnorm  [cap][60]   f64 column norms (hoisted out of distDirectSC, :78-81)
-// Kernels: k_sc_make (one workgroup per scan: LDS atomic-max polar binning on an order-preserving integer image
-// of the f32 height, then keys/norms), k_sc_topk (brute-force ring-key distances in nanoflann's f32 accumulation
+// Kernels: k_sc_bin + k_sc_finish (LDS atomic-max polar binning on an order-preserving integer image of the f32
+// height, merged across workgroups with global atomic-max, then keys/norms), k_sc_topk (brute-force ring-key distances in nanoflann's f32 accumulation
 // order, per-block top-3), k_sc_detect (merge top-3, one wave per candidate runs the sector-key alignment and the
 // 7-shift cosine distance), k_sc_pairs / k_sc_matrix (batched distances).
 // All reductions that the reference does through Eigen follow Eigen 3.3's SSE2 order: four interleaved partial
@@ -63,17 +63,18 @@ __device__ __forceinline__ int ceil_to_int(double v) {  // int(ceil(v)); NaN -> 
     return static_cast<int>(c);
 }
 
-// points may be AoS xyzi (stride 4, y=z=null) or SoA
-__global__ void __launch_bounds__(1024) k_sc_make(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz,
-                                                  int stride, const int* __restrict__ d_n, int n_host, double max_radius, int float_math,
-                                                  double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
-                                                  double* __restrict__ cnorm) {
+// points may be AoS xyzi (stride 4, y=z=null) or SoA.  Two launches: k_sc_bin (many workgroups: LDS atomic-max polar
+// binning on an order-preserving integer image of the f32 height, merged into a global 1200-cell image) and k_sc_finish
+// (one workgroup: descriptor, keys, column norms; clears the global image again so it is always zero between scans).
+__global__ void __launch_bounds__(256) k_sc_bin(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int stride,
+                                                const int* __restrict__ d_n, int n_host, double max_radius, int float_math,
+                                                unsigned* __restrict__ gcell) {
     __shared__ unsigned cell[DESC];
-    __shared__ double d[DESC];
     const int n = d_n ? *d_n : n_host;
+    if (static_cast<int>(blockIdx.x * blockDim.x) >= n) return;
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) cell[i] = 0u;
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         float x, y, z;
         if (py) {
             x = px[k], y = py[k], z = pz[k];
@@ -90,10 +91,19 @@ __global__ void __launch_bounds__(1024) k_sc_make(const float* __restrict__ px, 
         atomicMax(&cell[(ring_idx - 1) + NR * (sctor_idx - 1)], float_to_ordered(zz));                             // :182-183
     }
     __syncthreads();
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x)
+        if (cell[i]) atomicMax(&gcell[i], cell[i]);
+}
+
+__global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell, double* __restrict__ desc, float* __restrict__ rkey,
+                                                   double* __restrict__ skey, double* __restrict__ cnorm) {
+    __shared__ double d[DESC];
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
+        const unsigned c = gcell[i];
+        gcell[i] = 0u;
         double v = 0.0;  // empty cell: -1000 -> 0 (:187-190)
-        if (cell[i] != 0u) {
-            const float f = ordered_to_float(cell[i]);
+        if (c != 0u) {
+            const float f = ordered_to_float(c);
             if (static_cast<double>(f) > -1000.0) v = static_cast<double>(f);
         }
         d[i] = v;
@@ -402,6 +412,7 @@ struct scal_sc {
     DevBuf<float> qrkey;
     DevBuf<float> pts;
     int pts_cap = 0;
+    DevBuf<unsigned> gcell;  // global polar image of k_sc_bin, zero between scans
     DevBuf<unsigned long long> block_best;
     DevBuf<SCRec> d_rec;
     PinBuf<SCRec> h_rec;
@@ -444,6 +455,8 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->qdesc.alloc(DESC)); A(c->qskey.alloc(NS)); A(c->qnorm.alloc(NS)); A(c->qrkey.alloc(NR));
     A(c->block_best.alloc((size_t)3 * div_up(c->cap, 256) + 3));
     A(c->d_rec.alloc(4));
+    A(c->gcell.alloc(DESC));
+    if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
     A(c->h_rec.alloc(4));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
@@ -498,8 +511,9 @@ static int commit_staged(scal_sc* c) {
 // into its database slot
 static int make_into(scal_sc* c, const float* px, const float* py, const float* pz, int stride, const int* d_n, int n_host, bool insert) {
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(k_sc_make, dim3(1), dim3(1024), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->qdesc.p,
-                       c->qrkey.p, c->qskey.p, c->qnorm.p);
+    const int nblk = std::max(1, std::min(64, div_up(n_host, 1024)));
+    hipLaunchKernelGGL(k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
+    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_HIP(hipGetLastError());
     if (insert) SCAL_TRY(commit_staged(c));
     return SCAL_OK;
