@@ -41,6 +41,7 @@ struct LMState {
     double cost_init, cost_final;
     int ticket;  // arrival counter of k_lm_iter
     int log_iters[2], log_success[2];  // per outer iteration, for the caller's statistics
+    int log_n_edge[2], log_n_plane[2];
     double log_cost_init[2], log_cost_final[2];
 };
 
@@ -173,7 +174,7 @@ __device__ __forceinline__ void factor_accumulate(int kind, const double* cp, co
     }
 }
 
-constexpr int LM_NACC = 28;
+constexpr int LM_NACC = 30;  // cost, g[6], upper H[21], number of live edge blocks, number of live plane blocks
 
 // which = 0: evaluate at st->x (iteration zero), 1: at st->cand
 static __global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
@@ -196,6 +197,8 @@ static __global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* 
         const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
         const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
         factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+        acc[28] += f.kind[i] == 0 ? 1.0 : 0.0;
+        acc[29] += f.kind[i] == 0 ? 0.0 : 1.0;
     }
 #pragma unroll
     for (int k = 0; k < LM_NACC; ++k) {
@@ -315,6 +318,10 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
         st->iteration = 0, st->done = 0, st->successful = 0, st->started = 1, st->termination = 0, st->mcc = 0;
         st->enabled = 1;
         st->x_cost = tot[0], st->cost_init = tot[0], st->cost_final = tot[0];
+        if (tot[28] + tot[29] == 0.0) {  // no residual blocks: Ceres finds no non-constant parameter block, parameters stay untouched
+            st->done = 1, st->termination = 4;
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a) st->g[a] = tot[1 + a];
 #pragma unroll
@@ -378,8 +385,7 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
 // partials in block order (bitwise reproducible) and advances Ceres' trust-region state machine.  No block ever waits,
 // so there is nothing to deadlock; a finished solve turns the remaining launches into no-ops.
 static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase, int outer,
-                                                        const int* __restrict__ d_enable, const int* __restrict__ d_live,
-                                                        double* partials, int dbg_mode) {
+                                                        const int* __restrict__ d_enable, double* partials, int dbg_mode) {
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
@@ -391,7 +397,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
     int enabled, done;
     if (phase == 0) {  // (re)arm: the state of the previous solve is stale, only x carries over
         enabled = d_enable ? *d_enable : 1;
-        done = (d_live && *d_live == 0) ? 1 : 0;  // no residual blocks: Ceres returns the parameters untouched
+        done = 0;
     } else {
         enabled = st->enabled, done = st->done;
     }
@@ -400,6 +406,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
             st->enabled = enabled, st->done = 1, st->termination = 4, st->iteration = 0, st->successful = 0;
             st->cost_init = 0, st->cost_final = 0, st->ticket = 0;
             st->log_iters[outer] = 0, st->log_success[outer] = 0, st->log_cost_init[outer] = 0, st->log_cost_final[outer] = 0;
+            st->log_n_edge[outer] = 0, st->log_n_plane[outer] = 0;
         }
         return;
     }
@@ -416,6 +423,8 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
         const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
         const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
         factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+        acc[28] += f.kind[i] == 0 ? 1.0 : 0.0;  // live residual blocks are counted here: no contended atomics in the
+        acc[29] += f.kind[i] == 0 ? 0.0 : 1.0;  // association kernels
     }
     // wave reduction through LDS: 28 conflict-free stores per lane, then lane k sums row k in lane order (fixed order =>
     // reproducible).  Six dependent cross-lane shuffle steps for each of 28 doubles were the slow part of this kernel.
@@ -464,6 +473,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
     if (tid != 0) return;
     // the serial tail runs on a local copy of the state (one global read, one global write)
     LMState L = *st;
+    if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
     lm_tail(&L, tot, phase);
     L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
     L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
@@ -471,13 +481,12 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
 }
 
 // host helper: the fixed chain of one solve (1 + 4 launches)
-inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, const int* d_live, double* partials,
-                            int outer) {
+inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, int outer) {
     const int nb = (f.cap + 255) / 256 > 0 ? (f.cap + 255) / 256 : 1;
     for (int phase = 0; phase < 5; ++phase) {
         ProfScope ps("k_lm_iter", s);
         static const int dbg_mode = getenv("SCAL_LM_DBG") ? atoi(getenv("SCAL_LM_DBG")) : 0;  // timing diagnostics only
-        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, d_live, partials, dbg_mode);
+        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, partials, dbg_mode);
     }
 }
 

@@ -457,12 +457,6 @@ __global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, 
         f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
         f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
     }
-    const uint64_t be = __ballot(valid && is_edge), bp = __ballot(valid && !is_edge);
-    if (lane_id() == 0) {
-        if (be) atomicAdd(&C->n_edge[outer], __popcll(be));
-        if (bp) atomicAdd(&C->n_plane[outer], __popcll(bp));
-        if (be | bp) atomicAdd(&C->n_live[outer], __popcll(be | bp));
-    }
 }
 
 __global__ void k_keep_error(const VoxMeta* m, MapCounters* C) {
@@ -835,7 +829,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
                                C, outer, F);
         }
         {
-                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, &C->n_live[outer], c->partials.p, outer);
+                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, outer);
         }
     }
     // restore the zero invariant of the cell counters
@@ -892,8 +886,8 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         stats->n_corner_stack = H.n_corner_stack, stats->n_surf_stack = H.n_surf_stack;
         stats->n_corner_map = H.n_valid[0], stats->n_surf_map = H.n_valid[1];
         for (int o = 0; o < 2; ++o) {
-            stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
             const LMState& L = *c->h_st.p;
+            stats->n_edge[o] = H.solve_on ? L.log_n_edge[o] : 0, stats->n_plane[o] = H.solve_on ? L.log_n_plane[o] : 0;
             stats->lm_iters[o] = H.solve_on ? L.log_iters[o] : 0, stats->lm_success[o] = H.solve_on ? L.log_success[o] : 0;
             stats->cost_init[o] = H.solve_on ? L.log_cost_init[o] : 0.0, stats->cost_final[o] = H.solve_on ? L.log_cost_final[o] : 0.0;
         }

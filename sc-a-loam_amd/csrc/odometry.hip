@@ -39,6 +39,7 @@ __device__ __forceinline__ unsigned long long make_key(float d, unsigned seq) {
     return (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | seq;
 }
 
+constexpr int RING_TAB = 96;   // per-ring first/last index tables of a target cloud
 constexpr int NN_QT = 64;      // queries per block
 constexpr int NN_TC = 2048;    // target points per block (staged through LDS)
 
@@ -85,14 +86,17 @@ __global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 
         transform_to_start(x7, Q.x[qi], Q.y[qi], Q.z[qi], sel);
         const int per = (tn + 3) / 4;
         const int b0 = partq * per, b1 = min(tn, b0 + per);
+        float bd = 3.4e38f;
+        int bi = -1;
+#pragma unroll 4
         for (int t = b0; t < b1; ++t) {
             const float dx = sel[0] - tx[t], dy = sel[1] - ty[t], dz = sel[2] - tz[t];
             float d = dx * dx;  // FLANN L2_Simple<float>
             d += dy * dy;
             d += dz * dz;
-            const unsigned long long k = make_key(d, static_cast<unsigned>(t0 + t));
-            best = k < best ? k : best;
+            if (d < bd) bd = d, bi = t;  // ascending t: the first (lowest index) of equal distances is kept
         }
+        if (bi >= 0) best = make_key(bd, static_cast<unsigned>(t0 + bi));
     }
     red[partq][ql] = best;
     __syncthreads();
@@ -106,13 +110,15 @@ __global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 
 
 // one wave per query
 __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st, OdomCounters* C,
-                                                    int outer, FactorSoA f, int nch, const unsigned long long* __restrict__ part) {
+                                                    int outer, FactorSoA f, int nch, const unsigned long long* __restrict__ part,
+                                                    const int* __restrict__ ring_tab) {
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
     if (blockIdx.x == 0 && threadIdx.x == 0) C->n_slots = min(ns + nf, f.cap);  // read by the LM launches that follow
-    const int q = blockIdx.x * 4 + wave_id();
+    __shared__ unsigned long long s_k2[4], s_k3[4];
+    const int q = blockIdx.x;  // one workgroup per query: its four waves interleave over the ring window (latency hiding)
     if (q >= ns + nf || q >= f.cap) return;
-    const int lane = lane_id();
+    const int lane = lane_id(), wv = wave_id();
     const bool is_edge = q < ns;
     const int j = is_edge ? q : q - ns;
     const CSoA4& Q = is_edge ? sharp : flat;
@@ -142,54 +148,76 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
         const int c = static_cast<int>(best & 0xffffffffu);
         const int id = static_cast<int>(T.w[c]);  // closestPointScanID = int(intensity) (:308, :398)
         unsigned long long k2 = ~0ull, k3 = ~0ull;
-        // ---- towards increasing index
-        for (int base = c + 1; base < nT; base += 64) {
-            const int t = base + lane;
-            const bool in = t < nT;
-            int rj = 0;
-            if (in) rj = static_cast<int>(T.w[t]);
-            const bool stop = in && (static_cast<double>(rj) > static_cast<double>(id) + 2.5);  // NEARBY_SCAN (:319, :405)
-            const uint64_t sm = __ballot(stop);
-            const int first = sm ? __ffsll(static_cast<long long>(sm)) - 1 : 64;
-            if (in && lane < first) {
-                const float d = sqdist(T.x[t], T.y[t], T.z[t], sx, sy, sz);
-                if (static_cast<double>(d) < 25.0) {
-                    const unsigned seq = static_cast<unsigned>(t - c - 1);
-                    if (is_edge) {
-                        if (rj > id) k2 = min(k2, make_key(d, seq));  // skip same-or-lower ring (:315)
-                    } else {
-                        if (rj <= id) k2 = min(k2, make_key(d, seq));  // :416
-                        else k3 = min(k3, make_key(d, seq));           // :422
-                    }
-                }
-            }
-            if (sm) break;
+        // window bounds from the per-ring first/last index tables of this target cloud (see k_odom_handover)
+        const int* first_idx = ring_tab + (is_edge ? 0 : 2 * RING_TAB);
+        const int* last_idx = first_idx + RING_TAB;
+        int fi = 0x7f7f7f7f, li = -1;
+        for (int r = lane; r < RING_TAB; r += 64) {
+            if (r >= id + 3) fi = min(fi, first_idx[r]);  // first index whose ring exceeds id + NEARBY_SCAN (:319, :405)
+            if (r <= id - 3) li = max(li, last_idx[r]);   // last index whose ring is below id - NEARBY_SCAN (:345, :433)
         }
-        // ---- towards decreasing index
-        for (int base = c - 1; base >= 0; base -= 64) {
-            const int t = base - lane;
-            const bool in = t >= 0;
-            int rj = 0;
-            if (in) rj = static_cast<int>(T.w[t]);
-            const bool stop = in && (static_cast<double>(rj) < static_cast<double>(id) - 2.5);  // :345, :433
-            const uint64_t sm = __ballot(stop);
-            const int first = sm ? __ffsll(static_cast<long long>(sm)) - 1 : 64;
-            if (in && lane < first) {
-                const float d = sqdist(T.x[t], T.y[t], T.z[t], sx, sy, sz);
-                if (static_cast<double>(d) < 25.0) {
-                    const unsigned seq = 0x40000000u + static_cast<unsigned>(c - 1 - t);  // visited after every upward candidate
-                    if (is_edge) {
-                        if (rj < id) k2 = min(k2, make_key(d, seq));  // skip same-or-higher ring (:341)
-                    } else {
-                        if (rj >= id) k2 = min(k2, make_key(d, seq));  // :444
-                        else k3 = min(k3, make_key(d, seq));           // :449
+        const int hi = min(wave_min_i(fi), nT);
+        const int lo = wave_max_i(li);
+        // Both walks are unrolled by four with the loads hoisted: the 16 loads of a step are independent, so a step costs one
+        // memory latency instead of four.
+        // ---- towards increasing index: j in (c, hi)
+        for (int t0 = c + 1 + lane + 64 * wv; t0 < hi; t0 += 1024) {
+            float tw[4], txx[4], tyy[4], tzz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u;
+                if (t < hi) tw[u] = T.w[t], txx[u] = T.x[t], tyy[u] = T.y[t], tzz[u] = T.z[t];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u;
+                if (t < hi) {
+                    const int rj = static_cast<int>(tw[u]);
+                    const float d = sqdist(txx[u], tyy[u], tzz[u], sx, sy, sz);
+                    if (static_cast<double>(d) < 25.0) {
+                        const unsigned seq = static_cast<unsigned>(t - c - 1);
+                        if (is_edge) {
+                            if (rj > id) k2 = min(k2, make_key(d, seq));  // skip same-or-lower ring (:315)
+                        } else {
+                            if (rj <= id) k2 = min(k2, make_key(d, seq));  // :416
+                            else k3 = min(k3, make_key(d, seq));           // :422
+                        }
                     }
                 }
             }
-            if (sm) break;
+        }
+        // ---- towards decreasing index: j in (lo, c)
+        for (int t0 = c - 1 - lane - 64 * wv; t0 > lo; t0 -= 1024) {
+            float tw[4], txx[4], tyy[4], tzz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 - 256 * u;
+                if (t > lo) tw[u] = T.w[t], txx[u] = T.x[t], tyy[u] = T.y[t], tzz[u] = T.z[t];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 - 256 * u;
+                if (t > lo) {
+                    const int rj = static_cast<int>(tw[u]);
+                    const float d = sqdist(txx[u], tyy[u], tzz[u], sx, sy, sz);
+                    if (static_cast<double>(d) < 25.0) {
+                        const unsigned seq = 0x40000000u + static_cast<unsigned>(c - 1 - t);  // visited after every upward candidate
+                        if (is_edge) {
+                            if (rj < id) k2 = min(k2, make_key(d, seq));  // skip same-or-higher ring (:341)
+                        } else {
+                            if (rj >= id) k2 = min(k2, make_key(d, seq));  // :444
+                            else k3 = min(k3, make_key(d, seq));           // :449
+                        }
+                    }
+                }
+            }
         }
         k2 = wave_min_u64(k2);
         k3 = wave_min_u64(k3);
+        if (lane == 0) s_k2[wv] = k2, s_k3[wv] = k3;
+        __syncthreads();  // uniform: every wave of the block takes this branch (same query, same NN)
+        k2 = min(min(s_k2[0], s_k2[1]), min(s_k2[2], s_k2[3]));
+        k3 = min(min(s_k3[0], s_k3[1]), min(s_k3[2], s_k3[3]));
         auto decode = [&](unsigned long long k) {
             const unsigned seq = static_cast<unsigned>(k & 0xffffffffu);
             return (seq & 0x40000000u) ? c - 1 - static_cast<int>(seq & 0x3fffffffu) : c + 1 + static_cast<int>(seq);
@@ -219,16 +247,12 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
             pb[0] = nx, pb[1] = ny, pb[2] = nz;
         }
     }
-    if (lane == 0) {
+    if (lane == 0 && wv == 0) {
         f.valid[q] = valid;
         f.kind[q] = kind;
         f.cp[q] = ox, f.cp[f.cap + q] = oy, f.cp[2 * f.cap + q] = oz;
         f.pa[q] = pa[0], f.pa[f.cap + q] = pa[1], f.pa[2 * f.cap + q] = pa[2];
         f.pb[q] = pb[0], f.pb[f.cap + q] = pb[1], f.pb[2 * f.cap + q] = pb[2];
-        if (valid) {
-            atomicAdd(is_edge ? &C->n_edge[outer] : &C->n_plane[outer], 1);
-            atomicAdd(&C->n_live[outer], 1);
-        }
     }
 }
 
@@ -241,6 +265,27 @@ __global__ void __launch_bounds__(256) k_odom_copy(CSoA4 in, const int* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *d_n_out = n;
     if (i < n) out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = in.w[i];
+}
+// hand-over copy of a target cloud that also records, per ring id r = int(intensity), the first and last index holding r.
+// first_idx must be pre-filled with a value >= n (0x7f7f7f7f), last_idx with -1.  The walks of :312-361 / :402-455 stop at
+// the first index past +-2.5 rings; with these tables that index is min_{r' >= id+3} first_idx[r'] (resp. the max of
+// last_idx below id-3): int(intensity) never drops by more than one ring along the cloud, so no earlier index qualifies.
+__global__ void __launch_bounds__(256) k_odom_handover(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap,
+                                                       int* __restrict__ first_idx, int* __restrict__ last_idx) {
+    const int n = min(*d_n, cap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *d_n_out = n;
+    if (i < n) {
+        const float w = in.w[i];
+        out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = w;
+        const int r = min(max(static_cast<int>(w), 0), RING_TAB - 1);
+        // consecutive points mostly share a ring: only ring boundaries (and the wave's first lane) touch the tables
+        const int rp = __shfl_up(r, 1, 64);
+        const int rn = __shfl_down(r, 1, 64);
+        const int lane = lane_id();
+        if (lane == 0 || rp != r) atomicMin(&first_idx[r], i);
+        if (lane == 63 || rn != r || i == n - 1) atomicMax(&last_idx[r], i);
+    }
 }
 __global__ void __launch_bounds__(256) k_odom_copy_aos(const float* __restrict__ aos, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out,
                                                        int cap) {
@@ -284,6 +329,7 @@ struct scal_odom {
     DevBuf<double> fcp, fpa, fpb, partials;
     DevBuf<unsigned long long> nn_part;
     int nch = 1;
+    DevBuf<int> ring_tab;  // [corner first | corner last | surf first | surf last] x RING_TAB
     DevBuf<LMState> d_st;
     DevBuf<OdomCounters> d_C;
     PinBuf<OdomCounters> h_C;
@@ -314,6 +360,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
+    A(c->ring_tab.alloc(4 * RING_TAB));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
@@ -375,19 +422,24 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
             }
             {
                 ProfScope ps("k_odom_assoc", s);
-                hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, div_up(c->slot_cap, 4))), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
-                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p);
+                hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p);
             }
             {
-                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, &C->n_live[outer], c->partials.p, outer);
+                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, outer);
             }
         }
     }
     // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets
-    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(c->feat_cap, 256))), dim3(256), 0, s, c->less_sharp.cv(), &C->n_less_sharp, c->corner_last.v(),
-                       &C->n_corner_last, c->feat_cap);
-    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, c->less_flat.cv(), &C->n_less_flat, c->surf_last.v(),
-                       &C->n_surf_last, c->cap);
+    int* tab = c->ring_tab.p;
+    SCAL_HIP(hipMemsetAsync(tab, 0x7f, sizeof(int) * RING_TAB, s));                   // corner first_idx: "beyond the cloud"
+    SCAL_HIP(hipMemsetAsync(tab + RING_TAB, 0xff, sizeof(int) * RING_TAB, s));        // corner last_idx: -1
+    SCAL_HIP(hipMemsetAsync(tab + 2 * RING_TAB, 0x7f, sizeof(int) * RING_TAB, s));
+    SCAL_HIP(hipMemsetAsync(tab + 3 * RING_TAB, 0xff, sizeof(int) * RING_TAB, s));
+    hipLaunchKernelGGL(k_odom_handover, dim3(std::max(1, div_up(c->feat_cap, 256))), dim3(256), 0, s, c->less_sharp.cv(), &C->n_less_sharp,
+                       c->corner_last.v(), &C->n_corner_last, c->feat_cap, tab, tab + RING_TAB);
+    hipLaunchKernelGGL(k_odom_handover, dim3(std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, c->less_flat.cv(), &C->n_less_flat, c->surf_last.v(),
+                       &C->n_surf_last, c->cap, tab + 2 * RING_TAB, tab + 3 * RING_TAB);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
@@ -407,10 +459,9 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         if (solve) {
-            const OdomCounters& H = *c->h_C.p;
             const LMState& L = *c->h_st.p;
             for (int o = 0; o < 2; ++o) {
-                stats->n_edge[o] = H.n_edge[o], stats->n_plane[o] = H.n_plane[o];
+                stats->n_edge[o] = L.log_n_edge[o], stats->n_plane[o] = L.log_n_plane[o];
                 stats->lm_iters[o] = L.log_iters[o], stats->lm_success[o] = L.log_success[o];
                 stats->cost_init[o] = L.log_cost_init[o], stats->cost_final[o] = L.log_cost_final[o];
             }
