@@ -127,10 +127,11 @@ void drain_entry(ProfEntry& p) {
 }
 }  // namespace
 
-ProfScope::ProfScope(const char* name, hipStream_t stream) : slot(-1), s(stream) {
-    if (!g_prof_on) return;
+bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    if (!g_prof_on) return false;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_filter.empty() && g_prof_filter != name) return;
+    if (!g_prof_filter.empty() && g_prof_filter != name) return false;
+    int slot = -1;
     for (size_t i = 0; i < g_prof.size(); ++i)
         if (g_prof[i].name == name) slot = static_cast<int>(i);
     if (slot < 0) {
@@ -138,15 +139,12 @@ ProfScope::ProfScope(const char* name, hipStream_t stream) : slot(-1), s(stream)
         g_prof.back().name = name;
         slot = static_cast<int>(g_prof.size()) - 1;
     }
-    if (g_prof[slot].pending.size() >= 8) drain_entry(g_prof[slot]);  // keep few events outstanding
+    if (g_prof[slot].pending.size() >= 64) drain_entry(g_prof[slot]);  // bounded number of outstanding events
     hipEvent_t a = take_event(), b = take_event();
+    if (!a || !b) return false;
     g_prof[slot].pending.push_back({a, b});
-    (void)hipEventRecord(a, s);
-}
-ProfScope::~ProfScope() {
-    if (slot < 0) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    (void)hipEventRecord(g_prof[slot].pending.back().second, s);
+    *start = a, *stop = b;
+    return true;
 }
 
 }  // namespace scal

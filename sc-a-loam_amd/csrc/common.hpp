@@ -1,6 +1,7 @@
 // Host-side plumbing shared by every stage of libscaloam_hip.so: error reporting, RAII device/pinned buffers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
@@ -97,13 +98,19 @@ struct PinBuf {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
-// Optional per-kernel timing with HIP events on the stream the kernel is launched on (bench.py's roofline leg).
-// Disabled by default: a ProfScope is then a single branch.
-struct ProfScope {
-    int slot;
-    hipStream_t s;
-    ProfScope(const char* name, hipStream_t stream);
-    ~ProfScope();
-};
+// Optional per-kernel timing (bench.py's roofline leg).  The start/stop events are attached to the kernel's own dispatch
+// (hipExtLaunchKernelGGL), so they read the dispatch's begin/end timestamps and put no extra packet on the stream: separate
+// hipEventRecord calls cost ~5 us of stream time each, more than many of the kernels they would bracket.
+// Disabled by default: SCAL_LAUNCH_PROF is then one branch + a plain launch.
+bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop);
+
+#define SCAL_LAUNCH_PROF(name, kernel, grid, block, lds, stream, ...)                                   \
+    do {                                                                                                \
+        hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                      \
+        if (::scal::prof_begin(name, &pe0_, &pe1_))                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pe0_, pe1_, 0, __VA_ARGS__);        \
+        else                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                          \
+    } while (0)
 
 }  // namespace scal

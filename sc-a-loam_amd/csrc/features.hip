@@ -770,8 +770,7 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     hipLaunchKernelGGL(k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p);
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
     {
-    ProfScope ps("k_ring", s);
-    hipLaunchKernelGGL(k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
+        SCAL_LAUNCH_PROF("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
                        c->d_gap.p, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->sx.p, c->sy.p, c->sz.p, c->si.p);
     }
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,

@@ -385,7 +385,7 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
 // partials in block order (bitwise reproducible) and advances Ceres' trust-region state machine.  No block ever waits,
 // so there is nothing to deadlock; a finished solve turns the remaining launches into no-ops.
 static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase, int outer,
-                                                        const int* __restrict__ d_enable, double* partials, int dbg_mode) {
+                                                        const int* __restrict__ d_enable, double* partials) {
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
@@ -418,7 +418,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
 #pragma unroll
     for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
     const int i = blockIdx.x * 256 + tid;
-    if (dbg_mode != 2 && i < n && f.valid[i]) {
+    if (i < n && f.valid[i]) {
         const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
         const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
         const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
@@ -442,7 +442,6 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
         }
     }
     __syncthreads();
-    if (dbg_mode == 1) return;
     // Hand-off without L2 write-back / invalidate fences (MI355X_MICROARCH.md "Valid forms"): EVERY store of the partials is
     // a write-through (sc0 sc1) store, drained with vmcnt(0) before the block's ticket; EVERY load of them is an sc1 load.
     if (tid < LM_NACC)
@@ -484,9 +483,7 @@ static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* 
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, int outer) {
     const int nb = (f.cap + 255) / 256 > 0 ? (f.cap + 255) / 256 : 1;
     for (int phase = 0; phase < 5; ++phase) {
-        ProfScope ps("k_lm_iter", s);
-        static const int dbg_mode = getenv("SCAL_LM_DBG") ? atoi(getenv("SCAL_LM_DBG")) : 0;  // timing diagnostics only
-        hipLaunchKernelGGL(k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, partials, dbg_mode);
+        SCAL_LAUNCH_PROF("k_lm_iter", k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, partials);
     }
 }
 

@@ -577,9 +577,9 @@ __global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* _
     out.cube[o] = in.cube[vals[i]];
 }
 
-__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, const LMState* __restrict__ st, SoA4 out) {
+__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st, SoA4 out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *d_n) return;
+    if (i >= min(*d_n, cap)) return;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
@@ -588,19 +588,26 @@ __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __
     out.x[i] = sel[0], out.y[i] = sel[1], out.z[i] = sel[2], out.w[i] = in.w[i];
 }
 
-__global__ void __launch_bounds__(256) k_copy_soa(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
-    const int n = min(*d_n, cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *d_n_out = n;
-    if (i < n) out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = in.w[i];
-}
-__global__ void __launch_bounds__(256) k_copy_aos(const float* __restrict__ aos, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
-    const int n = min(*d_n, cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *d_n_out = n;
-    if (i < n) {
-        const float4 p = reinterpret_cast<const float4*>(aos)[i];
-        out.x[i] = p.x, out.y[i] = p.y, out.z[i] = p.z, out.w[i] = p.w;
+// Start of a device-resident step in ONE launch: clears the per-scan counters and copies the lessSharp cloud (xyzi records)
+// and the lessFlat cloud (SoA) of a features context into corner_in / surf_in.  Blocks [0,nbc) corner, the rest surf.
+__global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ less_aos, const int* __restrict__ d_n_less, CSoA4 less_flat,
+                                                    const int* __restrict__ d_n_less_flat, SoA4 corner_in, SoA4 surf_in, MapCounters* C, int cap,
+                                                    int nbc) {
+    const bool corner = static_cast<int>(blockIdx.x) < nbc;
+    const int b = corner ? blockIdx.x : blockIdx.x - nbc;
+    const int n = min(corner ? *d_n_less : *d_n_less_flat, cap);
+    const int i = b * 256 + threadIdx.x;
+    if (blockIdx.x == 0) {  // every counter except the two input counts, which have exactly one writer each below
+        int* w = reinterpret_cast<int*>(C);
+        for (int t = 2 + threadIdx.x; t < static_cast<int>(sizeof(MapCounters) / sizeof(int)); t += 256) w[t] = 0;
+    }
+    if (i == 0) (corner ? C->n_corner_in : C->n_surf_in) = n;
+    if (i >= n) return;
+    if (corner) {
+        const float4 p = reinterpret_cast<const float4*>(less_aos)[i];
+        corner_in.x[i] = p.x, corner_in.y[i] = p.y, corner_in.z[i] = p.z, corner_in.w[i] = p.w;
+    } else {
+        surf_in.x[i] = less_flat.x[i], surf_in.y[i] = less_flat.y[i], surf_in.z[i] = less_flat.z[i], surf_in.w[i] = less_flat.w[i];
     }
 }
 
@@ -761,7 +768,8 @@ void h_rot(const double* q, const double* v, double* o) {
 }
 
 // everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C
-int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, int n_corner_bound, int n_surf_bound, double* q_out,
+int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full, int n_corner_bound,
+             int n_surf_bound, double* q_out,
              double* t_out, scal_map_stats* stats) {
     hipStream_t s = c->stream;
     // transformAssociateToMap (:143-147)
@@ -819,13 +827,11 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     const int assoc_blocks = std::max(1, div_up(c->slot_cap, 4));
     for (int outer = 0; outer < 2; ++outer) {
         {
-            ProfScope ps("k_assoc_knn", s);
-            hipLaunchKernelGGL(k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p,
+            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p,
                                c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, c->nnbuf());
         }
         {
-            ProfScope ps("k_assoc_fit", s);
-            hipLaunchKernelGGL(k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), c->nnbuf(),
+            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), c->nnbuf(),
                                C, outer, F);
         }
         {
@@ -858,7 +864,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     }
     if (have_full) {
         const int nb = std::max(1, div_up(c->scan_cap, 256));
-        hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, st, c->full_out.v());
+        hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, full_view, d_n_full, c->scan_cap, st, c->full_out.v());
     }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
@@ -939,7 +945,7 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     SCAL_TRY(up(corner_last, n_corner, c->corner_in));
     SCAL_TRY(up(surf_last, n_surf, c->surf_in));
     if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
-    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, n_corner, n_surf, q_w_curr, t_w_curr, stats));
+    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, c->full_in.cv(), c->d_nfull.p, n_corner, n_surf, q_w_curr, t_w_curr, stats));
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
         SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
@@ -961,22 +967,18 @@ extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, cons
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_TRY(reset_counters(c, 0, 0, 0));
-    SCAL_HIP(hipStreamSynchronize(s));
-    // order after the feature extraction stream
-    SCAL_HIP(hipEventRecord(c->ev, v.stream));
-    SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
-    MapCounters* C = c->d_C.p;
-    // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563), full-res = ordered cloud
+    if (v.stream != s) {  // order after the feature extraction stream (contexts of one device share a stream by default)
+        SCAL_HIP(hipEventRecord(c->ev, v.stream));
+        SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
+    }
+    // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
+    // read in place by the registration transform
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
-    hipLaunchKernelGGL(k_copy_aos, dim3(std::max(1, div_up(ls_cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp, c->corner_in.v(),
-                       &C->n_corner_in, c->scan_cap);
     const int cap = std::min(c->scan_cap, v.cap);
-    hipLaunchKernelGGL(k_copy_soa, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat,
-                       c->surf_in.v(), &C->n_surf_in, c->scan_cap);
-    hipLaunchKernelGGL(k_copy_soa, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->full_in.v(),
-                       c->d_nfull.p, c->scan_cap);
-    return run_step(c, q_wodom, t_wodom, true, ls_cap, cap, q_w_curr, t_w_curr, stats);
+    const int nbc = std::max(1, div_up(ls_cap, 256));
+    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
+                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in.v(), c->surf_in.v(), c->d_C.p, c->scan_cap, nbc);
+    return run_step(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, q_w_curr, t_w_curr, stats);
 }
 
 extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int cap) {

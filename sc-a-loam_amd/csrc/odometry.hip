@@ -256,25 +256,42 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
     }
 }
 
-__global__ void k_odom_init_pose(LMState* st) {
-    st->x[0] = st->x[1] = st->x[2] = 0.0, st->x[3] = 1.0;  // para_q = {0,0,0,1}, para_t = {0,0,0} (:97-98)
-    st->x[4] = st->x[5] = st->x[6] = 0.0;
+__global__ void k_odom_init_pose(LMState* st, int* ring_tab) {
+    if (threadIdx.x == 0) {
+        st->x[0] = st->x[1] = st->x[2] = 0.0, st->x[3] = 1.0;  // para_q = {0,0,0,1}, para_t = {0,0,0} (:97-98)
+        st->x[4] = st->x[5] = st->x[6] = 0.0;
+    }
+    for (int t = threadIdx.x; t < 8 * RING_TAB; t += blockDim.x) ring_tab[t] = ((t / RING_TAB) & 1) ? -1 : 0x7f7f7f7f;
 }
-__global__ void __launch_bounds__(256) k_odom_copy(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap) {
-    const int n = min(*d_n, cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *d_n_out = n;
-    if (i < n) out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = in.w[i];
-}
-// hand-over copy of a target cloud that also records, per ring id r = int(intensity), the first and last index holding r.
-// first_idx must be pre-filled with a value >= n (0x7f7f7f7f), last_idx with -1.  The walks of :312-361 / :402-455 stop at
+// hand-over copy of both target clouds that also records, per ring id r = int(intensity), the first and last index holding r.
+// The tables are double-buffered: first_idx must be pre-filled with a value >= n (0x7f7f7f7f), last_idx with -1, which the
+// previous hand-over did for the set written now.  The walks of :312-361 / :402-455 stop at
 // the first index past +-2.5 rings; with these tables that index is min_{r' >= id+3} first_idx[r'] (resp. the max of
 // last_idx below id-3): int(intensity) never drops by more than one ring along the cloud, so no earlier index qualifies.
-__global__ void __launch_bounds__(256) k_odom_handover(CSoA4 in, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out, int cap,
-                                                       int* __restrict__ first_idx, int* __restrict__ last_idx) {
-    const int n = min(*d_n, cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *d_n_out = n;
+struct HandoverArgs {
+    CSoA4 in[2];        // current lessSharp, lessFlat
+    const int* d_n[2];
+    SoA4 out[2];        // next scan's corner_last, surf_last
+    int* d_n_out[2];
+    int cap[2];
+    int nb0;            // blocks of the corner part
+    int* tab_write;     // [corner first | corner last | surf first | surf last] x RING_TAB, pre-filled
+    int* tab_reset;     // the set the association of this scan used: re-filled here for the next hand-over
+};
+__global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
+    int b = blockIdx.x;
+    const int k = b < a.nb0 ? 0 : 1;
+    if (k) b -= a.nb0;
+    if (blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < 4 * RING_TAB; t += 256) a.tab_reset[t] = ((t / RING_TAB) & 1) ? -1 : 0x7f7f7f7f;
+    }
+    int* first_idx = a.tab_write + 2 * k * RING_TAB;
+    int* last_idx = first_idx + RING_TAB;
+    const CSoA4 in = a.in[k];
+    const SoA4 out = a.out[k];
+    const int n = min(*a.d_n[k], a.cap[k]);
+    const int i = b * 256 + threadIdx.x;
+    if (i == 0) *a.d_n_out[k] = n;
     if (i < n) {
         const float w = in.w[i];
         out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = w;
@@ -287,14 +304,45 @@ __global__ void __launch_bounds__(256) k_odom_handover(CSoA4 in, const int* __re
         if (lane == 63 || rn != r || i == n - 1) atomicMax(&last_idx[r], i);
     }
 }
-__global__ void __launch_bounds__(256) k_odom_copy_aos(const float* __restrict__ aos, const int* __restrict__ d_n, SoA4 out, int* __restrict__ d_n_out,
-                                                       int cap) {
+// Start of a device-resident step in ONE launch: refreshes the per-scan counters and copies the four feature clouds of a
+// features context (sharp / flat / lessSharp as xyzi records, lessFlat as SoA) into this context's SoA clouds.
+// Block ranges: [0,nbs) sharp, [nbs,2nbs) flat, [2nbs,2nbs+nbf) lessSharp, the rest lessFlat.
+struct OdomGatherArgs {
+    const float *sharp, *flat, *less;   // xyzi records
+    CSoA4 less_flat;
+    const int *n_sharp, *n_flat, *n_less, *n_less_flat;
+    SoA4 o_sharp, o_flat, o_less, o_less_flat;
+    int slot_cap, feat_cap, cap, nbs, nbf;
+};
+__global__ void __launch_bounds__(256) k_odom_gather(OdomGatherArgs a, OdomCounters* C) {
+    int b = blockIdx.x;
+    const float* aos = nullptr;
+    const int* d_n;
+    int* d_n_out;
+    SoA4 out;
+    int cap;
+    if (b < a.nbs) {
+        aos = a.sharp, d_n = a.n_sharp, d_n_out = &C->n_sharp, out = a.o_sharp, cap = a.slot_cap;
+        if (b == 0 && threadIdx.x == 0) {
+            C->n_slots = 0, C->enable = 1;
+            C->n_live[0] = C->n_live[1] = C->n_edge[0] = C->n_edge[1] = C->n_plane[0] = C->n_plane[1] = 0;
+        }
+    } else if (b < 2 * a.nbs) {
+        b -= a.nbs, aos = a.flat, d_n = a.n_flat, d_n_out = &C->n_flat, out = a.o_flat, cap = a.slot_cap;
+    } else if (b < 2 * a.nbs + a.nbf) {
+        b -= 2 * a.nbs, aos = a.less, d_n = a.n_less, d_n_out = &C->n_less_sharp, out = a.o_less, cap = a.feat_cap;
+    } else {
+        b -= 2 * a.nbs + a.nbf, d_n = a.n_less_flat, d_n_out = &C->n_less_flat, out = a.o_less_flat, cap = a.cap;
+    }
     const int n = min(*d_n, cap);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = b * 256 + threadIdx.x;
     if (i == 0) *d_n_out = n;
-    if (i < n) {
+    if (i >= n) return;
+    if (aos) {
         const float4 p = reinterpret_cast<const float4*>(aos)[i];
         out.x[i] = p.x, out.y[i] = p.y, out.z[i] = p.z, out.w[i] = p.w;
+    } else {
+        out.x[i] = a.less_flat.x[i], out.y[i] = a.less_flat.y[i], out.z[i] = a.less_flat.z[i], out.w[i] = a.less_flat.w[i];
     }
 }
 
@@ -329,7 +377,8 @@ struct scal_odom {
     DevBuf<double> fcp, fpa, fpb, partials;
     DevBuf<unsigned long long> nn_part;
     int nch = 1;
-    DevBuf<int> ring_tab;  // [corner first | corner last | surf first | surf last] x RING_TAB
+    DevBuf<int> ring_tab;  // 2 sets of [corner first | corner last | surf first | surf last] x RING_TAB (double-buffered)
+    int tab_cur = 0;       // set read by this scan's association
     DevBuf<LMState> d_st;
     DevBuf<OdomCounters> d_C;
     PinBuf<OdomCounters> h_C;
@@ -360,14 +409,14 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
-    A(c->ring_tab.alloc(4 * RING_TAB));
+    A(c->ring_tab.alloc(8 * RING_TAB));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         if (hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        hipLaunchKernelGGL(k_odom_init_pose, dim3(1), dim3(1), 0, c->stream, c->d_st.p);
+        hipLaunchKernelGGL(k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
         if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
     if (rc != SCAL_OK) {
@@ -415,15 +464,13 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     if (solve) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
             {
-                ProfScope ps("k_odom_nn", s);
                 // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
-                hipLaunchKernelGGL(k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
             }
             {
-                ProfScope ps("k_odom_assoc", s);
-                hipLaunchKernelGGL(k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
-                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p);
+                SCAL_LAUNCH_PROF("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
             }
             {
                                 launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, outer);
@@ -431,15 +478,19 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
         }
     }
     // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets
-    int* tab = c->ring_tab.p;
-    SCAL_HIP(hipMemsetAsync(tab, 0x7f, sizeof(int) * RING_TAB, s));                   // corner first_idx: "beyond the cloud"
-    SCAL_HIP(hipMemsetAsync(tab + RING_TAB, 0xff, sizeof(int) * RING_TAB, s));        // corner last_idx: -1
-    SCAL_HIP(hipMemsetAsync(tab + 2 * RING_TAB, 0x7f, sizeof(int) * RING_TAB, s));
-    SCAL_HIP(hipMemsetAsync(tab + 3 * RING_TAB, 0xff, sizeof(int) * RING_TAB, s));
-    hipLaunchKernelGGL(k_odom_handover, dim3(std::max(1, div_up(c->feat_cap, 256))), dim3(256), 0, s, c->less_sharp.cv(), &C->n_less_sharp,
-                       c->corner_last.v(), &C->n_corner_last, c->feat_cap, tab, tab + RING_TAB);
-    hipLaunchKernelGGL(k_odom_handover, dim3(std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, c->less_flat.cv(), &C->n_less_flat, c->surf_last.v(),
-                       &C->n_surf_last, c->cap, tab + 2 * RING_TAB, tab + 3 * RING_TAB);
+    {
+        HandoverArgs h;
+        h.in[0] = c->less_sharp.cv(), h.in[1] = c->less_flat.cv();
+        h.d_n[0] = &C->n_less_sharp, h.d_n[1] = &C->n_less_flat;
+        h.out[0] = c->corner_last.v(), h.out[1] = c->surf_last.v();
+        h.d_n_out[0] = &C->n_corner_last, h.d_n_out[1] = &C->n_surf_last;
+        h.cap[0] = c->feat_cap, h.cap[1] = c->cap;
+        h.nb0 = std::max(1, div_up(c->feat_cap, 256));
+        h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
+        h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
+        hipLaunchKernelGGL(k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
+        c->tab_cur ^= 1;
+    }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
@@ -523,21 +574,13 @@ extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, do
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    {
-        OdomCounters& H = *c->h_C.p;
-        std::memset(&H, 0, sizeof H);
-        H.enable = 1;
-        const size_t off = offsetof(OdomCounters, n_sharp);
-        SCAL_HIP(hipMemcpyAsync(reinterpret_cast<char*>(c->d_C.p) + off, reinterpret_cast<char*>(&H) + off, sizeof(OdomCounters) - off,
-                                hipMemcpyHostToDevice, s));
-    }
-    OdomCounters* C = c->d_C.p;
-    const int nb_slot = std::max(1, div_up(c->slot_cap, 256)), nb_feat = std::max(1, div_up(c->feat_cap, 256));
-    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_slot), dim3(256), 0, s, v.sharp_xyzi, &v.P->n_sharp, c->sharp.v(), &C->n_sharp, c->slot_cap);
-    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_slot), dim3(256), 0, s, v.flat_xyzi, &v.P->n_flat, c->flat.v(), &C->n_flat, c->slot_cap);
-    hipLaunchKernelGGL(k_odom_copy_aos, dim3(nb_feat), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp, c->less_sharp.v(), &C->n_less_sharp, c->feat_cap);
-    const int cap = std::min(c->cap, v.cap);
-    hipLaunchKernelGGL(k_odom_copy, dim3(std::max(1, div_up(cap, 256))), dim3(256), 0, s, CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat,
-                       c->less_flat.v(), &C->n_less_flat, c->cap);
+    OdomGatherArgs a;
+    a.sharp = v.sharp_xyzi, a.flat = v.flat_xyzi, a.less = v.less_xyzi;
+    a.less_flat = CSoA4{v.lfx, v.lfy, v.lfz, v.lfi};
+    a.n_sharp = &v.P->n_sharp, a.n_flat = &v.P->n_flat, a.n_less = &v.P->n_less_sharp, a.n_less_flat = &v.P->n_less_flat;
+    a.o_sharp = c->sharp.v(), a.o_flat = c->flat.v(), a.o_less = c->less_sharp.v(), a.o_less_flat = c->less_flat.v();
+    a.slot_cap = c->slot_cap, a.feat_cap = c->feat_cap, a.cap = std::min(c->cap, v.cap);
+    a.nbs = std::max(1, div_up(c->slot_cap, 256)), a.nbf = std::max(1, div_up(c->feat_cap, 256));
+    hipLaunchKernelGGL(k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
     return odom_run(c, q_lc, t_lc, q_w, t_w, stats);
 }

@@ -68,18 +68,27 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
     // scatter base of digit d for this block = (exclusive prefix of the digit totals)[d] + sum_{b < block} hist[d][b]
-    int before[2], totals[2];
+    int before[2] = {0, 0}, totals[2] = {0, 0};
+    {
+        // both rows are read in batches of 8 independent loads: one dependent load per block column would serialise
+        // ~2 x nb L2 round trips in front of the scatter
+        const int* row0 = hist + (2 * threadIdx.x) * nb;
+        const int* row1 = row0 + nb;
+        const int me = static_cast<int>(blockIdx.x);
+        for (int b0 = 0; b0 < nb; b0 += 8) {
+            int v0[8], v1[8];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int d = 2 * threadIdx.x + u;
-        int bsum = 0, tsum = 0;
-        const int* row = hist + d * nb;
-        for (int b = 0; b < nb; ++b) {
-            const int v = row[b];
-            tsum += v;
-            if (b < static_cast<int>(blockIdx.x)) bsum += v;
+            for (int q = 0; q < 8; ++q) {
+                const bool in = b0 + q < nb;
+                v0[q] = in ? row0[b0 + q] : 0;
+                v1[q] = in ? row1[b0 + q] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                totals[0] += v0[q], totals[1] += v1[q];
+                if (b0 + q < me) before[0] += v0[q], before[1] += v1[q];
+            }
         }
-        before[u] = bsum, totals[u] = tsum;
     }
     int dummy;
     const int pre = block_exclusive_scan(totals[0] + totals[1], smem, &dummy);
@@ -137,8 +146,7 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
         const int in = pass & 1, o = in ^ 1;
         hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p);
         {
-            ProfScope ps("k_rs_scatter", s);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o]);
+            SCAL_LAUNCH_PROF("k_rs_scatter", k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o]);
         }
     }
     out->keys[0] = kb[0], out->keys[1] = kb[1];

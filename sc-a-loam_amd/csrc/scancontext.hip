@@ -95,8 +95,15 @@ __global__ void __launch_bounds__(256) k_sc_bin(const float* __restrict__ px, co
         if (cell[i]) atomicMax(&gcell[i], cell[i]);
 }
 
-__global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell, double* __restrict__ desc, float* __restrict__ rkey,
-                                                   double* __restrict__ skey, double* __restrict__ cnorm) {
+struct SCSlot {  // one keyframe's record: descriptor (column-major 20x60), ring key, sector key, column norms
+    double* desc;
+    float* rkey;
+    double* skey;
+    double* cnorm;
+};
+
+// writes the record to slot a and, when b.desc != null, to slot b as well (query staging + database slot in one pass)
+__global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell, SCSlot a, SCSlot b) {
     __shared__ double d[DESC];
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
         const unsigned c = gcell[i];
@@ -107,18 +114,29 @@ __global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell,
             if (static_cast<double>(f) > -1000.0) v = static_cast<double>(f);
         }
         d[i] = v;
-        desc[i] = v;
+        a.desc[i] = v;
+        if (b.desc) b.desc[i] = v;
     }
     __syncthreads();
     if (threadIdx.x < NR) {  // makeRingkeyFromScancontext (:198-211) + eig2stdvec cast (:62-66)
         const int r = threadIdx.x;
-        const double m = eigen_sum4(NS, [&](int c) { return d[r + NR * c]; }) / NS;
-        rkey[r] = static_cast<float>(m);
+        const float m = static_cast<float>(eigen_sum4(NS, [&](int c) { return d[r + NR * c]; }) / NS);
+        a.rkey[r] = m;
+        if (b.desc) b.rkey[r] = m;
     } else if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) {  // makeSectorkeyFromScancontext (:214-227), column norms
         const int c = threadIdx.x - 64;
-        skey[c] = eigen_sum4(NR, [&](int r) { return d[r + NR * c]; }) / NR;
-        cnorm[c] = sqrt(eigen_sum4(NR, [&](int r) { return d[r + NR * c] * d[r + NR * c]; }));
+        const double sk = eigen_sum4(NR, [&](int r) { return d[r + NR * c]; }) / NR;
+        const double cn = sqrt(eigen_sum4(NR, [&](int r) { return d[r + NR * c] * d[r + NR * c]; }));
+        a.skey[c] = sk, a.cnorm[c] = cn;
+        if (b.desc) b.skey[c] = sk, b.cnorm[c] = cn;
     }
+}
+
+// copies one record (saveScancontextAndKeys path: the staged descriptor becomes a database slot)
+__global__ void __launch_bounds__(256) k_sc_store(SCSlot from, SCSlot to) {
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x) to.desc[i] = from.desc[i];
+    if (threadIdx.x < NR) to.rkey[threadIdx.x] = from.rkey[threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) to.skey[threadIdx.x - 64] = from.skey[threadIdx.x - 64], to.cnorm[threadIdx.x - 64] = from.cnorm[threadIdx.x - 64];
 }
 
 // keys / norms of a descriptor supplied by the caller (saveScancontextAndKeys, :236-246)
@@ -427,6 +445,8 @@ struct scal_sc {
     int vf_cap = 0;
     hipEvent_t ev = nullptr;
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
+    SCSlot staging() const { return SCSlot{qdesc.p, qrkey.p, qskey.p, qnorm.p}; }
+    SCSlot slot(size_t sl) const { return SCSlot{desc.p + sl * DESC, rkey.p + sl * NR, skey.p + sl * NS, cnorm.p + sl * NS}; }
     bool owns(int g) const { return cfg.n_shards <= 1 || (g % cfg.n_shards) == cfg.shard; }
 };
 
@@ -496,11 +516,8 @@ static int commit_staged(scal_sc* c) {
             set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
             return SCAL_E_CAPACITY;
         }
-        const size_t sl = c->n_local;
-        SCAL_HIP(hipMemcpyAsync(c->desc.p + sl * DESC, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->skey.p + sl * NS, c->qskey.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->cnorm.p + sl * NS, c->qnorm.p, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-        SCAL_HIP(hipMemcpyAsync(c->rkey.p + sl * NR, c->qrkey.p, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_sc_store, dim3(1), dim3(256), 0, s, c->staging(), c->slot(c->n_local));
+        SCAL_HIP(hipGetLastError());
         c->n_local++;
     }
     c->n_global++;
@@ -508,17 +525,26 @@ static int commit_staged(scal_sc* c) {
 }
 
 // build the descriptor of a cloud into the query staging slot; when this shard owns the new global index, also
-// into its database slot
+// into its database slot (same kernel)
 static int make_into(scal_sc* c, const float* px, const float* py, const float* pz, int stride, const int* d_n, int n_host, bool insert) {
     hipStream_t s = c->stream;
+    SCSlot db{nullptr, nullptr, nullptr, nullptr};
+    const bool store = insert && c->owns(c->n_global);
+    if (store) {
+        if (c->n_local >= c->cap) {
+            set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
+            return SCAL_E_CAPACITY;
+        }
+        db = c->slot(c->n_local);
+    }
     const int nblk = std::max(1, std::min(64, div_up(n_host, 1024)));
     hipLaunchKernelGGL(k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
-    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->staging(), db);
     SCAL_HIP(hipGetLastError());
-    if (insert) SCAL_TRY(commit_staged(c));
+    if (store) c->n_local++;
+    if (insert) c->n_global++;
     return SCAL_OK;
 }
-
 static int upload_points(scal_sc* c, const float* xyzi, int n) {
     if (n > c->pts_cap) {
         const int nc = std::max(n, 65536);
@@ -688,13 +714,13 @@ extern "C" int scal_sc_get_descriptor(scal_sc_t* c, int idx, double* desc, float
 }
 
 // ring-key top-3 over global indices < limit on this shard + SC distance of the three; records -> h_rec[0..2]
-static int search_local(scal_sc* c, int limit, bool fill_zero) {
+static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q) {
     hipStream_t s = c->stream;
     const int nb = std::max(1, div_up(c->n_local, 256));
-    hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
+    hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
                        c->block_best.p);
-    hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
-                       c->qnorm.p, fill_zero ? 1 : 0, c->d_rec.p);
+    hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
+                       q.cnorm, fill_zero ? 1 : 0, c->d_rec.p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_rec.p, c->d_rec.p, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
@@ -743,14 +769,8 @@ extern "C" int scal_sc_detect(scal_sc_t* c, scal_sc_result* res) {
     SCAL_HIP(hipSetDevice(c->cfg.device));
     if (c->tree_making_period_conter % TREE_MAKING_PERIOD_ == 0) c->size_at_rebuild = c->n_global;  // :353-364
     c->tree_making_period_conter++;
-    // query = newest keyframe (:340-341)
-    const size_t sl = c->n_global - 1;
-    hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, c->desc.p + sl * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->qskey.p, c->skey.p + sl * NS, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->qnorm.p, c->cnorm.p + sl * NS, sizeof(double) * NS, hipMemcpyDeviceToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->qrkey.p, c->rkey.p + sl * NR, sizeof(float) * NR, hipMemcpyDeviceToDevice, s));
-    SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true));
+    // query = newest keyframe (:340-341), read in place from its database slot
+    SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1)));
     finish_result(c->h_rec.p, 3, c->cfg.dist_thres, res);
     return SCAL_OK;
 }
@@ -765,7 +785,7 @@ extern "C" int scal_sc_shard_query(scal_sc_t* c, const double* query_desc, int g
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->qdesc.p, query_desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
-    SCAL_TRY(search_local(c, global_size_at_rebuild - 30, true));
+    SCAL_TRY(search_local(c, global_size_at_rebuild - 30, true, c->staging()));
     static_assert(sizeof(SCRec) == sizeof(scal_sc_cand), "record layout");
     std::memcpy(out, c->h_rec.p, sizeof(SCRec) * 3);
     return SCAL_OK;

@@ -277,8 +277,7 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
             attr_set = true;
         }
         {
-            ProfScope ps("k_vox_small", s);
-            hipLaunchKernelGGL(k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p);
+            SCAL_LAUNCH_PROF("k_vox_small", k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p);
         }
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
