@@ -268,23 +268,132 @@ __global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, 
     gap[i] = g;
 }
 
-// mark the +-5 neighbours of ring-relative index `li` as picked (:332-355); executed by wave 0.
-// flags[] lives in LDS: bit 0 = cloudNeighborPicked, bit 1 = "the squared gap to the NEXT point exceeds 0.05".
-__device__ __forceinline__ void suppress_neighbours(unsigned char* flags, int li, int lane) {
-    // forward: l = 1..5 stops at the first gap between (ind+l-1, ind+l) => gap bit of ind+l-1
-    bool g = false;
-    if (lane >= 1 && lane <= 5) g = (flags[li + lane - 1] & 2) != 0;
-    uint64_t gm = __ballot(g) >> 1;  // bit k-1 set <=> step l=k is blocked
-    int nf = gm ? (__ffsll(static_cast<long long>(gm)) - 1) : 5;
-    nf = min(nf, 5);
-    // backward: l = -1..-5 stops at the first gap between (ind+l, ind+l+1) => gap bit of ind+l
-    bool gb = false;
-    if (lane >= 1 && lane <= 5) gb = (flags[li - lane] & 2) != 0;
-    uint64_t gbm = __ballot(gb) >> 1;
-    int nbk = gbm ? (__ffsll(static_cast<long long>(gbm)) - 1) : 5;
-    nbk = min(nbk, 5);
-    if (lane >= 1 && lane <= nf) flags[li + lane] |= 1;
-    if (lane >= 1 && lane <= nbk) flags[li - lane] |= 1;
+// Greedy picks of one segment (:304-403), executed by ONE wave.  `keys` = the segment's (curvature, ring-relative index)
+// keys sorted ascending, flags[] = per-point LDS bytes: bit 0 = cloudNeighborPicked, bit 1 = "the squared gap to the NEXT
+// point exceeds 0.05" (:334-340 / :344-351).
+//
+// A window of 64 candidates is held in registers together with everything a pick needs: each lane knows how far its own
+// +-5 suppression would reach (the gap flags never change), so one pick is ballot -> readlane -> range test on registers.
+// LDS is only written (for later windows and segments), never read back inside the window.
+struct PickWindow {
+    int li;    // ring-relative index of the candidate
+    int nf;    // forward reach of its suppression: l = 1..nf
+    int nb;    // backward reach: l = -1..-nb
+    unsigned g; // gap flags of li-5 .. li+5 (bit d+5), so a pick can rewrite its neighbours' bytes without reading them
+    bool cand; // passes the curvature test
+    bool ok;   // cand and not picked yet
+};
+
+template <bool SHARP>
+__device__ __forceinline__ PickWindow load_window(const unsigned long long* keys, int L, int base, const unsigned char* flags, int lane) {
+    PickWindow w;
+    const int p = base + lane;
+    const bool valid = p < L;
+    const unsigned long long k = valid ? keys[SHARP ? L - 1 - p : p] : 0ull;
+    w.li = valid ? static_cast<int>(k & 0xffffffffu) : 5;
+    const float c = __uint_as_float(static_cast<unsigned>(k >> 32));
+    w.cand = valid && (SHARP ? static_cast<double>(c) > 0.1 : static_cast<double>(c) < 0.1);
+    unsigned g = 0, own = 0;
+#pragma unroll
+    for (int d = -5; d <= 5; ++d) {
+        const unsigned f = flags[w.li + d];
+        g |= ((f >> 1) & 1u) << (d + 5);
+        if (d == 0) own = f & 1u;
+    }
+    w.g = g;
+    // forward l = 1..5 stops at the first gap between (li+l-1, li+l) => flag of li+l-1
+    const unsigned gm = (g >> 5) & 0x1fu;
+    w.nf = gm ? __ffs(static_cast<int>(gm)) - 1 : 5;
+    // backward l = -1..-5 stops at the first gap between (li+l, li+l+1) => flag of li+l
+    int nb = 5;
+#pragma unroll
+    for (int l = 5; l >= 1; --l)
+        if ((g >> (5 - l)) & 1u) nb = l - 1;
+    w.nb = nb;
+    w.ok = w.cand && own == 0;
+    return w;
+}
+
+// marks the picked point and its +-reach neighbours in LDS and in the register window
+__device__ __forceinline__ void apply_pick(PickWindow& w, int pli, int pnf, int pnb, unsigned pg, unsigned char* flags, int lane) {
+    if (lane == 0) flags[pli] = 1u | (((pg >> 5) & 1u) << 1);
+    if (lane >= 1 && lane <= pnf) flags[pli + lane] = 1u | (((pg >> (5 + lane)) & 1u) << 1);
+    if (lane >= 1 && lane <= pnb) flags[pli - lane] = 1u | (((pg >> (5 - lane)) & 1u) << 1);
+    if (w.li >= pli - pnb && w.li <= pli + pnf) w.ok = false;
+}
+
+__device__ __forceinline__ void pick_segment(const unsigned long long* keys, int L, int rs, int seg, unsigned char* picked, int* __restrict__ label, int* __restrict__ seg_sharp, int* __restrict__ seg_less,
+                                             int* __restrict__ seg_flat, int* __restrict__ seg_cnt, int lane) {
+    // ---- sharp / lessSharp: largest curvature first (:304-357)
+    int largestPickedNum = 0, n_sh = 0, n_ls = 0;
+    for (int base = 0; base < L; base += 64) {
+        PickWindow w = load_window<true>(keys, L, base, picked, lane);
+        const uint64_t stopm = __ballot(base + lane < L && !w.cand);  // sorted: nothing after the first failure can pass
+        const uint64_t live = stopm ? ((1ull << (__ffsll(static_cast<long long>(stopm)) - 1)) - 1ull) : ~0ull;
+        bool done = false;
+        while (true) {
+            const uint64_t okm = __ballot(w.ok) & live;
+            if (!okm) break;
+            const int f = __ffsll(static_cast<long long>(okm)) - 1;
+            const int pli = __builtin_amdgcn_readlane(w.li, f);
+            const int pnf = __builtin_amdgcn_readlane(w.nf, f), pnb = __builtin_amdgcn_readlane(w.nb, f);
+            const unsigned pg = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w.g), f));
+            largestPickedNum++;
+            if (largestPickedNum <= 2) {
+                if (lane == 0) {
+                    label[rs + pli] = 2;
+                    seg_sharp[seg * 2 + n_sh] = rs + pli;
+                    seg_less[seg * 20 + n_ls] = rs + pli;
+                }
+                n_sh++, n_ls++;
+            } else if (largestPickedNum <= 20) {
+                if (lane == 0) {
+                    label[rs + pli] = 1;
+                    seg_less[seg * 20 + n_ls] = rs + pli;
+                }
+                n_ls++;
+            } else {
+                done = true;  // :327-330: the 21st candidate ends the scan of this segment
+                break;
+            }
+            apply_pick(w, pli, pnf, pnb, pg, picked, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (done || stopm) break;
+    }
+    // ---- flat: smallest curvature first (:359-403)
+    int smallestPickedNum = 0;
+    for (int base = 0; base < L; base += 64) {
+        PickWindow w = load_window<false>(keys, L, base, picked, lane);
+        const uint64_t stopm = __ballot(base + lane < L && !w.cand);
+        const uint64_t live = stopm ? ((1ull << (__ffsll(static_cast<long long>(stopm)) - 1)) - 1ull) : ~0ull;
+        bool done = false;
+        while (true) {
+            const uint64_t okm = __ballot(w.ok) & live;
+            if (!okm) break;
+            const int f = __ffsll(static_cast<long long>(okm)) - 1;
+            const int pli = __builtin_amdgcn_readlane(w.li, f);
+            const int pnf = __builtin_amdgcn_readlane(w.nf, f), pnb = __builtin_amdgcn_readlane(w.nb, f);
+            const unsigned pg = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w.g), f));
+            if (lane == 0) {
+                label[rs + pli] = -1;
+                seg_flat[seg * 4 + smallestPickedNum] = rs + pli;
+            }
+            smallestPickedNum++;
+            if (smallestPickedNum >= 4) {  // the 4th is appended but neither marked nor suppressing (:371-375)
+                done = true;
+                break;
+            }
+            apply_pick(w, pli, pnf, pnb, pg, picked, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (done || stopm) break;
+    }
+    if (lane == 0) {
+        seg_cnt[seg * 3 + 0] = n_sh;
+        seg_cnt[seg * 3 + 1] = n_ls;
+        seg_cnt[seg * 3 + 2] = smallestPickedNum;
+    }
 }
 
 __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const float* __restrict__ x, const float* __restrict__ y,
@@ -364,93 +473,8 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
             if (__syncthreads_or(tie) && tid == 0) atomicAdd(&P->n_tied, 1);
         }
 
-        if (wv == 0) {
-            const unsigned long long* keys = skeys;  // this segment's sorted keys
-            const int seg = r * 6 + j;
-            // ---- sharp / lessSharp: largest curvature first (:304-357)
-            int largestPickedNum = 0, n_sh = 0, n_ls = 0;
-            int base = 0;
-            bool done = false;
-            while (base < L && !done) {
-                const int p = base + lane;
-                const bool valid = p < L;
-                const unsigned long long k = valid ? keys[L - 1 - p] : 0ull;
-                const int li = static_cast<int>(k & 0xffffffffu);
-                const float c = __uint_as_float(static_cast<unsigned>(k >> 32));
-                const bool big = valid && static_cast<double>(c) > 0.1;
-                const bool ok = big && (picked[li] & 1) == 0;
-                const uint64_t okm = __ballot(ok);
-                const uint64_t stopm = __ballot(valid && !big);  // sorted: nothing after this can pass c > 0.1
-                const int first_stop = stopm ? __ffsll(static_cast<long long>(stopm)) - 1 : 64;
-                const int first_ok = okm ? __ffsll(static_cast<long long>(okm)) - 1 : 64;
-                if (first_ok >= first_stop) {
-                    if (stopm) break;
-                    base += 64;
-                    continue;
-                }
-                const int pli = __shfl(li, first_ok, 64);
-                largestPickedNum++;
-                if (largestPickedNum <= 2) {
-                    if (lane == 0) {
-                        label[rs + pli] = 2;
-                        seg_sharp[seg * 2 + n_sh] = rs + pli;
-                        seg_less[seg * 20 + n_ls] = rs + pli;
-                    }
-                    n_sh++, n_ls++;
-                } else if (largestPickedNum <= 20) {
-                    if (lane == 0) {
-                        label[rs + pli] = 1;
-                        seg_less[seg * 20 + n_ls] = rs + pli;
-                    }
-                    n_ls++;
-                } else {
-                    done = true;
-                    break;
-                }
-                if (lane == 0) picked[pli] |= 1;
-                suppress_neighbours(picked, pli, lane);
-                __builtin_amdgcn_wave_barrier();
-                base += first_ok + 1;
-            }
-            // ---- flat: smallest curvature first (:359-403)
-            int smallestPickedNum = 0;
-            base = 0;
-            while (base < L) {
-                const int p = base + lane;
-                const bool valid = p < L;
-                const unsigned long long k = valid ? keys[p] : 0ull;
-                const int li = static_cast<int>(k & 0xffffffffu);
-                const float c = __uint_as_float(static_cast<unsigned>(k >> 32));
-                const bool small = valid && static_cast<double>(c) < 0.1;
-                const bool ok = small && (picked[li] & 1) == 0;
-                const uint64_t okm = __ballot(ok);
-                const uint64_t stopm = __ballot(valid && !small);
-                const int first_stop = stopm ? __ffsll(static_cast<long long>(stopm)) - 1 : 64;
-                const int first_ok = okm ? __ffsll(static_cast<long long>(okm)) - 1 : 64;
-                if (first_ok >= first_stop) {
-                    if (stopm) break;
-                    base += 64;
-                    continue;
-                }
-                const int pli = __shfl(li, first_ok, 64);
-                if (lane == 0) {
-                    label[rs + pli] = -1;
-                    seg_flat[seg * 4 + smallestPickedNum] = rs + pli;
-                }
-                smallestPickedNum++;
-                if (smallestPickedNum >= 4) break;  // the 4th is appended but neither marked nor suppressing (:371-375)
-                if (lane == 0) picked[pli] |= 1;
-                suppress_neighbours(picked, pli, lane);
-                __builtin_amdgcn_wave_barrier();
-                base += first_ok + 1;
-            }
-            if (lane == 0) {
-                seg_cnt[seg * 3 + 0] = n_sh;
-                seg_cnt[seg * 3 + 1] = n_ls;
-                seg_cnt[seg * 3 + 2] = smallestPickedNum;
-            }
-        }
-        __syncthreads();
+        if (wv == 0) pick_segment(skeys, L, rs, r * 6 + j, picked, label, seg_sharp, seg_less, seg_flat, seg_cnt, lane);
+        if (!fast) __syncthreads();  // the next segment's block-wide sort reuses the key buffer
     }
     __threadfence_block();
     __syncthreads();

@@ -114,26 +114,51 @@ __global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
 
+// One thread per voxel (run head) sums its members in sorted = arrival order, as CentroidPoint<PointXYZI> does in f32.  The
+// additions of a run are inherently serial, the loads need not be: the block stages its 256 sorted positions plus a
+// 256-position look-ahead (keys + gathered points) in LDS with independent loads, the per-run loops then read LDS; only a
+// run longer than the look-ahead finishes from global memory.
 __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, CSoA4 in, SoA4 out) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
+    constexpr int SPAN = 512;
     __shared__ int s[17];
+    __shared__ unsigned long long skey[SPAN];
+    __shared__ float sx[SPAN], sy[SPAN], sz[SPAN], sw[SPAN];
     const int sel = sorted_sel(sp);
     const unsigned long long* keys = sp.keys[sel];
     const int* vals = sp.vals[sel];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int base = blockIdx.x * 256;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = h * 256 + threadIdx.x;
+        if (base + t < n) {
+            const int g = vals[base + t];
+            skey[t] = keys[base + t];
+            sx[t] = in.x[g], sy[t] = in.y[g], sz[t] = in.z[g], sw[t] = in.w[g];
+        }
+    }
+    const int i = base + threadIdx.x;
     const int head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
     int total;
-    const int rank = block_exclusive_scan(head, s, &total);
+    const int rank = block_exclusive_scan(head, s, &total);  // contains the barrier that publishes the staged span
     if (!head) return;
-    const unsigned long long k = keys[i];
+    const unsigned long long k = skey[threadIdx.x];
+    const int lim = min(n - base, SPAN);
     float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-    int u = i;
-    while (u < n && keys[u] == k) {  // CentroidPoint<PointXYZI>: f32 sums in sorted (arrival) order
-        const int g = vals[u];
-        ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
-        ++u;
+    int t = threadIdx.x;
+    while (t < lim && skey[t] == k) {
+        ax += sx[t], ay += sy[t], az += sz[t], aw += sw[t];
+        ++t;
+    }
+    int u = base + t;
+    if (t == SPAN) {
+        while (u < n && keys[u] == k) {
+            const int g = vals[u];
+            ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
+            ++u;
+        }
     }
     const float c = static_cast<float>(u - i);
     const int o = blockoff[blockIdx.x] + rank;
