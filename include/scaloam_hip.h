@@ -185,6 +185,7 @@ typedef struct {
     double cost_init[2], cost_final[2];
     int solved;                     /* 0: map too small (:555, :731-734), pose = prior */
     int n_map_corner_total, n_map_surf_total;
+    int insert_path;                /* how :738-802 ran: 0 = full sort of the map pool, 1 = merge of the scan's points into the sorted map */
 } scal_map_stats;
 
 typedef struct scal_map scal_map_t;
@@ -202,6 +203,8 @@ int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double*
 /* current map points of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap content); returns count */
 int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
 int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);
+/* enable (default) / disable the merge insert; both give identical maps, the switch exists for tests and measurements */
+int scal_map_set_merge_insert(scal_map_t* ctx, int enable);
 
 /* ------------------------------------------------------------------ stage B: scan-to-scan odometry
  * Replaces the main loop body of src/laserOdometry.cpp:267-291, :299-506, :554-568. */

@@ -7,6 +7,27 @@
 
 namespace scal {
 
+// Development aid (make STAMPS=1): section time stamps inside single-workgroup kernels.  SCAL_STAMP(i) stores the 100 MHz
+// wall clock into this translation unit's g_stamps[i]; SCAL_DEFINE_STAMP_READER(fn) exports a C function copying them out.
+#ifdef SCAL_STAMPS
+static __device__ long long g_stamps[32];
+#define SCAL_STAMP(i)                                                   \
+    do {                                                                \
+        __builtin_amdgcn_s_waitcnt(0);                                  \
+        ::scal::g_stamps[i] = static_cast<long long>(wall_clock64());   \
+    } while (0)
+#define SCAL_DEFINE_STAMP_READER(fn)                                                                                      \
+    extern "C" int fn(long long* out32) {                                                                                 \
+        if (hipDeviceSynchronize() != hipSuccess) return -1;                                                              \
+        return hipMemcpyFromSymbol(out32, HIP_SYMBOL(::scal::g_stamps), sizeof(long long) * 32) == hipSuccess ? 0 : -1;   \
+    }
+#else
+#define SCAL_STAMP(i) \
+    do {              \
+    } while (0)
+#define SCAL_DEFINE_STAMP_READER(fn)
+#endif
+
 constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -412,6 +412,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
 
     const int r = blockIdx.x;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (r == 32 && tid == 0) SCAL_STAMP(7);
     const int rs = P->ring_off[r], cnt = P->ring_count[r];
     const int start = rs + 5, end = rs + cnt - 6;
     if (tid < 18) seg_cnt[r * 18 + tid] = 0;
@@ -423,6 +424,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
     }
     for (int t = tid; t < cnt + 16; t += blockDim.x) picked[t] = (t < cnt && gap[rs + t]) ? 2 : 0;
     __syncthreads();
+    if (r == 32 && tid == 0) SCAL_STAMP(0);
 
     // segment bounds (:297-298)
     int seg_sp[6], seg_L[6];
@@ -454,6 +456,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
             if (__ballot(tie) && lane == 0) atomicAdd(&P->n_tied, 1);
         }
         __syncthreads();
+        if (r == 32 && tid == 0) SCAL_STAMP(1);
     }
     for (int j = 0; j < 6; ++j) {
         const int sp = seg_sp[j];
@@ -479,6 +482,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
     __threadfence_block();
     __syncthreads();
 
+    if (r == 32 && tid == 0) SCAL_STAMP(2);
     // ---- lessFlat of this ring (:405-411): every k in [start, end-1] with label <= 0, arrival order
     const int span = end - start;  // segments tile [start, end-1]
     const int per = (span + blockDim.x - 1) / blockDim.x;
@@ -532,6 +536,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         if (!guard && wide && m > 0) atomicExch(&P->error, SCAL_E_CAPACITY);
     }
     __syncthreads();
+    if (r == 32 && tid == 0) SCAL_STAMP(3);
     const int mb0 = s_misc[0], mb1 = s_misc[1], mb2 = s_misc[2];
     const bool guard = s_misc[3] != 0;
     const int Mp = max(2, next_pow2(m));
@@ -557,10 +562,12 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         }
     }
     __syncthreads();
+    if (r == 32 && tid == 0) SCAL_STAMP(4);
     if (Mp >= 512)
         block_bitonic_sort_u64_fast(keys, Mp);
     else
         block_bitonic_sort_u64(keys, Mp);
+    if (r == 32 && tid == 0) SCAL_STAMP(5);
     // heads of voxel runs -> output slots
     const int per2 = (m + blockDim.x - 1) / blockDim.x;
     const int c0 = min(m, tid * per2), c1 = min(m, c0 + per2);
@@ -587,7 +594,10 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         }
     }
     if (tid == 0) P->lf_ring_cnt[r] = n_out;
+    if (r == 32 && tid == 0) SCAL_STAMP(6);
 }
+
+SCAL_DEFINE_STAMP_READER(scal_debug_stamps_features)
 
 // one block: turn per-segment pick slots into the reference's emission order (segments in (ring, sixth) order)
 __global__ void __launch_bounds__(1024) k_finalize(FeatParams* P, int n_scans, const int* __restrict__ seg_sharp,

@@ -54,6 +54,8 @@ struct MapCounters {
     int n_total[2];                      // map points to sort in the re-filter pass (old + new)
     int n_map_new[2];                    // map size after the re-filter
     int error;
+    int merge_fail;                      // the merge insert met a case it does not handle: redo with the full sort
+    int merge_neff[2];                   // new points inside the cube window (merge insert)
 };
 
 __device__ __forceinline__ int pack_cube(int ai, int aj, int ak) { return (ai + 512) | ((aj + 512) << 10) | ((ak + 512) << 20); }
@@ -469,6 +471,28 @@ __global__ void k_after_stack(const VoxMeta* m, MapCounters* C, int cap) {
 }
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
+// sort key of a map point: [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; ~0 = outside the cube window
+__device__ __forceinline__ unsigned long long map_key(const MapParams& mp, float inv_leaf, float x, float y, float z, int pc, MapCounters* C) {
+    int ai, aj, ak;
+    unpack_cube(pc, ai, aj, ak);
+    const int I = ai + mp.cenW, J = aj + mp.cenH, K = ak + mp.cenD;
+    if (I < 0 || I >= CW || J < 0 || J >= CH || K < 0 || K >= CD) return ~0ull;  // cleared slab (:346-347 ...) or rejected insert (:753-759)
+    if (abs(I - mp.cI) <= 2 && abs(J - mp.cJ) <= 2 && abs(K - mp.cK) <= 1) {
+        // slot of the cube inside the 5x5x3 valid set, then voxel coordinates relative to one cell below the cube's
+        // lower face; lexicographic (vz,vy,vx) order equals PCL's idx order inside the cube
+        const unsigned long long slot = static_cast<unsigned long long>((I - mp.cI + 2) + 5 * (J - mp.cJ + 2) + 25 * (K - mp.cK + 1));
+        const int bx = static_cast<int>(floorf((50.0f * ai - 26.0f) * inv_leaf));
+        const int by = static_cast<int>(floorf((50.0f * aj - 26.0f) * inv_leaf));
+        const int bz = static_cast<int>(floorf((50.0f * ak - 26.0f) * inv_leaf));
+        int vx = static_cast<int>(floorf(x * inv_leaf)) - bx, vy = static_cast<int>(floorf(y * inv_leaf)) - by,
+            vz = static_cast<int>(floorf(z * inv_leaf)) - bz;
+        if (vx < 0 || vx > 511 || vy < 0 || vy > 511 || vz < 0 || vz > 511) C->error = SCAL_E_CAPACITY;
+        vx = min(max(vx, 0), 511), vy = min(max(vy, 0), 511), vz = min(max(vz, 0), 511);
+        return (slot << 27) | (static_cast<unsigned long long>(vz) << 18) | (static_cast<unsigned long long>(vy) << 9) | static_cast<unsigned long long>(vx);
+    }
+    return MAP_NOMERGE << 27;  // cube not re-filtered this scan: keep every point; one shared key + stable sort = arrival order
+}
+
 // appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
 //   key layout (36 sorted bits = 4 passes): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
 __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA4 stack, const int* __restrict__ d_nstack, const LMState* __restrict__ st,
@@ -497,29 +521,7 @@ __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA
         // cube_abs already excludes cen; see unpack below
         m.x[i] = x, m.y[i] = y, m.z[i] = z, m.w[i] = stack.w[j], m.cube[i] = pc;
     }
-    int ai, aj, ak;
-    unpack_cube(pc, ai, aj, ak);
-    const int I = ai + mp.cenW, J = aj + mp.cenH, K = ak + mp.cenD;
-    unsigned long long k;
-    if (I < 0 || I >= CW || J < 0 || J >= CH || K < 0 || K >= CD) {
-        k = ~0ull;  // outside the 21x21x11 window: cleared slab (:346-347 ...) or rejected insert (:753-759)
-    } else {
-        if (abs(I - mp.cI) <= 2 && abs(J - mp.cJ) <= 2 && abs(K - mp.cK) <= 1) {
-            // slot of the cube inside the 5x5x3 valid set, then voxel coordinates relative to one cell below the cube's
-            // lower face; lexicographic (vz,vy,vx) order equals PCL's idx order inside the cube
-            const unsigned long long slot = static_cast<unsigned long long>((I - mp.cI + 2) + 5 * (J - mp.cJ + 2) + 25 * (K - mp.cK + 1));
-            const int bx = static_cast<int>(floorf((50.0f * ai - 26.0f) * inv_leaf));
-            const int by = static_cast<int>(floorf((50.0f * aj - 26.0f) * inv_leaf));
-            const int bz = static_cast<int>(floorf((50.0f * ak - 26.0f) * inv_leaf));
-            int vx = static_cast<int>(floorf(x * inv_leaf)) - bx, vy = static_cast<int>(floorf(y * inv_leaf)) - by,
-                vz = static_cast<int>(floorf(z * inv_leaf)) - bz;
-            if (vx < 0 || vx > 511 || vy < 0 || vy > 511 || vz < 0 || vz > 511) C->error = SCAL_E_CAPACITY;
-            vx = min(max(vx, 0), 511), vy = min(max(vy, 0), 511), vz = min(max(vz, 0), 511);
-            k = (slot << 27) | (static_cast<unsigned long long>(vz) << 18) | (static_cast<unsigned long long>(vy) << 9) | static_cast<unsigned long long>(vx);
-        } else {
-            k = MAP_NOMERGE << 27;  // cube not re-filtered this scan: keep every point; one shared key + stable sort = arrival order
-        }
-    }
+    const unsigned long long k = map_key(mp, inv_leaf, x, y, z, pc, C);
     keys[i] = k;
     vals[i] = i;
 }
@@ -575,6 +577,215 @@ __global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* _
     const float c = static_cast<float>(u - i);
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
     out.cube[o] = in.cube[vals[i]];
+}
+
+// ---------------------------------------------------------------------------------------------- merge insert
+// The re-filter of :738-802 without sorting the map.  After a re-filter every valid cube holds one point per voxel in key
+// order, and re-filtering such points alone returns them unchanged ((0 + x) / 1 in f32).  So when the cube window did not
+// move since the previous scan, only the scan's new points need sorting (<= MERGE_MAX, one workgroup); they are then merged
+// into the old sequence: a new voxel run whose key equals an old point's joins that point's centroid (old point first, then
+// the new points in arrival order - exactly the order the stable full sort would give), the other runs are inserted.
+// Anything unusual - old keys not strictly increasing inside a valid cube (a centroid rounded across a voxel face, a cube
+// that collected unfiltered points while it was outside the 5x5x3 window), an old point outside the window, too many new
+// points - raises MapCounters::merge_fail and the host redoes the insertion with the full sort.
+constexpr int MERGE_MAX = 8192;
+constexpr int MERGE_IDX_BITS = 13;
+
+struct MergeNew {            // per class, MERGE_MAX entries
+    float *x, *y, *z, *w;    // new points in the map frame, arrival order
+    int* cube;
+    unsigned long long* key;     // their map keys
+    unsigned long long* sorted;  // (key << 13 | arrival index), ascending; entries >= n_eff are ~0
+    int* pre;                    // [MERGE_MAX + 1] inserted (unmatched) runs that start before sorted position t
+    int* lb;                     // run heads: number of old points in front of the run
+    unsigned char* hm;           // bit 0: run head, bit 1: run joins an old point
+};
+struct MergeArgs {
+    MapCloud in[2], out[2];
+    int n_old[2];
+    CSoA4 stack[2];
+    const int* d_ns[2];
+    float inv_leaf[2];
+    unsigned long long* okeys[2];  // keys of the old points
+    MergeNew nw[2];
+    int nbo[2];                    // blocks over the old points
+    int cap;
+};
+constexpr int MERGE_NEW_BLOCKS = MERGE_MAX / 256;
+
+__device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >> 27) == MAP_NOMERGE; }
+
+__global__ void __launch_bounds__(256) k_merge_keys(MergeArgs a, const LMState* __restrict__ st, MapParams mp, MapCounters* C) {
+    int b = blockIdx.x;
+    int cls, part;  // part 0: old points, 1: new points
+    if (b < a.nbo[0]) cls = 0, part = 0;
+    else if ((b -= a.nbo[0]) < a.nbo[1]) cls = 1, part = 0;
+    else if ((b -= a.nbo[1]) < MERGE_NEW_BLOCKS) cls = 0, part = 1;
+    else b -= MERGE_NEW_BLOCKS, cls = 1, part = 1;
+    const int i = b * 256 + threadIdx.x;
+    const MapCloud m = a.in[cls];
+    if (part == 0) {
+        if (i >= a.n_old[cls]) return;
+        const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
+        a.okeys[cls][i] = k;
+        bool bad = k == ~0ull;
+        if (i > 0) {
+            const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
+            bad |= kp > k || (kp == k && !key_nomerge(k));
+        }
+        if (bad) C->merge_fail = 1;
+        return;
+    }
+    const int ns = *a.d_ns[cls];
+    if (i == 0 && (ns > MERGE_MAX || a.n_old[cls] + ns > a.cap)) C->merge_fail = 1;
+    if (i >= min(ns, MERGE_MAX)) return;
+    double x7[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+    float sel[3];
+    const CSoA4 stack = a.stack[cls];
+    associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);  // :740 / :764
+    const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
+    const MergeNew nw = a.nw[cls];
+    nw.x[i] = sel[0], nw.y[i] = sel[1], nw.z[i] = sel[2], nw.w[i] = stack.w[i], nw.cube[i] = pc;
+    nw.key[i] = map_key(mp, a.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
+}
+
+// one workgroup per class: sort the new keys, find the run heads, look each head up among the old keys, count the inserts
+__global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters* C) {
+    extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX keys
+    __shared__ unsigned char s_hm[MERGE_MAX];
+    __shared__ int s_scan[17];
+    const int cls = blockIdx.x;
+    const MergeNew nw = a.nw[cls];
+    const int tid = threadIdx.x;
+    const int n_new = min(*a.d_ns[cls], MERGE_MAX);
+    const int n_old = a.n_old[cls];
+    const unsigned long long* okeys = a.okeys[cls];
+    const int np2 = max(512, next_pow2(n_new));
+    int mine = 0;
+    for (int t = tid; t < np2; t += 1024) {
+        unsigned long long k = ~0ull;
+        if (t < n_new) {
+            const unsigned long long kk = nw.key[t];
+            if (kk != ~0ull) k = (kk << MERGE_IDX_BITS) | static_cast<unsigned long long>(t), ++mine;
+        }
+        sk[t] = k;
+    }
+    int n_eff = 0;
+    block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
+    block_bitonic_sort_u64_fast(sk, np2);
+    // heads + lookups; element t = e * 1024 + tid, so the eight binary searches of a thread advance in lock step
+    constexpr int PER = MERGE_MAX / 1024;
+    unsigned long long key[PER];
+    int lo[PER], hi[PER];
+    bool head[PER], nom[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int t = e * 1024 + tid;
+        head[e] = false, nom[e] = false, key[e] = 0, lo[e] = 0, hi[e] = 0;
+        if (t < n_eff) {
+            key[e] = sk[t] >> MERGE_IDX_BITS;
+            nom[e] = key_nomerge(key[e]);
+            head[e] = nom[e] || t == 0 || (sk[t - 1] >> MERGE_IDX_BITS) != key[e];
+            if (head[e] && !nom[e]) hi[e] = n_old;       // lower bound among the old keys
+            if (nom[e]) lo[e] = hi[e] = n_old;           // behind every old point (NOMERGE is the largest old key)
+        }
+    }
+    for (int step = 0; step < 32; ++step) {
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (lo[e] < hi[e]) {
+                const int mid = (lo[e] + hi[e]) >> 1;
+                if (okeys[mid] < key[e]) lo[e] = mid + 1;
+                else hi[e] = mid;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int t = e * 1024 + tid;
+        if (t < n_eff) {
+            const bool matched = head[e] && !nom[e] && lo[e] < n_old && okeys[lo[e]] == key[e];
+            s_hm[t] = (head[e] ? 1 : 0) | (matched ? 2 : 0);
+            nw.lb[t] = lo[e];
+        }
+    }
+    __syncthreads();
+    // inserted runs in front of every sorted position
+    const int c0 = min(n_eff, tid * PER), c1 = min(n_eff, c0 + PER);
+    int ins = 0;
+    for (int t = c0; t < c1; ++t) ins += (s_hm[t] & 3) == 1;
+    int total = 0;
+    int run = block_exclusive_scan(ins, s_scan, &total);
+    for (int t = c0; t < c1; ++t) {
+        nw.pre[t] = run;
+        run += (s_hm[t] & 3) == 1;
+        nw.hm[t] = s_hm[t];
+        nw.sorted[t] = sk[t];
+    }
+    if (tid == 0) {
+        nw.pre[n_eff] = total;
+        C->merge_neff[cls] = n_eff;
+        C->n_map_new[cls] = n_old + total;
+        if (n_old + total > a.cap) C->merge_fail = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, const MapCounters* __restrict__ C) {
+    int b = blockIdx.x;
+    int cls, part;
+    if (b < a.nbo[0]) cls = 0, part = 0;
+    else if ((b -= a.nbo[0]) < a.nbo[1]) cls = 1, part = 0;
+    else if ((b -= a.nbo[1]) < MERGE_NEW_BLOCKS) cls = 0, part = 1;
+    else b -= MERGE_NEW_BLOCKS, cls = 1, part = 1;
+    const int i = b * 256 + threadIdx.x;
+    const MapCloud in = a.in[cls], out = a.out[cls];
+    const MergeNew nw = a.nw[cls];
+    const int n_eff = C->merge_neff[cls];
+    const int n_old = a.n_old[cls];
+    if (part == 0) {
+        if (i >= n_old) return;
+        const unsigned long long k = a.okeys[cls][i];
+        int lo = 0, hi = n_eff;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((nw.sorted[mid] >> MERGE_IDX_BITS) < k) lo = mid + 1;
+            else hi = mid;
+        }
+        const int o = min(i + nw.pre[lo], a.cap - 1);
+        // (0 + x) / 1: what the re-filter computes for a voxel holding this point alone
+        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+        ax += in.x[i], ay += in.y[i], az += in.z[i], aw += in.w[i];
+        int cnt = 1;
+        if (!key_nomerge(k)) {
+            int u = lo;
+            while (u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k) {  // new points of the same voxel, arrival order
+                const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
+                ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
+                ++u, ++cnt;
+            }
+        }
+        const float c = static_cast<float>(cnt);
+        out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c, out.cube[o] = in.cube[i];
+        return;
+    }
+    if (i >= n_eff || (nw.hm[i] & 3) != 1) return;  // only heads of inserted runs
+    const unsigned long long k = nw.sorted[i] >> MERGE_IDX_BITS;
+    const int o = min(nw.lb[i] + nw.pre[i], a.cap - 1);
+    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+    int u = i;
+    do {
+        const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
+        ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
+        ++u;
+    } while (!key_nomerge(k) && u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k);
+    const float c = static_cast<float>(u - i);
+    out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
+    out.cube[o] = nw.cube[static_cast<int>(nw.sorted[i] & (MERGE_MAX - 1))];
 }
 
 __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st, SoA4 out) {
@@ -670,6 +881,16 @@ struct scal_map {
     RadixSort sorter;
     DevBuf<unsigned long long> keys;
     DevBuf<int> vals, blockcnt;
+    // merge insert
+    bool merge_insert = true;
+    int last_insert_path = 0;  // 0 full sort, 1 merge
+    SoAStore mnew[2];
+    DevBuf<int> mcube[2], mpre[2], mlb[2];
+    DevBuf<unsigned long long> mkey[2], msorted[2];
+    DevBuf<unsigned char> mhm[2];
+    MergeNew merge_new(int k) {
+        return MergeNew{mnew[k].x.p, mnew[k].y.p, mnew[k].z.p, mnew[k].w.p, mcube[k].p, mkey[k].p, msorted[k].p, mpre[k].p, mlb[k].p, mhm[k].p};
+    }
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
     DevBuf<float> nnx, nny, nnz, nnd5;
@@ -718,6 +939,10 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     }
     A(c->sorter.init(c->map_cap));
     A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
+    for (int k = 0; k < 2; ++k) {
+        A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
+        A(c->mkey[k].alloc(MERGE_MAX)); A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX));
+    }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
     A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
@@ -795,6 +1020,8 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
     mp.ox = 50 * (cI - 2 - c->cenW) - 25, mp.oy = 50 * (cJ - 2 - c->cenH) - 25, mp.oz = 50 * (cK - 1 - c->cenD) - 25;
     mp.inv_line = 1.0f / c->cfg.line_res, mp.inv_plane = 1.0f / c->cfg.plane_res;
+    const bool window_same = c->have_mp && c->last_mp.cenW == mp.cenW && c->last_mp.cenH == mp.cenH && c->last_mp.cenD == mp.cenD &&
+                             c->last_mp.cI == mp.cI && c->last_mp.cJ == mp.cJ && c->last_mp.cK == mp.cK;
     c->last_mp = mp;
     c->have_mp = true;
 
@@ -845,22 +1072,51 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         hipLaunchKernelGGL(k_grid_clear, dim3(nb), dim3(256), 0, s, M.cloud(M.cur), M.n, mp, c->grid[k].rank.p, c->grid[k].cnt.p);
     }
     // insert + re-filter (:738-802)
-    for (int k = 0; k < 2; ++k) {
-        MapStore& M = c->map[k];
-        const int n_new_max = k == 0 ? c->scan_cap : c->scan_cap;
-        const int n_tot_max = std::min(c->map_cap, M.n + n_new_max);
-        const int nb = std::max(1, div_up(n_tot_max, 256));
-        MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
-        const CSoA4 stack = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
-        const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
-                           c->keys.p, c->vals.p, C, k);
-        SortedPairs sp;
-        SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
-        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
-        launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
-        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
-        M.cur ^= 1;
+    auto insert_full_sort = [&]() -> int {
+        for (int k = 0; k < 2; ++k) {
+            MapStore& M = c->map[k];
+            const int n_tot_max = std::min(c->map_cap, M.n + c->scan_cap);
+            const int nb = std::max(1, div_up(n_tot_max, 256));
+            MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
+            const CSoA4 stack = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
+            const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+            hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
+                               c->keys.p, c->vals.p, C, k);
+            SortedPairs sp;
+            SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
+            hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
+            launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
+            hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
+        }
+        return SCAL_OK;
+    };
+    const bool try_merge = c->merge_insert && window_same && c->map[0].n + MERGE_MAX <= c->map_cap && c->map[1].n + MERGE_MAX <= c->map_cap;
+    if (try_merge) {
+        MergeArgs a;
+        for (int k = 0; k < 2; ++k) {
+            MapStore& M = c->map[k];
+            a.in[k] = M.cloud(M.cur), a.out[k] = M.cloud(M.cur ^ 1);
+            a.n_old[k] = M.n;
+            a.stack[k] = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
+            a.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+            a.inv_leaf[k] = k == 0 ? mp.inv_line : mp.inv_plane;
+            a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
+            a.nw[k] = c->merge_new(k);
+            a.nbo[k] = std::max(1, div_up(M.n, 256));
+        }
+        a.cap = c->map_cap;
+        const int grid = a.nbo[0] + a.nbo[1] + 2 * MERGE_NEW_BLOCKS;
+        static bool attr_set = false;
+        const int lds = sizeof(unsigned long long) * MERGE_MAX;
+        if (!attr_set) {
+            SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_merge_keys, dim3(grid), dim3(256), 0, s, a, st, mp, C);
+        hipLaunchKernelGGL(k_merge_prepare, dim3(2), dim3(1024), lds, s, a, C);
+        hipLaunchKernelGGL(k_merge_write, dim3(grid), dim3(256), 0, s, a, C);
+    } else {
+        SCAL_TRY(insert_full_sort());
     }
     if (have_full) {
         const int nb = std::max(1, div_up(c->scan_cap, 256));
@@ -870,6 +1126,15 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
+    c->last_insert_path = try_merge ? 1 : 0;
+    if (try_merge && c->h_C.p->merge_fail && !c->h_C.p->error) {  // a case the merge does not cover: redo with the full sort
+        SCAL_TRY(insert_full_sort());
+        SCAL_HIP(hipGetLastError());
+        SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+        c->last_insert_path = 0;
+    }
+    for (int k = 0; k < 2; ++k) c->map[k].cur ^= 1;
     const MapCounters& H = *c->h_C.p;
     for (int k = 0; k < 2; ++k) c->map[k].n = H.n_map_new[k];
     if (H.error) {
@@ -899,6 +1164,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         }
         stats->solved = H.solve_on;
         stats->n_map_corner_total = H.n_map_new[0], stats->n_map_surf_total = H.n_map_new[1];
+        stats->insert_path = c->last_insert_path;
     }
     return SCAL_OK;
 }
@@ -1006,6 +1272,12 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
         return m;
     }
     return n;
+}
+
+extern "C" int scal_map_set_merge_insert(scal_map_t* c, int enable) {
+    if (!c) return SCAL_E_ARG;
+    c->merge_insert = enable != 0;
+    return SCAL_OK;
 }
 
 extern "C" int scal_map_get_wmap_wodom(scal_map_t* c, double* q, double* t) {

@@ -175,6 +175,7 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     __shared__ int s_mb[4];
     const int n = min(*d_n, VOX_SMALL);
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (tid == 0) SCAL_STAMP(0);
     if (tid == 0) m->error = (*d_n > VOX_SMALL) ? SCAL_E_CAPACITY : 0, m->guard = 0;
     if (n == 0) {
         if (tid == 0) *d_n_out = 0;
@@ -215,6 +216,7 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     }
     __syncthreads();
     const bool guard = s_mb[3] != 0;
+    if (tid == 0) SCAL_STAMP(1);
     const int np2 = max(2, next_pow2(n));
     for (int i = tid; i < np2; i += blockDim.x) {
         unsigned long long k = ~0ull;
@@ -232,10 +234,12 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
         skeys[i] = k;
     }
     __syncthreads();
+    if (tid == 0) SCAL_STAMP(2);
     if (np2 >= 512)
         block_bitonic_sort_u64_fast(skeys, np2);
     else
         block_bitonic_sort_u64(skeys, np2);
+    if (tid == 0) SCAL_STAMP(3);
     // every thread owns 8 consecutive sorted positions; their points are gathered up front (independent loads) so the
     // ordered f32 sums below run on registers; a run that continues past the thread's window finishes from memory
     constexpr int PER = VOX_SMALL / 1024;
@@ -255,6 +259,7 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     }
     int n_out = 0;
     int opos = block_exclusive_scan(heads, s_scan, &n_out);
+    if (tid == 0) SCAL_STAMP(4);
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         const int t = c0 + e;
@@ -280,7 +285,9 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
         }
     }
     if (tid == 0) *d_n_out = n_out;
+    if (tid == 0) SCAL_STAMP(5);
 }
+SCAL_DEFINE_STAMP_READER(scal_debug_stamps_voxel)
 
 int VoxelFilter::init(int capacity) {
     cap = capacity;

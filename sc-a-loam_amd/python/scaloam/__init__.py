@@ -61,7 +61,7 @@ class MapStats(C.Structure):
     _fields_ = [("n_corner_stack", C.c_int), ("n_surf_stack", C.c_int), ("n_corner_map", C.c_int), ("n_surf_map", C.c_int),
                 ("n_edge", C.c_int * 2), ("n_plane", C.c_int * 2), ("lm_iters", C.c_int * 2), ("lm_success", C.c_int * 2),
                 ("cost_init", C.c_double * 2), ("cost_final", C.c_double * 2), ("solved", C.c_int),
-                ("n_map_corner_total", C.c_int), ("n_map_surf_total", C.c_int)]
+                ("n_map_corner_total", C.c_int), ("n_map_surf_total", C.c_int), ("insert_path", C.c_int)]
 
 
 class OdomConfig(C.Structure):
@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features",
     "scal_factors_eval",
 ]
@@ -142,6 +142,7 @@ def lib():
     L.scal_map_step_features.argtypes = [vp, vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(MapStats)]
     L.scal_map_export.argtypes = [vp, C.c_int, _f32p, C.c_int]
     L.scal_map_get_wmap_wodom.argtypes = [vp, _f64p, _f64p]
+    L.scal_map_set_merge_insert.argtypes = [vp, C.c_int]
     L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
     L.scal_odom_destroy.argtypes = [vp]
     L.scal_odom_destroy.restype = None
@@ -414,6 +415,9 @@ class LaserMapping:
         out = np.zeros((max(n, 1), 4), np.float32)
         m = lib().scal_map_export(self.h, which, _p(out, _f32p), n)
         return out[:m]
+
+    def set_merge_insert(self, enable):
+        _check(lib().scal_map_set_merge_insert(self.h, 1 if enable else 0))
 
     def wmap_wodom(self):
         q = np.zeros(4)

@@ -97,3 +97,25 @@ def test_window_roll(O, S, stage_ab):
             mo, mg = _sorted_rows(om.export(which)), _sorted_rows(gm.export(which))
             assert mo.shape == mg.shape, (step, which)
     gm.close()
+
+
+def test_merge_insert_equals_full_sort(S, stage_ab):
+    """The map insertion (:738-802) has two device paths: a full sort of the map pool and, while the cube window stays put, a
+    merge of the scan's sorted points into the already sorted map.  Both must give the same map, bit for bit, hence the same poses."""
+    a = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    b = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    b.set_merge_insert(False)
+    used = 0
+    frames = list(stage_ab) + [stage_ab[-1], stage_ab[-1]]  # a repeated scan: every new voxel run joins an old point
+    for k, fr in enumerate(frames):
+        qa, ta, sa, _ = a.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+        qb, tb, sb, _ = b.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+        assert sb.insert_path == 0
+        used += sa.insert_path
+        assert np.array_equal(qa, qb) and np.array_equal(ta, tb), k
+        assert sa.n_map_corner_total == sb.n_map_corner_total and sa.n_map_surf_total == sb.n_map_surf_total, k
+        for which in (0, 1):
+            ma, mb = _sorted_rows(a.export(which)), _sorted_rows(b.export(which))  # export order is not defined
+            assert ma.shape == mb.shape and np.array_equal(ma, mb), (k, which)
+    assert used >= len(frames) - 3, used  # first scan and window moves take the full sort
+    a.close(), b.close()
