@@ -99,132 +99,168 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* smem, int* total
     return base + incl - v;
 }
 
-// In-LDS bitonic sort of n_pow2 uint64 keys (ascending) by the whole block.  Contains __syncthreads().
-__device__ __forceinline__ void block_bitonic_sort_u64(unsigned long long* s, int n_pow2) {
-    const int half = n_pow2 >> 1;
-    for (int k = 2; k <= n_pow2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < half; t += blockDim.x) {
-                const int i = 2 * t - (t & (j - 1));
-                const int ixj = i + j;
-                const bool up = (i & k) == 0;
-                const unsigned long long a = s[i], b = s[ixj];
-                if ((a > b) == up) {
-                    s[i] = b;
-                    s[ixj] = a;
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
     const unsigned lo = static_cast<unsigned>(__shfl_xor(static_cast<int>(v & 0xffffffffu), mask, 64));
     const unsigned hi = static_cast<unsigned>(__shfl_xor(static_cast<int>(v >> 32), mask, 64));
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-// Bitonic stages k = 2 .. 512 on 512 keys held by ONE wave, 8 per lane, element index = r*64 + lane (r = 0..7).
-// No LDS, no barrier: partners closer than 64 are exchanged with lane shuffles, the others live in the same lane.
-// The direction of every compare follows the global network: ascending iff ((global_base + index) & k) == 0, so the
-// chunk can be one 512-block of a larger bitonic sort that continues in LDS from k = 1024.
-__device__ __forceinline__ void wave_bitonic_sort512(unsigned long long (&v)[8], int global_base) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 2; k <= 512; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= 64) {
-                const int rr = j >> 6;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if ((r & rr) == 0) {
-                        const bool up = ((global_base + r * 64 + lane) & k) == 0;
-                        const unsigned long long a = v[r], b = v[r | rr];
-                        if ((a > b) == up) v[r] = b, v[r | rr] = a;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const unsigned long long a = v[r];
-                    const unsigned long long p = shfl_xor_u64(a, j);
-                    const bool up = ((global_base + r * 64 + lane) & k) == 0;
-                    const bool lower = (lane & j) == 0;
-                    const unsigned long long mn = a < p ? a : p, mx = a < p ? p : a;
-                    v[r] = (lower == up) ? mn : mx;
-                }
-            }
-        }
-    }
+// value of lane (lane ^ X) for the lane masks a bitonic network needs.  X = 1, 2, 3, 7, 15 are DPP modifiers (quad_perm,
+// row_half_mirror, row_mirror: full VALU rate, no LDS round trip), 4, 8, 16, 31 use ds_swizzle (no address VGPR), 32 and 63
+// fall back to ds_bpermute.
+template <int X>
+__device__ __forceinline__ int lane_xor_i32(int v) {
+    if constexpr (X == 1) return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (X == 2) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (X == 3) return __builtin_amdgcn_mov_dpp(v, 0x1B, 0xf, 0xf, false);   // quad_perm [3,2,1,0]
+    else if constexpr (X == 7) return __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    else if constexpr (X == 15) return __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, false); // row_mirror
+    else if constexpr (X == 4 || X == 8 || X == 16 || X == 31) return __builtin_amdgcn_ds_swizzle(v, 0x1F | (X << 10));
+    else return __shfl_xor(v, X, 64);
+}
+template <int X>
+__device__ __forceinline__ unsigned long long lane_xor_u64(unsigned long long v) {
+    const unsigned lo = static_cast<unsigned>(lane_xor_i32<X>(static_cast<int>(v & 0xffffffffu)));
+    const unsigned hi = static_cast<unsigned>(lane_xor_i32<X>(static_cast<int>(v >> 32)));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 
-// The steps j = 256 .. 1 of merge stage k (k >= 1024) on one 512-chunk held in registers (same layout as above).
-__device__ __forceinline__ void wave_bitonic_merge512(unsigned long long (&v)[8], int global_base, int k) {
-    const int lane = lane_id();
+// ---- ascending bitonic sort of 512 keys held by ONE wave, 8 per lane, element index = lane*8 + r.
+// "Flip" form of the network: stage k first compares i with its mirror image inside the k-block, then runs half-cleaners
+// j = k/4 .. 1; every compare is ascending, so keys equal to the maximum (padding) never move down.  With this layout the
+// distances 1, 2, 4 stay inside a lane (24 of the 45 steps), the lane masks of the others are 1, 2, 3, 7, 15 (DPP),
+// 4, 8, 16, 31 (swizzle) and 32, 63 (bpermute): 8 steps through the LDS crossbar instead of 39.
+__device__ __forceinline__ void cmpswap(unsigned long long& a, unsigned long long& b) {
+    const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo, b = hi;
+}
+template <int J>
+__device__ __forceinline__ void reg_half_cleaner(unsigned long long (&v)[8]) {
 #pragma unroll
-    for (int j = 256; j > 0; j >>= 1) {
-        if (j >= 64) {
-            const int rr = j >> 6;
+    for (int r = 0; r < 8; ++r)
+        if ((r & J) == 0) cmpswap(v[r], v[r | J]);
+}
+template <int K>
+__device__ __forceinline__ void reg_mirror(unsigned long long (&v)[8]) {  // K = 2, 4, 8 registers per block
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if ((r & rr) == 0) {
-                    const bool up = ((global_base + r * 64 + lane) & k) == 0;
-                    const unsigned long long a = v[r], b = v[r | rr];
-                    if ((a > b) == up) v[r] = b, v[r | rr] = a;
-                }
-            }
-        } else {
+    for (int r = 0; r < 8; ++r)
+        if ((r & (K >> 1)) == 0) cmpswap(v[r], v[r ^ (K - 1)]);
+}
+__device__ __forceinline__ void reg_tail(unsigned long long (&v)[8]) {
+    reg_half_cleaner<4>(v);
+    reg_half_cleaner<2>(v);
+    reg_half_cleaner<1>(v);
+}
+// half-cleaner between lanes l and l ^ X (same register)
+template <int X>
+__device__ __forceinline__ void lane_half_cleaner(unsigned long long (&v)[8]) {
+    const bool lower = (lane_id() & X) == 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const unsigned long long a = v[r];
-                const unsigned long long p = shfl_xor_u64(a, j);
-                const bool up = ((global_base + r * 64 + lane) & k) == 0;
-                const bool lower = (lane & j) == 0;
-                const unsigned long long mn = a < p ? a : p, mx = a < p ? p : a;
-                v[r] = (lower == up) ? mn : mx;
-            }
-        }
+    for (int r = 0; r < 8; ++r) {
+        const unsigned long long a = v[r], p = lane_xor_u64<X>(a);
+        v[r] = ((a < p) == lower) ? a : p;
     }
 }
+// mirror step of a stage spanning M lanes: (lane, r) <-> (lane ^ (M-1), 7 - r)
+template <int M>
+__device__ __forceinline__ void lane_mirror(unsigned long long (&v)[8]) {
+    const bool lower = (lane_id() & (M >> 1)) == 0;
+    unsigned long long p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p[r] = lane_xor_u64<M - 1>(v[7 - r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = ((v[r] < p[r]) == lower) ? v[r] : p[r];
+}
+template <int M>
+__device__ __forceinline__ void lane_stage(unsigned long long (&v)[8]) {  // stage k = 8*M
+    lane_mirror<M>(v);
+    if constexpr (M >= 64) lane_half_cleaner<16>(v);
+    if constexpr (M >= 32) lane_half_cleaner<8>(v);
+    if constexpr (M >= 16) lane_half_cleaner<4>(v);
+    if constexpr (M >= 8) lane_half_cleaner<2>(v);
+    if constexpr (M >= 4) lane_half_cleaner<1>(v);
+    reg_tail(v);
+}
+__device__ __forceinline__ void wave_sort512(unsigned long long (&v)[8]) {
+    reg_mirror<2>(v);
+    reg_mirror<4>(v);
+    reg_half_cleaner<1>(v);
+    reg_mirror<8>(v);
+    reg_half_cleaner<2>(v);
+    reg_half_cleaner<1>(v);
+    lane_stage<2>(v);
+    lane_stage<4>(v);
+    lane_stage<8>(v);
+    lane_stage<16>(v);
+    lane_stage<32>(v);
+    lane_stage<64>(v);
+}
+// the in-chunk part (distances 256 .. 1) of a merge stage k >= 1024
+__device__ __forceinline__ void wave_merge512(unsigned long long (&v)[8]) {
+    lane_half_cleaner<32>(v);
+    lane_half_cleaner<16>(v);
+    lane_half_cleaner<8>(v);
+    lane_half_cleaner<4>(v);
+    lane_half_cleaner<2>(v);
+    lane_half_cleaner<1>(v);
+    reg_tail(v);
+}
+__device__ __forceinline__ void chunk_load(const unsigned long long* s, int c, unsigned long long (&v)[8]) {
+    const ulonglong2* p = reinterpret_cast<const ulonglong2*>(s + c * 512 + lane_id() * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const ulonglong2 t = p[q];
+        v[2 * q] = t.x, v[2 * q + 1] = t.y;
+    }
+}
+__device__ __forceinline__ void chunk_store(unsigned long long* s, int c, const unsigned long long (&v)[8]) {
+    ulonglong2* p = reinterpret_cast<ulonglong2*>(s + c * 512 + lane_id() * 8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = make_ulonglong2(v[2 * q], v[2 * q + 1]);
+}
 
-// Bitonic sort of n_pow2 (>= 512, power of two) uint64 keys in LDS.  Every 512-chunk is sorted in registers by one wave;
-// of each merge stage k >= 1024 only the steps that cross chunks (j >= 512) go through LDS with block barriers, the
-// nine steps inside a chunk run in registers again.  8192 keys: 10 barrier steps instead of 91.
-__device__ __forceinline__ void block_bitonic_sort_u64_fast(unsigned long long* s, int n_pow2) {
-    const int nw = blockDim.x >> 6, w = wave_id(), lane = lane_id();
-    for (int c = w; c * 512 < n_pow2; c += nw) {
+// Ascending sort of s[0 .. n_pow2) in LDS (16-byte aligned, n_pow2 a power of two >= 512) by the whole block.  Entries at
+// index >= n_live must hold the maximum key (~0): they are never touched, so the work follows n_live, not n_pow2.
+// 512-chunks are sorted in registers; of each merge stage only the steps that cross chunks go through LDS with barriers.
+__device__ __forceinline__ void block_sort_u64(unsigned long long* s, int n_pow2, int n_live) {
+    const int nw = blockDim.x >> 6, w = wave_id();
+    const int nc = (n_live + 511) >> 9;  // chunks holding live keys
+    for (int c = w; c < nc; c += nw) {
         unsigned long long v[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = s[c * 512 + r * 64 + lane];
-        wave_bitonic_sort512(v, c * 512);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) s[c * 512 + r * 64 + lane] = v[r];
+        chunk_load(s, c, v);
+        wave_sort512(v);
+        chunk_store(s, c, v);
     }
     __syncthreads();
     const int half = n_pow2 >> 1;
     for (int k = 1024; k <= n_pow2; k <<= 1) {
-        for (int j = k >> 1; j >= 512; j >>= 1) {
+        if ((k >> 1) >= n_live) break;  // only padding beyond the first half: already sorted
+        // mirror step: o-th element of a k-block's lower half against the o-th from the block's end
+        for (int t = threadIdx.x; t < half; t += blockDim.x) {
+            const int blk = t / (k >> 1), o = t - blk * (k >> 1);
+            const int i = blk * k + o, p = blk * k + k - 1 - o;
+            if (p < n_live) {
+                const unsigned long long a = s[i], b = s[p];
+                if (a > b) s[i] = b, s[p] = a;
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j >= 512; j >>= 1) {
             for (int t = threadIdx.x; t < half; t += blockDim.x) {
                 const int i = 2 * t - (t & (j - 1));
-                const int ixj = i + j;
-                const bool up = (i & k) == 0;
-                const unsigned long long a = s[i], b = s[ixj];
-                if ((a > b) == up) {
-                    s[i] = b;
-                    s[ixj] = a;
+                const int p = i + j;
+                if (p < n_live) {
+                    const unsigned long long a = s[i], b = s[p];
+                    if (a > b) s[i] = b, s[p] = a;
                 }
             }
             __syncthreads();
         }
-        for (int c = w; c * 512 < n_pow2; c += nw) {
+        for (int c = w; c < nc; c += nw) {
             unsigned long long v[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = s[c * 512 + r * 64 + lane];
-            wave_bitonic_merge512(v, c * 512, k);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) s[c * 512 + r * 64 + lane] = v[r];
+            chunk_load(s, c, v);
+            wave_merge512(v);
+            chunk_store(s, c, v);
         }
         __syncthreads();
     }

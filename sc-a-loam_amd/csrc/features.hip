@@ -444,12 +444,11 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
             bool tie = false;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const int t = r * 64 + lane;
+                const int t = lane * 8 + r;
                 v[r] = t < L ? ((static_cast<unsigned long long>(__float_as_uint(curv[sp + t])) << 32) | static_cast<unsigned>(sp + t - rs)) : ~0ull;
             }
-            wave_bitonic_sort512(v, 0);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) keys[wv * 512 + r * 64 + lane] = v[r];
+            wave_sort512(v);
+            chunk_store(keys, wv, v);
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
             for (int t = lane; t + 1 < L; t += 64) tie |= (keys[wv * 512 + t] >> 32) == (keys[wv * 512 + t + 1] >> 32);
@@ -463,14 +462,14 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
         const int L = seg_L[j];
         unsigned long long* skeys = keys + (fast ? j * 512 : 0);
         if (!fast) {
-            const int Lp = max(2, next_pow2(L));
+            const int Lp = max(512, next_pow2(L));
             for (int t = tid; t < Lp; t += blockDim.x) {
                 unsigned long long k = ~0ull;
                 if (t < L) k = (static_cast<unsigned long long>(__float_as_uint(curv[sp + t])) << 32) | static_cast<unsigned>(sp + t - rs);
                 keys[t] = k;  // curvature >= 0, so its bit pattern orders like the float; ties fall back to the index
             }
             __syncthreads();
-            block_bitonic_sort_u64(keys, Lp);
+            block_sort_u64(keys, Lp, L);
             bool tie = false;
             for (int t = tid; t + 1 < L; t += blockDim.x) tie |= (keys[t] >> 32) == (keys[t + 1] >> 32);
             if (__syncthreads_or(tie) && tid == 0) atomicAdd(&P->n_tied, 1);
@@ -539,7 +538,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
     if (r == 32 && tid == 0) SCAL_STAMP(3);
     const int mb0 = s_misc[0], mb1 = s_misc[1], mb2 = s_misc[2];
     const bool guard = s_misc[3] != 0;
-    const int Mp = max(2, next_pow2(m));
+    const int Mp = max(512, next_pow2(m));
     for (int t = tid; t < Mp; t += blockDim.x) keys[t] = ~0ull;
     __syncthreads();
     {
@@ -563,10 +562,7 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
     }
     __syncthreads();
     if (r == 32 && tid == 0) SCAL_STAMP(4);
-    if (Mp >= 512)
-        block_bitonic_sort_u64_fast(keys, Mp);
-    else
-        block_bitonic_sort_u64(keys, Mp);
+    block_sort_u64(keys, Mp, m);
     if (r == 32 && tid == 0) SCAL_STAMP(5);
     // heads of voxel runs -> output slots
     const int per2 = (m + blockDim.x - 1) / blockDim.x;

@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
     }
     int n_eff = 0;
     block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
-    block_bitonic_sort_u64_fast(sk, np2);
+    block_sort_u64(sk, np2, n_new);
     // heads + lookups; element t = e * 1024 + tid, so the eight binary searches of a thread advance in lock step
     constexpr int PER = MERGE_MAX / 1024;
     unsigned long long key[PER];

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     __syncthreads();
     const bool guard = s_mb[3] != 0;
     if (tid == 0) SCAL_STAMP(1);
-    const int np2 = max(2, next_pow2(n));
+    const int np2 = max(512, next_pow2(n));
     for (int i = tid; i < np2; i += blockDim.x) {
         unsigned long long k = ~0ull;
         if (i < n) {
@@ -235,10 +235,7 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     }
     __syncthreads();
     if (tid == 0) SCAL_STAMP(2);
-    if (np2 >= 512)
-        block_bitonic_sort_u64_fast(skeys, np2);
-    else
-        block_bitonic_sort_u64(skeys, np2);
+    block_sort_u64(skeys, np2, n);
     if (tid == 0) SCAL_STAMP(3);
     // every thread owns 8 consecutive sorted positions; their points are gathered up front (independent loads) so the
     // ordered f32 sums below run on registers; a run that continues past the thread's window finishes from memory
