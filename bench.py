@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
+    ap.add_argument("--no-overlap", action="store_true", help="keep ScanContext on the pipeline's stream (no stage D overlap)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
@@ -101,7 +102,7 @@ def main():
     od = S.LaserOdometry(max_points=cap, device=local)
     mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
     sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=a.sc_db // world + total * world + 64, device=local,
-                     n_shards=world, shard=rank)
+                     n_shards=world, shard=rank, side_stream=1 if (world == 1 and not a.no_overlap) else 0)
     rng = np.random.default_rng(4242)
     for d in synth_descs(rng, a.sc_db):
         sc.saveScancontextAndKeys(d.T)  # every shard sees every insert and keeps the ones it owns
@@ -116,10 +117,11 @@ def main():
 
     def step(k):
         reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
+        if world == 1:
+            sc.insert_features(reg)  # stage D only needs stage A: enqueued on the side stream, overlaps with B and C
         qlc, tlc, qw, tw, ost = od.step_features(reg)
         qm, tm, mst = mp.process_features(reg, qw, tw)
         if world == 1:
-            sc.insert_features(reg)
             r = sc.detectLoopClosureID()
         else:
             sc.make_features(reg, d_q.data_ptr())

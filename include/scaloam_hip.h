@@ -113,6 +113,9 @@ typedef struct {
     int device;
     /* sharding (multi-GPU): this context stores keyframes i with i % n_shards == shard; 1/0 = everything */
     int n_shards, shard;
+    /* 1: run this context on the device's side stream so that insert/detect overlap with stages B and C of the same scan;
+     * ordering against the features context (scal_sc_insert_features / scal_sc_make_features) is kept with events */
+    int side_stream;
 } scal_sc_config;
 
 typedef struct {

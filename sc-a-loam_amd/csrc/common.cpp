@@ -47,16 +47,16 @@ struct DevStream {
     hipStream_t s = nullptr;
     int refs = 0;
 };
-DevStream g_streams[64];
+DevStream g_streams[64][2];  // [device][lane]: lane 0 = the pipeline's in-order stream, lane 1 = side stream
 }  // namespace
 
-int acquire_stream(int device, hipStream_t* out) {
-    if (device < 0 || device >= 64) {
+int acquire_stream(int device, hipStream_t* out, int lane) {
+    if (device < 0 || device >= 64 || lane < 0 || lane > 1) {
         set_error("device ordinal %d out of range", device);
         return SCAL_E_ARG;
     }
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    DevStream& d = g_streams[device];
+    DevStream& d = g_streams[device][lane];
     if (!d.s) {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.s, hipStreamNonBlocking);
@@ -71,10 +71,10 @@ int acquire_stream(int device, hipStream_t* out) {
     return SCAL_OK;
 }
 
-void release_stream(int device) {
-    if (device < 0 || device >= 64) return;
+void release_stream(int device, int lane) {
+    if (device < 0 || device >= 64 || lane < 0 || lane > 1) return;
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    DevStream& d = g_streams[device];
+    DevStream& d = g_streams[device][lane];
     if (d.refs > 0 && --d.refs == 0 && d.s) {
         (void)hipSetDevice(device);
         (void)hipStreamSynchronize(d.s);

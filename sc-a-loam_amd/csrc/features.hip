@@ -670,6 +670,8 @@ using namespace scal;
 struct scal_features {
     scal_features_config cfg;
     hipStream_t stream = nullptr;
+    hipEvent_t reader_ev = nullptr;  // last read of this context's buffers by a consumer on another stream
+    bool reader_pending = false;
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
     DevBuf<signed char> d_ring;
@@ -704,6 +706,12 @@ FeatDeviceView features_view(scal_features* c) {
     v.device = c->cfg.device;
     v.n_scans = c->cfg.n_scans;
     return v;
+}
+int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
+    if (!c->reader_ev) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev, hipEventDisableTiming));
+    SCAL_HIP(hipEventRecord(c->reader_ev, consumer_stream));
+    c->reader_pending = true;
+    return SCAL_OK;
 }
 }  // namespace scal
 
@@ -775,6 +783,10 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
 extern "C" void scal_features_destroy(scal_features_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->reader_ev) {  // consumers on other streams must be done with the buffers
+        (void)hipEventSynchronize(c->reader_ev);
+        (void)hipEventDestroy(c->reader_ev);
+    }
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device);
@@ -791,6 +803,10 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     k.thres2 = thres * thres;
     const int nb = max(1, div_up(n, TILE));
     FeatParams* P = c->d_P.p;
+    if (c->reader_pending) {  // a consumer on another stream may still be reading the previous scan's outputs
+        SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev, 0));
+        c->reader_pending = false;
+    }
     hipLaunchKernelGGL(k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
     hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
     hipLaunchKernelGGL(k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);

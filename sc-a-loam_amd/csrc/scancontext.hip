@@ -478,7 +478,7 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->gcell.alloc(DESC));
     if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
     A(c->h_rec.alloc(4));
-    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->cfg.side_stream ? 1 : 0) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -495,7 +495,7 @@ extern "C" void scal_sc_destroy(scal_sc_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        release_stream(c->cfg.device);
+        release_stream(c->cfg.device, c->cfg.side_stream ? 1 : 0);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
@@ -622,11 +622,14 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
         SCAL_TRY(c->d_nds.alloc(2));
         c->vf_cap = v.cap;
     }
-    if (!c->ev) SCAL_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-    SCAL_HIP(hipEventRecord(c->ev, v.stream));
-    SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    if (v.stream != c->stream) {  // side stream: start after stage A of this scan
+        if (!c->ev) SCAL_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+        SCAL_HIP(hipEventRecord(c->ev, v.stream));
+        SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+    }
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
     SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
+    if (v.stream != c->stream) SCAL_TRY(features_note_reader(feat, c->stream));  // the filter was the last reader of feat's buffers
     *d_n = c->d_nds.p;
     *n_cap = v.cap;
     return SCAL_OK;

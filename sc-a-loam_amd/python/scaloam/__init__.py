@@ -40,7 +40,7 @@ class FeaturesOut(C.Structure):
 
 class SCConfig(C.Structure):
     _fields_ = [("max_radius", C.c_double), ("dist_thres", C.c_double), ("max_keyframes", C.c_int), ("float_math", C.c_int),
-                ("device", C.c_int), ("n_shards", C.c_int), ("shard", C.c_int)]
+                ("device", C.c_int), ("n_shards", C.c_int), ("shard", C.c_int), ("side_stream", C.c_int)]
 
 
 class SCResult(C.Structure):
@@ -284,8 +284,8 @@ class SCManager:
     """Mirror of the reference's SCManager public API (Scancontext.h:62-79, :107-108).  Descriptors cross this
     boundary as [ring, sector] numpy arrays; the C-ABI itself uses Eigen's column-major layout."""
 
-    def __init__(self, max_radius=80.0, dist_thres=0.2, max_keyframes=8192, float_math=0, device=0, n_shards=1, shard=0):
-        self.cfg = SCConfig(max_radius, dist_thres, max_keyframes, float_math, device, n_shards, shard)
+    def __init__(self, max_radius=80.0, dist_thres=0.2, max_keyframes=8192, float_math=0, device=0, n_shards=1, shard=0, side_stream=0):
+        self.cfg = SCConfig(max_radius, dist_thres, max_keyframes, float_math, device, n_shards, shard, side_stream)
         self.h = C.c_void_p()
         _check(lib().scal_sc_create(C.byref(self.cfg), C.byref(self.h)))
 

@@ -138,3 +138,35 @@ def test_sc_insert_features_matches_host_path(O, S, hdl64_stream):
     assert sc.size() == 44
     reg.close()
     sc.close()
+
+
+def test_sc_side_stream_overlap_is_ordered(O, S, hdl64_stream):
+    """ScanContext on the device's side stream (stage D overlapping stages B and C): the same records and detections as
+    the oracle while the features context is re-run back to back, i.e. the events keep reader and writer apart."""
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
+    od = S.LaserOdometry(max_points=200000)
+    sc = S.SCManager(dist_thres=0.4, side_stream=1)
+    osc = O.SCManager(dist_thres=0.4)
+    rng = np.random.default_rng(5)
+    for i in range(40):
+        d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+        sc.saveScancontextAndKeys(d)
+        osc.saveScancontextAndKeys(d)
+    for k in range(6):
+        reg.laserCloudHandler(hdl64_stream(k))
+        sc.insert_features(reg)   # side stream, no host synchronisation
+        od.step_features(reg)     # main stream work of the same scan
+        if k % 2 == 0:            # detect on some scans only: the next run_device must wait for the reader by itself
+            rg = sc.detectLoopClosureID()
+        f = O.features(hdl64_stream(k), O.HDL64, 5.0)
+        ds, _ = O.voxel_grid(f["cloud"], 0.4)
+        osc.makeAndSaveScancontextAndKeys(ds)
+        if k % 2 == 0:
+            ro = osc.detectLoopClosureID()
+            assert rg["loop_id"] == ro["loop_id"] and rg["nn_idx"] == ro["nn_idx"] and abs(rg["min_dist"] - ro["min_dist"]) <= 1e-12, k
+    for k in range(6):
+        dg, kg = sc.get(40 + k)
+        do, ko = osc.get(40 + k)
+        assert np.array_equal(dg, do) and np.array_equal(kg.view(np.uint32), ko.view(np.uint32)), k
+    for x in (reg, od, sc):
+        x.close()
