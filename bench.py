@@ -117,6 +117,8 @@ def main():
 
     def step(k):
         reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
+        if not a.no_overlap:
+            mp.prefetch_features(reg)  # stage C's input gather + stack downsample do not need the odometry pose: side stream
         if world == 1:
             sc.insert_features(reg)  # stage D only needs stage A: enqueued on the side stream, overlaps with B and C
         qlc, tlc, qw, tw, ost = od.step_features(reg)

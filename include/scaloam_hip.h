@@ -203,6 +203,9 @@ int scal_map_step(scal_map_t* ctx, const float* corner_last, int n_corner, const
 /* same, inputs taken from a features context on the same device (lessSharp / lessFlat / ordered cloud) */
 int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom,
                            double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
+/* Optional: start the pose-independent part of the next scal_map_step_features(ctx, feat, ...) - input gather and the stack
+ * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately. */
+int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
 /* current map points of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap content); returns count */
 int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
 int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);

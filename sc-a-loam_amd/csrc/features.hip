@@ -672,6 +672,8 @@ struct scal_features {
     hipStream_t stream = nullptr;
     hipEvent_t reader_ev = nullptr;  // last read of this context's buffers by a consumer on another stream
     bool reader_pending = false;
+    hipEvent_t done_ev = nullptr;    // end of the most recent run, recorded on demand
+    bool done_recorded = false;
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
     DevBuf<signed char> d_ring;
@@ -706,6 +708,16 @@ FeatDeviceView features_view(scal_features* c) {
     v.device = c->cfg.device;
     v.n_scans = c->cfg.n_scans;
     return v;
+}
+int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
+    if (consumer_stream == c->stream) return SCAL_OK;
+    if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
+    if (!c->done_recorded) {
+        SCAL_HIP(hipEventRecord(c->done_ev, c->stream));
+        c->done_recorded = true;
+    }
+    SCAL_HIP(hipStreamWaitEvent(consumer_stream, c->done_ev, 0));
+    return SCAL_OK;
 }
 int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
     if (!c->reader_ev) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev, hipEventDisableTiming));
@@ -787,6 +799,7 @@ extern "C" void scal_features_destroy(scal_features_t* c) {
         (void)hipEventSynchronize(c->reader_ev);
         (void)hipEventDestroy(c->reader_ev);
     }
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device);
@@ -807,6 +820,7 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
         SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev, 0));
         c->reader_pending = false;
     }
+    c->done_recorded = false;
     hipLaunchKernelGGL(k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
     hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
     hipLaunchKernelGGL(k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);

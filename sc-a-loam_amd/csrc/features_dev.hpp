@@ -33,5 +33,7 @@ FeatDeviceView features_view(scal_features* c);
 // A consumer that reads the view's buffers on ANOTHER stream calls this after enqueuing its last read: the next run of the
 // features context waits for it before overwriting the buffers.
 int features_note_reader(scal_features* c, hipStream_t consumer_stream);
+// makes consumer_stream wait for the most recent run of the features context (one event per run, shared by all consumers)
+int features_wait_done(scal_features* c, hipStream_t consumer_stream);
 
 }  // namespace scal

@@ -865,7 +865,9 @@ using namespace scal;
 struct scal_map {
     scal_map_config cfg;
     hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
+    hipStream_t side = nullptr;          // side stream for scal_map_prefetch_features (lazily acquired)
+    hipEvent_t ev = nullptr, ev_pre = nullptr;
+    scal_features_t* prefetched_from = nullptr;
     int scan_cap = 0, map_cap = 0, slot_cap = 0;
     // host-side pose state (laserMapping.cpp:110-120)
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};
@@ -972,7 +974,12 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device);
     }
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        release_stream(c->cfg.device, 1);
+    }
     if (c->ev) (void)hipEventDestroy(c->ev);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     delete c;
 }
 
@@ -992,9 +999,23 @@ void h_rot(const double* q, const double* v, double* o) {
     o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
 }
 
+// stack downsample (:543-551) of corner_in / surf_in into corner_stack / surf_stack; independent of the pose
+static int enqueue_stack_filters(scal_map* c, hipStream_t s, int n_corner_bound, int n_surf_bound) {
+    MapCounters* C = c->d_C.p;
+    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack.v(), &C->n_corner_stack));
+    if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
+        // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
+        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
+    }
+    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack.v(), &C->n_surf_stack));
+    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, c->vf.meta.p, C, c->slot_cap);
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
 // everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C
 int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full, int n_corner_bound,
-             int n_surf_bound, double* q_out,
+             int n_surf_bound, bool filters_done, double* q_out,
              double* t_out, scal_map_stats* stats) {
     hipStream_t s = c->stream;
     // transformAssociateToMap (:143-147)
@@ -1030,14 +1051,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     for (int i = 0; i < 7; ++i) c->h_x0.p[i] = x0[i];
     SCAL_HIP(hipMemcpyAsync(st->x, c->h_x0.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));  // LMState::x is the first member
 
-    // stack downsample (:543-551); 12 bits per axis: up to 4096 cells of the leaf size
-    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack.v(), &C->n_corner_stack));
-    if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
-        // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
-        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
-    }
-    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack.v(), &C->n_surf_stack));
-    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, c->vf.meta.p, C, c->slot_cap);
+    if (!filters_done) SCAL_TRY(enqueue_stack_filters(c, s, n_corner_bound, n_surf_bound));
 
     // cell grids over the valid cubes
     for (int k = 0; k < 2; ++k) {
@@ -1211,12 +1225,46 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     SCAL_TRY(up(corner_last, n_corner, c->corner_in));
     SCAL_TRY(up(surf_last, n_surf, c->surf_in));
     if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
-    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, c->full_in.cv(), c->d_nfull.p, n_corner, n_surf, q_w_curr, t_w_curr, stats));
+    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, c->full_in.cv(), c->d_nfull.p, n_corner, n_surf, false, q_w_curr, t_w_curr, stats));
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
         SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
         SCAL_HIP(hipStreamSynchronize(s));
     }
+    return SCAL_OK;
+}
+
+// laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
+// read in place by the registration transform
+static int enqueue_gather(scal_map* c, const FeatDeviceView& v, hipStream_t s, int ls_cap, int cap) {
+    const int nbc = std::max(1, div_up(ls_cap, 256));
+    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
+                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in.v(), c->surf_in.v(), c->d_C.p, c->scan_cap, nbc);
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) {
+    if (!c || !feat) {
+        set_error("scal_map_prefetch_features: null argument");
+        return SCAL_E_ARG;
+    }
+    FeatDeviceView v = features_view(feat);
+    if (v.device != c->cfg.device) {
+        set_error("features context lives on device %d, map context on %d", v.device, c->cfg.device);
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, 1));
+    if (!c->ev_pre) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
+    const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
+    const int cap = std::min(c->scan_cap, v.cap);
+    SCAL_TRY(features_wait_done(feat, c->side));
+    SCAL_TRY(enqueue_gather(c, v, c->side, ls_cap, cap));
+    SCAL_TRY(enqueue_stack_filters(c, c->side, ls_cap, cap));
+    SCAL_HIP(hipEventRecord(c->ev_pre, c->side));
+    SCAL_TRY(features_note_reader(feat, c->side));
+    c->prefetched_from = feat;
     return SCAL_OK;
 }
 
@@ -1233,18 +1281,17 @@ extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, cons
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    if (v.stream != s) {  // order after the feature extraction stream (contexts of one device share a stream by default)
-        SCAL_HIP(hipEventRecord(c->ev, v.stream));
-        SCAL_HIP(hipStreamWaitEvent(s, c->ev, 0));
-    }
-    // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
-    // read in place by the registration transform
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
-    const int nbc = std::max(1, div_up(ls_cap, 256));
-    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
-                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in.v(), c->surf_in.v(), c->d_C.p, c->scan_cap, nbc);
-    return run_step(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, q_w_curr, t_w_curr, stats);
+    const bool pre = c->prefetched_from == feat;
+    c->prefetched_from = nullptr;
+    if (pre) {
+        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre, 0));  // inputs gathered and downsampled on the side stream
+    } else {
+        SCAL_TRY(features_wait_done(feat, s));
+        SCAL_TRY(enqueue_gather(c, v, s, ls_cap, cap));
+    }
+    return run_step(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, pre, q_w_curr, t_w_curr, stats);
 }
 
 extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int cap) {

@@ -622,11 +622,7 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
         SCAL_TRY(c->d_nds.alloc(2));
         c->vf_cap = v.cap;
     }
-    if (v.stream != c->stream) {  // side stream: start after stage A of this scan
-        if (!c->ev) SCAL_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
-        SCAL_HIP(hipEventRecord(c->ev, v.stream));
-        SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
-    }
+    SCAL_TRY(features_wait_done(feat, c->stream));  // side stream: start after stage A of this scan
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
     SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
     if (v.stream != c->stream) SCAL_TRY(features_note_reader(feat, c->stream));  // the filter was the last reader of feat's buffers

@@ -83,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features",
     "scal_factors_eval",
 ]
@@ -143,6 +143,7 @@ def lib():
     L.scal_map_export.argtypes = [vp, C.c_int, _f32p, C.c_int]
     L.scal_map_get_wmap_wodom.argtypes = [vp, _f64p, _f64p]
     L.scal_map_set_merge_insert.argtypes = [vp, C.c_int]
+    L.scal_map_prefetch_features.argtypes = [vp, vp]
     L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
     L.scal_odom_destroy.argtypes = [vp]
     L.scal_odom_destroy.restype = None
@@ -415,6 +416,9 @@ class LaserMapping:
         out = np.zeros((max(n, 1), 4), np.float32)
         m = lib().scal_map_export(self.h, which, _p(out, _f32p), n)
         return out[:m]
+
+    def prefetch_features(self, feat):
+        _check(lib().scal_map_prefetch_features(self.h, feat.h))
 
     def set_merge_insert(self, enable):
         _check(lib().scal_map_set_merge_insert(self.h, 1 if enable else 0))

@@ -88,6 +88,8 @@ def test_device_resident_pipeline(O, S, hdl64_stream):
     for k in range(6):
         xyz = hdl64_stream(k)
         f = reg.laserCloudHandler(xyz)  # leaves the device-resident results in the context too
+        if k % 2 == 1:
+            mp_dev.prefetch_features(reg)  # pose-independent part of stage C on the side stream, overlapping stage B
         qlc, tlc, qw, tw, st = od_dev.step_features(reg)
         qm, tm, sm = mp_dev.process_features(reg, qw, tw)
         c = f["cloud"]
