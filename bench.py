@@ -226,7 +226,7 @@ def roofline_of(prof, K, c):
         # one radix pass moves every (key, value) pair once: 12 B read + 12 B written; mean pair count over the sorts of a scan
         "k_rs_scatter": 24.0 * (3 * c["n_kept"] + 3 * c["n_less_flat"] + 4 * (c["map_pts"] + M)) / 10.0,
         # one evaluation reads every residual block once (72 B edge / 56 B plane-norm parameters + 8 B kind/valid)
-        "k_lm_iter": 80.0 * M,
+        "k_lm_solve": 80.0 * M * 5.0,  # up to five evaluations (initial point + <=4 candidates) per launch
         # association: each stack point (16 B) and its 5 neighbours (5 x 16 B); fit: 5 neighbours in, one block out
         "k_assoc_knn": 16.0 * M * 6.0,
         "k_assoc_fit": 16.0 * M * 5.0 + 64.0 * c["blocks"],

@@ -2,17 +2,17 @@
 // laserMapping.cpp:566-573, :713-721): residual blocks of lidarFactor.hpp:12-138 over q (4, Eigen quaternion
 // parameterisation) and t (3), HuberLoss(0.1), DENSE_QR, max_num_iterations 4, Ceres defaults otherwise.
 //
-// What runs where:
-//   k_lm_eval   one thread per residual block: residual, analytic Jacobian of the un-normalised Eigen rotation
+// What runs where (k_lm_solve, one launch per solve):
+//   evaluation  one thread per residual block: residual, analytic Jacobian of the un-normalised Eigen rotation
 //               (equal to Ceres' autodiff up to rounding), projection through the 4x3
-//               plus-Jacobian, Huber weight per block; block-reduced to 28 doubles (cost, g[6], upper H[21])
-//               with wave shuffles and a fixed-order LDS stage => bitwise run-to-run reproducible, no float atomics.
-//   k_lm_step   one wave: sums the per-block partials in a fixed order and advances Ceres' trust-region state
-//               machine (Jacobi scaling fixed at iteration 0, D = sqrt(clamp(diag)/radius), step acceptance,
-//               parameter/function/gradient tolerances, radius update).  The damped 6x6 system is solved by
+//               plus-Jacobian, Huber weight per block; reduced per workgroup to LM_NACC doubles (cost, g[6], upper
+//               H[21], live edge / plane blocks) through a fixed-order LDS stage => bitwise run-to-run reproducible,
+//               no float atomics.
+//   step        after a grid barrier every workgroup sums the partials in workgroup order and advances Ceres'
+//               trust-region state machine (Jacobi scaling fixed at iteration 0, D = sqrt(clamp(diag)/radius), step
+//               acceptance, parameter/function/gradient tolerances, radius update).  The damped 6x6 system is solved by
 //               Cholesky on the normal equations, which is algebraically what Ceres' DENSE_QR on [J; D] solves.
-// The whole <=4-iteration solve is a fixed chain eval,step,(eval,step)x4 on one stream: every data-dependent
-// decision stays on the GPU, finished solves turn the remaining kernels into no-ops.
+// Every data-dependent decision stays on the GPU; the host reads the final state once per stage.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_utils.hpp"
@@ -39,7 +39,6 @@ struct LMState {
     int iteration, done, successful, started, enabled;
     int termination;  // 0 max iterations, 1 gradient, 2 parameter, 3 function, 4 no residual blocks
     double cost_init, cost_final;
-    int ticket;  // arrival counter of k_lm_iter
     int log_iters[2], log_success[2];  // per outer iteration, for the caller's statistics
     int log_n_edge[2], log_n_plane[2];
     double log_cost_init[2], log_cost_final[2];
@@ -215,7 +214,8 @@ __device__ __forceinline__ int hidx(int a, int b) {  // index into upper-triangu
 
 // solve (Hs + diag(d2)) y = gs by Cholesky; returns false when not positive definite / not finite
 __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, const double* gs, double* y) {
-    double L[6][6];
+    // one division per pivot: every other division by a diagonal entry is a multiplication by its reciprocal
+    double L[6][6], inv[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -226,8 +226,9 @@ __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, 
             if (i == j) {
                 if (!(s > 0.0)) return false;
                 L[i][i] = sqrt(s);
+                inv[i] = 1.0 / L[i][i];
             } else {
-                L[i][j] = s / L[j][j];
+                L[i][j] = s * inv[j];
             }
         }
     double z[6];
@@ -236,14 +237,14 @@ __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, 
         double s = gs[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i][k] * z[k];
-        z[i] = s / L[i][i];
+        z[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = z[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k][i] * y[k];
-        y[i] = s / L[i][i];
+        y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -267,8 +268,9 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 #pragma unroll
             for (int b = a; b < 6; ++b) Hs[hidx(a, b)] = st->H[hidx(a, b)] * st->scale[a] * st->scale[b];
         }
+        const double inv_radius = 1.0 / st->radius;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) d2[a] = fmin(fmax(Hs[hidx(a, a)], 1e-6), 1e32) / st->radius;
+        for (int a = 0; a < 6; ++a) d2[a] = fmin(fmax(Hs[hidx(a, a)], 1e-6), 1e32) * inv_radius;
         double y[6];
         bool ok = chol_solve6(Hs, d2, gs, y);
         double mcc = 0.0;
@@ -302,7 +304,6 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 
 // Trust-region bookkeeping after one evaluation (TrustRegionMinimizer: IterationZero / candidate evaluation).
 __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phase) {
-    st->ticket = 0;
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
     auto grad_max_norm = [&]() {
         double neg[6], proj[7], m = 0.0;
@@ -379,112 +380,155 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
     lm_compute_candidate(st);
 }
 
-// One LM round per launch: every block evaluates its share of the residual blocks at the current point (phase 0: the
-// accepted point, phase 1: the candidate) and publishes 28 partial sums; the LAST block to arrive (agent-scope release on
-// the producers, ticket atomic, agent-scope acquire on the consumer: cdna_hip_programming.md Guideline 16) sums the
-// partials in block order (bitwise reproducible) and advances Ceres' trust-region state machine.  No block ever waits,
-// so there is nothing to deadlock; a finished solve turns the remaining launches into no-ops.
-static __global__ void __launch_bounds__(256) k_lm_iter(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int phase, int outer,
-                                                        const int* __restrict__ d_enable, double* partials) {
+// The whole <= 4-iteration solve in ONE launch.  A small grid (<= LM_GRID workgroups, all resident at once on 256 CUs)
+// walks the rounds together: every workgroup evaluates its tiles of residual blocks at the current point (round 0: the
+// accepted point, later: the candidate), publishes LM_NACC partial sums, meets the others at a grid barrier, then sums ALL
+// partials in block order and advances Ceres' trust-region state machine on its own private copy of the state.  Same
+// inputs, same instruction sequence: the copies stay bitwise identical, so every workgroup takes the same decisions
+// (including when to stop) without a second exchange.  Workgroup 0 writes the state back.
+//
+// Grid barrier: arrivals are counted in a word that only grows; a round's target is epoch + G * (round + 1), with the
+// epoch read from memory at kernel start and advanced by workgroup 0 after the last round (when every workgroup has long
+// read it).  Partials are double buffered by round parity: a workgroup can be at most one round ahead of the slowest one.
+// Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
+// sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
+constexpr int LM_GRID = 32;
+struct LMSync {
+    unsigned arrivals;  // grows forever (wrap-around safe comparisons)
+    unsigned epoch;     // arrivals consumed by all earlier solves
+};
+
+static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
+                                                         const int* __restrict__ d_enable, double* partials, LMSync* sync) {
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
-    __shared__ int s_last;
+    __shared__ LMState L;
+    __shared__ int s_ok;
+    const int G = gridDim.x;
     const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
-    const int nb = max(1, (n + 255) / 256);
-    if (static_cast<int>(blockIdx.x) >= nb) return;
     const int tid = threadIdx.x;
-    int enabled, done;
-    if (phase == 0) {  // (re)arm: the state of the previous solve is stale, only x carries over
-        enabled = d_enable ? *d_enable : 1;
-        done = 0;
-    } else {
-        enabled = st->enabled, done = st->done;
-    }
-    if (!enabled || done) {
-        if (phase == 0 && blockIdx.x == 0 && tid == 0) {
-            st->enabled = enabled, st->done = 1, st->termination = 4, st->iteration = 0, st->successful = 0;
-            st->cost_init = 0, st->cost_final = 0, st->ticket = 0;
+    const int enabled = d_enable ? *d_enable : 1;
+    if (!enabled) {  // uniform over the grid: nobody reaches a barrier
+        if (blockIdx.x == 0 && tid == 0) {
+            st->enabled = 0, st->done = 1, st->termination = 4, st->iteration = 0, st->successful = 0;
+            st->cost_init = 0, st->cost_final = 0;
             st->log_iters[outer] = 0, st->log_success[outer] = 0, st->log_cost_init[outer] = 0, st->log_cost_final[outer] = 0;
             st->log_n_edge[outer] = 0, st->log_n_plane[outer] = 0;
         }
         return;
     }
-    const double* x = phase ? st->cand : st->x;
-    double xl[7];
+    const unsigned epoch = sync->epoch;
+    if (tid == 0) L = *st;  // only x carries over from the previous solve; lm_tail(phase 0) re-arms the rest
+    __syncthreads();
+    int rounds = 0;
+    for (int round = 0; round < 5; ++round) {
+        const int phase = round ? 1 : 0;
+        if (phase && L.done) break;  // identical in every workgroup
+        rounds = round + 1;
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 0);
+        double xl[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) xl[k] = x[k];
-    double acc[LM_NACC];
+        for (int k = 0; k < 7; ++k) xl[k] = phase ? L.cand[k] : L.x[k];
+        double acc[LM_NACC];
 #pragma unroll
-    for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
-    const int i = blockIdx.x * 256 + tid;
-    if (i < n && f.valid[i]) {
-        const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
-        const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
-        const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
-        factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
-        acc[28] += f.kind[i] == 0 ? 1.0 : 0.0;  // live residual blocks are counted here: no contended atomics in the
-        acc[29] += f.kind[i] == 0 ? 0.0 : 1.0;  // association kernels
-    }
-    // wave reduction through LDS: 28 conflict-free stores per lane, then lane k sums row k in lane order (fixed order =>
-    // reproducible).  Six dependent cross-lane shuffle steps for each of 28 doubles were the slow part of this kernel.
-    {
-        const int w = wave_id(), l = lane_id();
-#pragma unroll
-        for (int k = 0; k < LM_NACC; ++k) xch[w][k][l] = acc[k];
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        if (l < LM_NACC) {
-            double sum = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < 64; ++j) sum += xch[w][l][j];
-            red[w][l] = sum;
+        for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
+        for (int i = blockIdx.x * 256 + tid; i < n; i += G * 256) {
+            if (f.valid[i]) {
+                const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
+                const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
+                const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
+                factor_accumulate(f.kind[i], cp, pa, pb, xl, acc);
+                acc[28] += f.kind[i] == 0 ? 1.0 : 0.0;  // live residual blocks are counted here: no contended atomics in the
+                acc[29] += f.kind[i] == 0 ? 0.0 : 1.0;  // association kernels
+            }
         }
-    }
-    __syncthreads();
-    // Hand-off without L2 write-back / invalidate fences (MI355X_MICROARCH.md "Valid forms"): EVERY store of the partials is
-    // a write-through (sc0 sc1) store, drained with vmcnt(0) before the block's ticket; EVERY load of them is an sc1 load.
-    if (tid < LM_NACC)
-        __hip_atomic_store(&partials[blockIdx.x * LM_NACC + tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&st->ticket, 1) == nb - 1;
-    __syncthreads();
-    if (!s_last) return;
-    {   // sum the per-block partials: 8 groups of blocks in parallel (independent sc1 loads), combined in a fixed order
-        double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
-        const int k = tid & 31, g = tid >> 5;
-        if (k < LM_NACC) {
-            double sacc = 0.0;
-            for (int b = g; b < nb; b += 8) sacc += __hip_atomic_load(&partials[b * LM_NACC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gsum[0][k][g] = sacc;
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 1);
+        // wave reduction through LDS: conflict-free stores per lane, then lane k sums row k in lane order (fixed order =>
+        // reproducible).  Six dependent cross-lane shuffle steps for each of the doubles would be the slow part otherwise.
+        {
+            const int w = wave_id(), l = lane_id();
+#pragma unroll
+            for (int k = 0; k < LM_NACC; ++k) xch[w][k][l] = acc[k];
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (l < LM_NACC) {
+                double sum = 0.0;
+#pragma unroll 8
+                for (int j = 0; j < 64; ++j) sum += xch[w][l][j];
+                red[w][l] = sum;
+            }
         }
         __syncthreads();
-        if (tid < LM_NACC) {
-            double t8 = 0.0;
-#pragma unroll
-            for (int gg = 0; gg < 8; ++gg) t8 += gsum[0][tid][gg];
-            tot[tid] = t8;
+        double* mine = partials + (static_cast<size_t>(round & 1) * LM_GRID + blockIdx.x) * LM_NACC;
+        if (tid < LM_NACC)
+            __hip_atomic_store(&mine[tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 2);
+        if (tid == 0) {  // grid barrier
+            __hip_atomic_fetch_add(&sync->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // data already written through
+            const unsigned target = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(round + 1);
+            int ok = 0;
+            for (int poll = 0; poll < (1 << 22); ++poll) {
+                const unsigned cur = __hip_atomic_load(&sync->arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (static_cast<int>(cur - target) >= 0) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_ok = ok;
         }
+        __syncthreads();
+        if (!s_ok) {  // poll budget exhausted: give up (termination 5); the host reports it and resets the counters
+            if (tid == 0) L.done = 1, L.termination = 5;
+            __syncthreads();
+            break;
+        }
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 3);
+        {   // sum the per-workgroup partials: 8 groups of workgroups in parallel (independent sc1 loads), fixed order
+            double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
+            const double* all = partials + static_cast<size_t>(round & 1) * LM_GRID * LM_NACC;
+            const int k = tid & 31, g = tid >> 5;
+            if (k < LM_NACC) {
+                double sacc = 0.0;
+                for (int b = g; b < G; b += 8) sacc += __hip_atomic_load(&all[b * LM_NACC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gsum[0][k][g] = sacc;
+            }
+            __syncthreads();
+            if (tid < LM_NACC) {
+                double t8 = 0.0;
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) t8 += gsum[0][tid][gg];
+                tot[tid] = t8;
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 4);
+        if (tid == 0) {  // the serial tail runs on a register copy of the state
+            LMState R = L;
+            if (phase == 0) R.log_n_edge[outer] = static_cast<int>(tot[28]), R.log_n_plane[outer] = static_cast<int>(tot[29]);
+            lm_tail(&R, tot, phase);
+            L = R;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 5);
     }
-    __syncthreads();
-    if (tid != 0) return;
-    // the serial tail runs on a local copy of the state (one global read, one global write)
-    LMState L = *st;
-    if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
-    lm_tail(&L, tot, phase);
-    L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
-    L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
-    *st = L;
+    if (blockIdx.x == 0 && tid == 0) {
+        L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
+        L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
+        *st = L;
+        sync->epoch = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(rounds);
+    }
 }
 
-// host helper: the fixed chain of one solve (1 + 4 launches)
-inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, int outer) {
-    const int nb = (f.cap + 255) / 256 > 0 ? (f.cap + 255) / 256 : 1;
-    for (int phase = 0; phase < 5; ++phase) {
-        SCAL_LAUNCH_PROF("k_lm_iter", k_lm_iter, dim3(nb), dim3(256), 0, s, f, d_nslots, st, phase ? 1 : 0, outer, d_enable, partials);
-    }
+// host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
+inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
+                            int outer) {
+    int g = (f.cap + 255) / 256;
+    g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
+    SCAL_LAUNCH_PROF("k_lm_solve", k_lm_solve, dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync);
 }
 
 }  // namespace scal

@@ -858,6 +858,7 @@ struct GridStore {
     GridPts pts() { return GridPts{g.x.p, g.y.p, g.z.p, idx.p}; }
 };
 
+SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
 }  // namespace scal
 
 using namespace scal;
@@ -895,6 +896,7 @@ struct scal_map {
     }
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<LMSync> lm_sync;
     DevBuf<float> nnx, nny, nnz, nnd5;
     NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
@@ -947,7 +949,9 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
-    A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
+    A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
+    A(c->lm_sync.alloc(1));
+    if (rc == SCAL_OK && hipMemset(c->lm_sync.p, 0, sizeof(LMSync)) != hipSuccess) rc = SCAL_E_HIP;
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
     A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4)); A(c->h_x0.alloc(8));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
@@ -1076,7 +1080,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
                                C, outer, F);
         }
         {
-                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, outer);
+                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer);
         }
     }
     // restore the zero invariant of the cell counters
@@ -1154,6 +1158,11 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     if (H.error) {
         set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
         return H.error;
+    }
+    if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+        (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
+        set_error("LM solve abandoned: grid barrier timed out");
+        return SCAL_E_HIP;
     }
     const double* xf = c->h_st.p->x;
     for (int i = 0; i < 4; ++i) q_out[i] = xf[i];

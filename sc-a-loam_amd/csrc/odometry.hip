@@ -375,6 +375,7 @@ struct scal_odom {
     OSoA corner_last, surf_last;              // previous scan (kd-tree inputs, :567-568)
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
+    DevBuf<LMSync> lm_sync;
     DevBuf<unsigned long long> nn_part;
     int nch = 1;
     DevBuf<int> ring_tab;  // 2 sets of [corner first | corner last | surf first | surf last] x RING_TAB (double-buffered)
@@ -406,7 +407,9 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->less_flat.alloc(c->cap)); A(c->surf_last.alloc(c->cap));
     A(c->fvalid.alloc(c->slot_cap)); A(c->fkind.alloc(c->slot_cap));
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
-    A(c->partials.alloc((size_t)LM_NACC * (div_up(c->slot_cap, 256) + 1)));
+    A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
+    A(c->lm_sync.alloc(1));
+    if (rc == SCAL_OK && hipMemset(c->lm_sync.p, 0, sizeof(LMSync)) != hipSuccess) rc = SCAL_E_HIP;
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->ring_tab.alloc(8 * RING_TAB));
@@ -473,7 +476,7 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
             }
             {
-                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, outer);
+                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, c->lm_sync.p, outer);
             }
         }
     }
@@ -495,6 +498,11 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
+    if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+        (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
+        set_error("LM solve abandoned: grid barrier timed out");
+        return SCAL_E_HIP;
+    }
     const double* x = c->h_st.p->x;
     if (solve) {  // :504-505
         double r[3];
