@@ -117,14 +117,24 @@ def main():
 
     def step(k):
         reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
-        if not a.no_overlap:
-            mp.prefetch_features(reg)  # stage C's input gather + stack downsample do not need the odometry pose: side stream
-        if world == 1:
-            sc.insert_features(reg)  # stage D only needs stage A: enqueued on the side stream, overlaps with B and C
-        qlc, tlc, qw, tw, ost = od.step_features(reg)
+        if a.no_overlap:
+            qlc, tlc, qw, tw, ost = od.step_features(reg)
+        else:
+            # stage B is queued first (critical path), then everything that only needs stage A goes to the side stream while
+            # B runs: stage C's input gather + stack downsample, and stage D (insert + search) for single-GPU runs
+            od.enqueue_features(reg)
+            mp.prefetch_features(reg)
+            if world == 1:
+                sc.insert_features(reg)
+                sc.detect_enqueue()
+            qlc, tlc, qw, tw, ost = od.collect()
         qm, tm, mst = mp.process_features(reg, qw, tw)
         if world == 1:
-            r = sc.detectLoopClosureID()
+            if a.no_overlap:
+                sc.insert_features(reg)
+                r = sc.detectLoopClosureID()
+            else:
+                r = sc.detect_collect()
         else:
             sc.make_features(reg, d_q.data_ptr())
             all_gather(all_q, d_q)

@@ -153,6 +153,10 @@ int scal_sc_make_descriptor(scal_sc_t* ctx, const float* xyzi, int n, double* de
 /* detectLoopClosureID(): query = newest keyframe; reproduces the >=31 gate, the 30-query tree period,
  * the exclusion of the newest 30 keys and the 3-candidate / 7-shift search (Scancontext.cpp:336-427). */
 int scal_sc_detect(scal_sc_t* ctx, scal_sc_result* res);
+/* the same in two halves: enqueue launches the search for the newest keyframe and returns, collect waits for it.
+ * scal_sc_detect = enqueue + collect.  No other query may run on the context in between. */
+int scal_sc_detect_enqueue(scal_sc_t* ctx);
+int scal_sc_detect_collect(scal_sc_t* ctx, scal_sc_result* res);
 /* distanceBtnScanContext for descriptor pairs already in the database */
 int scal_sc_distance_pairs(scal_sc_t* ctx, const int* idx_a, const int* idx_b, int n_pairs, double* dist, int* shift);
 /* dense mode: all 60 shifts for queries [q0,q1) x database [d0,d1): min over shifts; mode 0 = the
@@ -231,6 +235,10 @@ int scal_odom_step(scal_odom_t* ctx, const float* sharp, int n_sharp, const floa
                    double* t_last_curr, double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
 int scal_odom_step_features(scal_odom_t* ctx, scal_features_t* feat, double* q_last_curr, double* t_last_curr,
                             double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
+/* the same in two halves (= enqueue + collect): the caller can queue other work while the step runs */
+int scal_odom_enqueue_features(scal_odom_t* ctx, scal_features_t* feat);
+int scal_odom_collect(scal_odom_t* ctx, double* q_last_curr, double* t_last_curr, double* q_w_curr, double* t_w_curr,
+                      scal_odom_stats* stats);
 
 /* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
  * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,

@@ -674,6 +674,7 @@ struct scal_features {
     bool reader_pending = false;
     hipEvent_t done_ev = nullptr;    // end of the most recent run, recorded on demand
     bool done_recorded = false;
+    bool cross_stream_consumers = false;  // seen once: record done_ev right behind every run, before later main-stream work
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
     DevBuf<signed char> d_ring;
@@ -712,6 +713,7 @@ FeatDeviceView features_view(scal_features* c) {
 int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     if (consumer_stream == c->stream) return SCAL_OK;
     if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
+    c->cross_stream_consumers = true;
     if (!c->done_recorded) {
         SCAL_HIP(hipEventRecord(c->done_ev, c->stream));
         c->done_recorded = true;
@@ -838,6 +840,10 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     hipLaunchKernelGGL(k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->f_sharp.p, c->f_less.p, c->f_flat.p);
     SCAL_HIP(hipGetLastError());
+    if (c->cross_stream_consumers) {  // the event must sit right behind stage A, not behind whatever the stream gets next
+        SCAL_HIP(hipEventRecord(c->done_ev, s));
+        c->done_recorded = true;
+    }
     c->ran = true;
     c->last_n = n;
     return SCAL_OK;

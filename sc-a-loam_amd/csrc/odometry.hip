@@ -369,6 +369,7 @@ struct scal_odom {
     hipEvent_t ev = nullptr;
     int cap = 0, feat_cap = 0, slot_cap = 0;
     bool systemInited = false;
+    bool pending = false, pending_solve = false;  // a step is enqueued and not collected yet
     double q_w_curr[4] = {0, 0, 0, 1}, t_w_curr[3] = {0, 0, 0};  // :93-94
     DevBuf<float> aos;
     OSoA sharp, flat, less_sharp, less_flat;  // current scan
@@ -458,7 +459,7 @@ void o_rot(const double* q, const double* v, double* o) {
 }
 
 // inputs already in sharp / flat / less_sharp / less_flat with counts in d_C
-int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w, scal_odom_stats* stats) {
+int odom_enqueue(scal_odom* c) {
     hipStream_t s = c->stream;
     OdomCounters* C = c->d_C.p;
     LMState* st = c->d_st.p;
@@ -497,7 +498,19 @@ int odom_run(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w,
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    c->pending = true, c->pending_solve = solve;
+    return SCAL_OK;
+}
+
+// waits for the enqueued step and integrates the pose on the host (:504-505)
+int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w, scal_odom_stats* stats) {
+    if (!c->pending) {
+        set_error("scal_odom_collect: no step enqueued");
+        return SCAL_E_STATE;
+    }
+    c->pending = false;
+    const bool solve = c->pending_solve;
+    SCAL_HIP(hipStreamSynchronize(c->stream));
     if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
         (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
         set_error("LM solve abandoned: grid barrier timed out");
@@ -566,14 +579,18 @@ extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, c
     SCAL_TRY(up(flat, n_flat, c->flat));
     SCAL_TRY(up(less_sharp, n_less_sharp, c->less_sharp));
     SCAL_TRY(up(less_flat, n_less_flat, c->less_flat));
-    return odom_run(c, q_lc, t_lc, q_w, t_w, stats);
+    SCAL_TRY(odom_enqueue(c));
+    return odom_collect(c, q_lc, t_lc, q_w, t_w, stats);
 }
 
-extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, double* q_lc, double* t_lc, double* q_w, double* t_w,
-                                       scal_odom_stats* stats) {
-    if (!c || !feat || !q_lc || !t_lc || !q_w || !t_w) {
-        set_error("scal_odom_step_features: null argument");
+extern "C" int scal_odom_enqueue_features(scal_odom_t* c, scal_features_t* feat) {
+    if (!c || !feat) {
+        set_error("scal_odom_enqueue_features: null argument");
         return SCAL_E_ARG;
+    }
+    if (c->pending) {
+        set_error("scal_odom_enqueue_features: the previous step has not been collected");
+        return SCAL_E_STATE;
     }
     FeatDeviceView v = features_view(feat);
     if (v.device != c->cfg.device) {
@@ -590,5 +607,24 @@ extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, do
     a.slot_cap = c->slot_cap, a.feat_cap = c->feat_cap, a.cap = std::min(c->cap, v.cap);
     a.nbs = std::max(1, div_up(c->slot_cap, 256)), a.nbf = std::max(1, div_up(c->feat_cap, 256));
     hipLaunchKernelGGL(k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
-    return odom_run(c, q_lc, t_lc, q_w, t_w, stats);
+    return odom_enqueue(c);
+}
+
+extern "C" int scal_odom_collect(scal_odom_t* c, double* q_lc, double* t_lc, double* q_w, double* t_w, scal_odom_stats* stats) {
+    if (!c || !q_lc || !t_lc || !q_w || !t_w) {
+        set_error("scal_odom_collect: null argument");
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    return odom_collect(c, q_lc, t_lc, q_w, t_w, stats);
+}
+
+extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, double* q_lc, double* t_lc, double* q_w, double* t_w,
+                                       scal_odom_stats* stats) {
+    if (!c || !feat || !q_lc || !t_lc || !q_w || !t_w) {
+        set_error("scal_odom_step_features: null argument");
+        return SCAL_E_ARG;
+    }
+    SCAL_TRY(scal_odom_enqueue_features(c, feat));
+    return odom_collect(c, q_lc, t_lc, q_w, t_w, stats);
 }

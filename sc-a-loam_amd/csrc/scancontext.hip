@@ -444,6 +444,7 @@ struct scal_sc {
     DevBuf<int> d_nds;
     int vf_cap = 0;
     hipEvent_t ev = nullptr;
+    int detect_pending = 0;  // 1: search launched, 2: database too small (nothing launched)
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
     SCSlot staging() const { return SCSlot{qdesc.p, qrkey.p, qskey.p, qnorm.p}; }
     SCSlot slot(size_t sl) const { return SCSlot{desc.p + sl * DESC, rkey.p + sl * NR, skey.p + sl * NS, cnorm.p + sl * NS}; }
@@ -713,7 +714,7 @@ extern "C" int scal_sc_get_descriptor(scal_sc_t* c, int idx, double* desc, float
 }
 
 // ring-key top-3 over global indices < limit on this shard + SC distance of the three; records -> h_rec[0..2]
-static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q) {
+static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q, bool wait = true) {
     hipStream_t s = c->stream;
     const int nb = std::max(1, div_up(c->n_local, 256));
     hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
@@ -722,7 +723,7 @@ static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q) {
                        q.cnorm, fill_zero ? 1 : 0, c->d_rec.p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_rec.p, c->d_rec.p, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    if (wait) SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
 }
 
@@ -750,6 +751,62 @@ static void finish_result(const SCRec* rec, int n, double thres, scal_sc_result*
     res->yaw_rad = static_cast<float>(deg * M_PI / 180.0);
 }
 
+// detectLoopClosureID (:335-427) in two halves so that the search can run behind other work: enqueue launches the ring-key
+// search + candidate distances for the newest keyframe, collect waits and applies the threshold.
+static int detect_enqueue(scal_sc* c) {
+    if (c->cfg.n_shards > 1) {
+        set_error("scal_sc_detect needs the whole database on one context; use scal_sc_shard_query + scal_sc_merge_candidates");
+        return SCAL_E_STATE;
+    }
+    if (c->detect_pending) {
+        set_error("scal_sc_detect_enqueue: the previous detection has not been collected");
+        return SCAL_E_STATE;
+    }
+    const int NUM_EXCLUDE_RECENT = 30, TREE_MAKING_PERIOD_ = 30;
+    c->detect_pending = 1;
+    if (c->n_global < NUM_EXCLUDE_RECENT + 1) {  // :346-350
+        c->detect_pending = 2;  // nothing launched
+        return SCAL_OK;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (c->tree_making_period_conter % TREE_MAKING_PERIOD_ == 0) c->size_at_rebuild = c->n_global;  // :353-364
+    c->tree_making_period_conter++;
+    // query = newest keyframe (:340-341), read in place from its database slot
+    return search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1), false);
+}
+static int detect_collect(scal_sc* c, scal_sc_result* res) {
+    std::memset(res, 0, sizeof *res);
+    res->loop_id = -1;
+    res->min_dist = 10000000;
+    if (!c->detect_pending) {
+        set_error("scal_sc_detect_collect: no detection enqueued");
+        return SCAL_E_STATE;
+    }
+    const int mode = c->detect_pending;
+    c->detect_pending = 0;
+    if (mode == 2) return SCAL_OK;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    finish_result(c->h_rec.p, 3, c->cfg.dist_thres, res);
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_detect_enqueue(scal_sc_t* c) {
+    if (!c) {
+        set_error("scal_sc_detect_enqueue: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    return detect_enqueue(c);
+}
+extern "C" int scal_sc_detect_collect(scal_sc_t* c, scal_sc_result* res) {
+    if (!c || !res) {
+        set_error("scal_sc_detect_collect: null argument");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    return detect_collect(c, res);
+}
 extern "C" int scal_sc_detect(scal_sc_t* c, scal_sc_result* res) {
     if (!c || !res) {
         set_error("scal_sc_detect: null argument");
@@ -759,19 +816,8 @@ extern "C" int scal_sc_detect(scal_sc_t* c, scal_sc_result* res) {
     std::memset(res, 0, sizeof *res);
     res->loop_id = -1;
     res->min_dist = 10000000;
-    if (c->cfg.n_shards > 1) {
-        set_error("scal_sc_detect needs the whole database on one context; use scal_sc_shard_query + scal_sc_merge_candidates");
-        return SCAL_E_STATE;
-    }
-    const int NUM_EXCLUDE_RECENT = 30, TREE_MAKING_PERIOD_ = 30;
-    if (c->n_global < NUM_EXCLUDE_RECENT + 1) return SCAL_OK;  // :346-350
-    SCAL_HIP(hipSetDevice(c->cfg.device));
-    if (c->tree_making_period_conter % TREE_MAKING_PERIOD_ == 0) c->size_at_rebuild = c->n_global;  // :353-364
-    c->tree_making_period_conter++;
-    // query = newest keyframe (:340-341), read in place from its database slot
-    SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1)));
-    finish_result(c->h_rec.p, 3, c->cfg.dist_thres, res);
-    return SCAL_OK;
+    SCAL_TRY(detect_enqueue(c));
+    return detect_collect(c, res);
 }
 
 extern "C" int scal_sc_shard_query(scal_sc_t* c, const double* query_desc, int global_size_at_rebuild, scal_sc_cand out[3]) {

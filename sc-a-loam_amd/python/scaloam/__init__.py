@@ -80,11 +80,11 @@ EXPORTED_SYMBOLS = [
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
-    "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_distance_pairs",
+    "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features",
-    "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features",
+    "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
 
@@ -123,6 +123,8 @@ def lib():
     L.scal_sc_get_descriptor.argtypes = [vp, C.c_int, _f64p, _f32p]
     L.scal_sc_make_descriptor.argtypes = [vp, _f32p, C.c_int, _f64p]
     L.scal_sc_detect.argtypes = [vp, C.POINTER(SCResult)]
+    L.scal_sc_detect_enqueue.argtypes = [vp]
+    L.scal_sc_detect_collect.argtypes = [vp, C.POINTER(SCResult)]
     L.scal_sc_distance_pairs.argtypes = [vp, _i32p, _i32p, C.c_int, _f64p, _i32p]
     L.scal_sc_distance_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _i32p]
     L.scal_sc_shard_query.argtypes = [vp, _f64p, C.c_int, C.POINTER(SCCand)]
@@ -150,6 +152,8 @@ def lib():
     L.scal_odom_step.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p, _f64p,
                                  C.POINTER(OdomStats)]
     L.scal_odom_step_features.argtypes = [vp, vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(OdomStats)]
+    L.scal_odom_enqueue_features.argtypes = [vp, vp]
+    L.scal_odom_collect.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(OdomStats)]
     L.scal_factors_eval.argtypes = [C.c_int, C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
     _lib = L
     return L
@@ -333,9 +337,21 @@ class SCManager:
     def shard_query_device(self, d_queries_ptr, nq, global_size_at_rebuild, d_out_ptr):
         _check(lib().scal_sc_shard_query_device(self.h, d_queries_ptr, nq, global_size_at_rebuild, d_out_ptr))
 
+    def detect_enqueue(self):
+        _check(lib().scal_sc_detect_enqueue(self.h))
+
+    def detect_collect(self):
+        r = SCResult()
+        _check(lib().scal_sc_detect_collect(self.h, C.byref(r)))
+        return self._result(r)
+
     def detectLoopClosureID(self):
         r = SCResult()
         _check(lib().scal_sc_detect(self.h, C.byref(r)))
+        return self._result(r)
+
+    @staticmethod
+    def _result(r):
         return dict(loop_id=r.loop_id, yaw=r.yaw_rad, min_dist=r.min_dist, nn_idx=r.nn_idx, nn_shift=r.nn_shift,
                     cand=np.array(r.cand_idx[:]), cand_d=np.array(r.cand_keydist[:], np.float32), cand_sc=np.array(r.cand_scdist[:]),
                     cand_shift=np.array(r.cand_shift[:]))
@@ -450,6 +466,15 @@ class LaserOdometry:
         st = OdomStats()
         _check(lib().scal_odom_step(self.h, _p(a[0], _f32p), a[0].shape[0], _p(a[1], _f32p), a[1].shape[0], _p(a[2], _f32p), a[2].shape[0],
                                     _p(a[3], _f32p), a[3].shape[0], _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
+        return qlc, tlc, qw, tw, st
+
+    def enqueue_features(self, feat):
+        _check(lib().scal_odom_enqueue_features(self.h, feat.h))
+
+    def collect(self):
+        qlc, tlc, qw, tw = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        st = OdomStats()
+        _check(lib().scal_odom_collect(self.h, _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
         return qlc, tlc, qw, tw, st
 
     def step_features(self, feat):

@@ -88,9 +88,12 @@ def test_device_resident_pipeline(O, S, hdl64_stream):
     for k in range(6):
         xyz = hdl64_stream(k)
         f = reg.laserCloudHandler(xyz)  # leaves the device-resident results in the context too
-        if k % 2 == 1:
-            mp_dev.prefetch_features(reg)  # pose-independent part of stage C on the side stream, overlapping stage B
-        qlc, tlc, qw, tw, st = od_dev.step_features(reg)
+        if k % 2 == 1:  # split entry points: B queued first, the pose-independent part of stage C on the side stream meanwhile
+            od_dev.enqueue_features(reg)
+            mp_dev.prefetch_features(reg)
+            qlc, tlc, qw, tw, st = od_dev.collect()
+        else:
+            qlc, tlc, qw, tw, st = od_dev.step_features(reg)
         qm, tm, sm = mp_dev.process_features(reg, qw, tw)
         c = f["cloud"]
         h = od_host.step(c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
@@ -157,9 +160,11 @@ def test_sc_side_stream_overlap_is_ordered(O, S, hdl64_stream):
     for k in range(6):
         reg.laserCloudHandler(hdl64_stream(k))
         sc.insert_features(reg)   # side stream, no host synchronisation
+        if k % 2 == 0:            # detect on some scans only: the next run must wait for the reader by itself
+            sc.detect_enqueue()
         od.step_features(reg)     # main stream work of the same scan
-        if k % 2 == 0:            # detect on some scans only: the next run_device must wait for the reader by itself
-            rg = sc.detectLoopClosureID()
+        if k % 2 == 0:
+            rg = sc.detect_collect()
         f = O.features(hdl64_stream(k), O.HDL64, 5.0)
         ds, _ = O.voxel_grid(f["cloud"], 0.4)
         osc.makeAndSaveScancontextAndKeys(ds)
