@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
+    ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
     ap.add_argument("--no-overlap", action="store_true", help="keep ScanContext on the pipeline's stream (no stage D overlap)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
@@ -115,26 +116,36 @@ def main():
     sc_state = dict(counter=0, size_at_rebuild=0, n_global=a.sc_db)
     stats = dict(loops=0, blocks=0, stack_pts=0, solved=0, map_pts=0)
 
+    host_t = {}
+
+    def timed(name, fn, *args):
+        if not a.host_timing:
+            return fn(*args)
+        t = time.perf_counter()
+        r = fn(*args)
+        host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
+        return r
+
     def step(k):
-        reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
+        timed("A.run_device", reg.run_device, d_scans[k].data_ptr(), npts[k], 3)
         if a.no_overlap:
             qlc, tlc, qw, tw, ost = od.step_features(reg)
         else:
             # stage B is queued first (critical path), then everything that only needs stage A goes to the side stream while
             # B runs: stage C's input gather + stack downsample, and stage D (insert + search) for single-GPU runs
-            od.enqueue_features(reg)
-            mp.prefetch_features(reg)
+            timed("B.enqueue", od.enqueue_features, reg)
+            timed("C.prefetch", mp.prefetch_features, reg)
             if world == 1:
-                sc.insert_features(reg)
-                sc.detect_enqueue()
-            qlc, tlc, qw, tw, ost = od.collect()
-        qm, tm, mst = mp.process_features(reg, qw, tw)
+                timed("D.insert", sc.insert_features, reg)
+                timed("D.detect_enqueue", sc.detect_enqueue)
+            qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+        qm, tm, mst = timed("C.process", mp.process_features, reg, qw, tw)
         if world == 1:
             if a.no_overlap:
                 sc.insert_features(reg)
                 r = sc.detectLoopClosureID()
             else:
-                r = sc.detect_collect()
+                r = timed("D.detect_collect", sc.detect_collect)
         else:
             sc.make_features(reg, d_q.data_ptr())
             all_gather(all_q, d_q)
@@ -170,6 +181,7 @@ def main():
     for k in range(W):
         step(k)
     S.prof_reset()
+    host_t.clear()
     for key in stats:
         stats[key] = 0
     fence()
@@ -216,6 +228,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: v[0] / max(1, n_prof_steps) for k, v in sorted(prof.items())}, "profiled_steps": n_prof_steps,
             "loops_detected": int(stats["loops"]), "input_gen_s": gen_s,
+            "host_us_per_step": {k: v / K * 1e6 for k, v in host_t.items()} if a.host_timing else None,
         }
         print(json.dumps(out))
     if world > 1:

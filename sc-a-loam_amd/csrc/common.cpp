@@ -47,11 +47,11 @@ struct DevStream {
     hipStream_t s = nullptr;
     int refs = 0;
 };
-DevStream g_streams[64][2];  // [device][lane]: lane 0 = the pipeline's in-order stream, lane 1 = side stream
+DevStream g_streams[64][3];  // [device][lane]: lane 0 = the pipeline's in-order stream, lanes 1 and 2 = side streams
 }  // namespace
 
 int acquire_stream(int device, hipStream_t* out, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 1) {
+    if (device < 0 || device >= 64 || lane < 0 || lane > 2) {
         set_error("device ordinal %d out of range", device);
         return SCAL_E_ARG;
     }
@@ -72,7 +72,7 @@ int acquire_stream(int device, hipStream_t* out, int lane) {
 }
 
 void release_stream(int device, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 1) return;
+    if (device < 0 || device >= 64 || lane < 0 || lane > 2) return;
     std::lock_guard<std::mutex> lk(g_stream_mu);
     DevStream& d = g_streams[device][lane];
     if (d.refs > 0 && --d.refs == 0 && d.s) {

@@ -32,8 +32,9 @@ void set_error(const char* fmt, ...);
 // selects the device and verifies it is a gfx950 part: the product path must fail loudly otherwise
 int select_device(int device);
 // Contexts of one device share ONE in-order stream (lane 0): stages A -> B -> C of a scan are strictly dependent and a
-// single queue needs no cross-stream events.  Lane 1 is a second shared stream for work that only depends on stage A
-// (ScanContext with scal_sc_config::side_stream): it overlaps with B and C, ordered against the producer by events.
+// single queue needs no cross-stream events.  Lanes 1 and 2 are side streams for work that only depends on stage A
+// (1: ScanContext with scal_sc_config::side_stream, 2: scal_map_prefetch_features): it overlaps with B and C, ordered
+// against the producer by events.
 // Reference counted.
 int acquire_stream(int device, hipStream_t* out, int lane = 0);
 void release_stream(int device, int lane = 0);

@@ -980,7 +980,7 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     }
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
-        release_stream(c->cfg.device, 1);
+        release_stream(c->cfg.device, 2);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
@@ -1264,7 +1264,7 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
         return SCAL_E_ARG;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, 1));
+    if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, 2));
     if (!c->ev_pre) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
