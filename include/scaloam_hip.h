@@ -41,6 +41,11 @@ const char* scal_last_error(void);
 /* number of visible HIP devices, -1 if the runtime cannot initialise */
 int scal_device_count(void);
 const char* scal_version(void);
+/* 0 (default): the stages of a scan share one in-order stream per device (plus the optional side streams).  1: every stage
+ * context created afterwards gets its own stream, so that consecutive scans overlap the way the reference's four ROS nodes do
+ * (A of scan k+1 during C of scan k ...); hand-overs between contexts are ordered by events.  Use two features contexts
+ * alternately in that mode: a context's outputs are rewritten by its next run, which waits for all their readers. */
+int scal_set_stream_mode(int mode);
 /* Optional per-kernel timing (HIP events on the launching stream), used by bench.py's roofline leg.
  * No counterpart in the reference: its TicToc phase timers print nothing. */
 int scal_prof_enable(int on);
@@ -210,6 +215,13 @@ int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double*
 /* Optional: start the pose-independent part of the next scal_map_step_features(ctx, feat, ...) - input gather and the stack
  * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately. */
 int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
+/* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns as soon as the optimised pose is on
+ * the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it - the next enqueue,
+ * scal_map_export and scal_map_finish wait for them (and report a capacity error of the insertion).  The map sizes in the
+ * statistics of collect are those before this scan's insertion, insert_path is -1. */
+int scal_map_enqueue_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom);
+int scal_map_collect(scal_map_t* ctx, double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
+int scal_map_finish(scal_map_t* ctx);
 /* current map points of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap content); returns count */
 int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
 int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);

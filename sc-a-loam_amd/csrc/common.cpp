@@ -47,11 +47,12 @@ struct DevStream {
     hipStream_t s = nullptr;
     int refs = 0;
 };
-DevStream g_streams[64][3];  // [device][lane]: lane 0 = the pipeline's in-order stream, lanes 1 and 2 = side streams
+DevStream g_streams[64][5];  // [device][lane], see common.hpp
+int g_stream_mode = 0;
 }  // namespace
 
 int acquire_stream(int device, hipStream_t* out, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 2) {
+    if (device < 0 || device >= 64 || lane < 0 || lane > 4) {
         set_error("device ordinal %d out of range", device);
         return SCAL_E_ARG;
     }
@@ -71,8 +72,14 @@ int acquire_stream(int device, hipStream_t* out, int lane) {
     return SCAL_OK;
 }
 
+int stage_lane(int stage) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    if (g_stream_mode == 0) return 0;
+    return stage == STAGE_ODOM ? 3 : stage == STAGE_MAP ? 4 : stage == STAGE_SC ? 1 : 0;
+}
+
 void release_stream(int device, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 2) return;
+    if (device < 0 || device >= 64 || lane < 0 || lane > 4) return;
     std::lock_guard<std::mutex> lk(g_stream_mu);
     DevStream& d = g_streams[device][lane];
     if (d.refs > 0 && --d.refs == 0 && d.s) {
@@ -187,6 +194,16 @@ extern "C" int scal_prof_names(char* buf, int cap) {
         buf[cap - 1] = 0;
     }
     return static_cast<int>(all.size());
+}
+
+extern "C" int scal_set_stream_mode(int mode) {
+    if (mode != 0 && mode != 1) {
+        scal::set_error("scal_set_stream_mode: mode must be 0 or 1");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(scal::g_stream_mu);
+    scal::g_stream_mode = mode;
+    return SCAL_OK;
 }
 
 extern "C" const char* scal_last_error(void) { return scal::g_err; }

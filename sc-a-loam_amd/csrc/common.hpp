@@ -31,11 +31,14 @@ void set_error(const char* fmt, ...);
 
 // selects the device and verifies it is a gfx950 part: the product path must fail loudly otherwise
 int select_device(int device);
-// Contexts of one device share ONE in-order stream (lane 0): stages A -> B -> C of a scan are strictly dependent and a
-// single queue needs no cross-stream events.  Lanes 1 and 2 are side streams for work that only depends on stage A
-// (1: ScanContext with scal_sc_config::side_stream, 2: scal_map_prefetch_features): it overlaps with B and C, ordered
-// against the producer by events.
-// Reference counted.
+// Streams are shared per device and reference counted.  Lane 0 is the pipeline's in-order stream: by default stages A -> B -> C
+// of a scan all run there, strictly dependent, no cross-stream events.  Lanes 1 and 2 carry work that only depends on stage A
+// (1: ScanContext with scal_sc_config::side_stream, 2: scal_map_prefetch_features).  With scal_set_stream_mode(1) (set before
+// the contexts are created) every stage gets its own stream - A: 0, D: 1, C prefetch: 2, B: 3, C: 4 - so that consecutive
+// scans overlap the way the reference's four ROS nodes do; every hand-over between contexts is ordered by events in both
+// directions (features_wait_done / features_note_reader).
+enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4 };
+int stage_lane(int stage);
 int acquire_stream(int device, hipStream_t* out, int lane = 0);
 void release_stream(int device, int lane = 0);
 

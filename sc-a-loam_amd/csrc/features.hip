@@ -670,8 +670,11 @@ using namespace scal;
 struct scal_features {
     scal_features_config cfg;
     hipStream_t stream = nullptr;
-    hipEvent_t reader_ev = nullptr;  // last read of this context's buffers by a consumer on another stream
-    bool reader_pending = false;
+    // last read of this context's buffers by each consumer stream (B, C, C's prefetch, D may all run on their own)
+    static constexpr int MAX_READERS = 8;
+    hipStream_t reader_stream[MAX_READERS] = {};
+    hipEvent_t reader_ev[MAX_READERS] = {};
+    bool reader_pending[MAX_READERS] = {};
     hipEvent_t done_ev = nullptr;    // end of the most recent run, recorded on demand
     bool done_recorded = false;
     bool cross_stream_consumers = false;  // seen once: record done_ev right behind every run, before later main-stream work
@@ -722,9 +725,18 @@ int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     return SCAL_OK;
 }
 int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
-    if (!c->reader_ev) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev, hipEventDisableTiming));
-    SCAL_HIP(hipEventRecord(c->reader_ev, consumer_stream));
-    c->reader_pending = true;
+    if (consumer_stream == c->stream) return SCAL_OK;
+    int slot = -1;
+    for (int i = 0; i < scal_features::MAX_READERS && slot < 0; ++i)
+        if (c->reader_stream[i] == consumer_stream || c->reader_stream[i] == nullptr) slot = i;
+    if (slot < 0) {
+        set_error("features context: more than %d consumer streams", scal_features::MAX_READERS);
+        return SCAL_E_STATE;
+    }
+    c->reader_stream[slot] = consumer_stream;
+    if (!c->reader_ev[slot]) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev[slot], hipEventDisableTiming));
+    SCAL_HIP(hipEventRecord(c->reader_ev[slot], consumer_stream));
+    c->reader_pending[slot] = true;
     return SCAL_OK;
 }
 }  // namespace scal
@@ -797,10 +809,11 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
 extern "C" void scal_features_destroy(scal_features_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    if (c->reader_ev) {  // consumers on other streams must be done with the buffers
-        (void)hipEventSynchronize(c->reader_ev);
-        (void)hipEventDestroy(c->reader_ev);
-    }
+    for (int i = 0; i < scal_features::MAX_READERS; ++i)
+        if (c->reader_ev[i]) {  // consumers on other streams must be done with the buffers
+            (void)hipEventSynchronize(c->reader_ev[i]);
+            (void)hipEventDestroy(c->reader_ev[i]);
+        }
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
@@ -818,10 +831,11 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     k.thres2 = thres * thres;
     const int nb = max(1, div_up(n, TILE));
     FeatParams* P = c->d_P.p;
-    if (c->reader_pending) {  // a consumer on another stream may still be reading the previous scan's outputs
-        SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev, 0));
-        c->reader_pending = false;
-    }
+    for (int i = 0; i < scal_features::MAX_READERS; ++i)
+        if (c->reader_pending[i]) {  // a consumer on another stream may still be reading the previous scan's outputs
+            SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev[i], 0));
+            c->reader_pending[i] = false;
+        }
     c->done_recorded = false;
     hipLaunchKernelGGL(k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
     hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);

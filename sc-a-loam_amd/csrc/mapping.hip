@@ -865,10 +865,17 @@ using namespace scal;
 
 struct scal_map {
     scal_map_config cfg;
+    int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // side stream for scal_map_prefetch_features (lazily acquired)
     hipEvent_t ev = nullptr, ev_pre = nullptr;
     scal_features_t* prefetched_from = nullptr;
+    // asynchronous step: pose first (ev_pose), insertion + registration behind it (ev_done)
+    hipEvent_t ev_pose = nullptr, ev_done = nullptr;
+    bool pose_pending = false, insert_pending = false, insert_try_merge = false, pending_prefetched = false;
+    double pend_q_wodom[4] = {0, 0, 0, 1}, pend_t_wodom[3] = {0, 0, 0};
+    MapParams pend_mp{};
+    int deferred_error = SCAL_OK;
     int scan_cap = 0, map_cap = 0, slot_cap = 0;
     // host-side pose state (laserMapping.cpp:110-120)
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};
@@ -877,7 +884,15 @@ struct scal_map {
     bool have_mp = false;
     // device
     DevBuf<float> aos;  // upload staging
-    SoAStore corner_in, surf_in, full_in, full_out, corner_stack, surf_stack;
+    // Per-step inputs are double buffered ("sets"): the side stream may gather + downsample scan k+1 (set ^ 1) while scan k's
+    // association and insertion still read set; a step flips `set` when it starts.
+    int set = 0;
+    SoAStore corner_in2[2], surf_in2[2], corner_stack2[2], surf_stack2[2];
+    SoAStore full_in, full_out;
+    SoAStore& corner_in(int st = -1) { return corner_in2[st < 0 ? set : st]; }
+    SoAStore& surf_in(int st = -1) { return surf_in2[st < 0 ? set : st]; }
+    SoAStore& corner_stack(int st = -1) { return corner_stack2[st < 0 ? set : st]; }
+    SoAStore& surf_stack(int st = -1) { return surf_stack2[st < 0 ? set : st]; }
     VoxelFilter vf;
     MapStore map[2];  // corner, surf
     GridStore grid[2];
@@ -900,10 +915,11 @@ struct scal_map {
     DevBuf<float> nnx, nny, nnz, nnd5;
     NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
-    DevBuf<MapCounters> d_C;
+    DevBuf<MapCounters> d_C2[2];
+    DevBuf<MapCounters>& d_C(int st = -1) { return d_C2[st < 0 ? set : st]; }
     DevBuf<double> d_x0;
     DevBuf<int> d_nfull;
-    PinBuf<MapCounters> h_C;
+    PinBuf<MapCounters> h_C, h_C1;  // counters at the end of the step / when the pose is ready
     PinBuf<int> h_misc;
     PinBuf<double> h_x0;
     PinBuf<LMState> h_st;
@@ -930,8 +946,11 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
     const size_t sc = c->scan_cap, mc = c->map_cap;
     A(c->aos.alloc(sc * 4));
-    A(c->corner_in.alloc(sc)); A(c->surf_in.alloc(sc)); A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
-    A(c->corner_stack.alloc(sc)); A(c->surf_stack.alloc(sc));
+    for (int k = 0; k < 2; ++k) {
+        A(c->corner_in2[k].alloc(sc)); A(c->surf_in2[k].alloc(sc)); A(c->corner_stack2[k].alloc(sc)); A(c->surf_stack2[k].alloc(sc));
+        A(c->d_C2[k].alloc(1));
+    }
+    A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
     A(c->vf.init(c->scan_cap));
     for (int k = 0; k < 2; ++k) {
         for (int b = 0; b < 2; ++b) {
@@ -952,9 +971,10 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
     A(c->lm_sync.alloc(1));
     if (rc == SCAL_OK && hipMemset(c->lm_sync.p, 0, sizeof(LMSync)) != hipSuccess) rc = SCAL_E_HIP;
-    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4));
+    A(c->d_st.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4)); A(c->h_C1.alloc(1));
     A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4)); A(c->h_x0.alloc(8));
-    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
+    c->lane = stage_lane(STAGE_MAP);
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         // the cell counters obey a zero invariant: every step clears exactly the cells it touched
@@ -976,7 +996,7 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        release_stream(c->cfg.device);
+        release_stream(c->cfg.device, c->lane);
     }
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
@@ -984,6 +1004,8 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    if (c->ev_pose) (void)hipEventDestroy(c->ev_pose);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     delete c;
 }
 
@@ -1004,23 +1026,80 @@ void h_rot(const double* q, const double* v, double* o) {
 }
 
 // stack downsample (:543-551) of corner_in / surf_in into corner_stack / surf_stack; independent of the pose
-static int enqueue_stack_filters(scal_map* c, hipStream_t s, int n_corner_bound, int n_surf_bound) {
-    MapCounters* C = c->d_C.p;
-    SCAL_TRY(c->vf.run(s, c->corner_in.cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack.v(), &C->n_corner_stack));
+static int enqueue_stack_filters(scal_map* c, hipStream_t s, int n_corner_bound, int n_surf_bound, int st) {
+    MapCounters* C = c->d_C(st).p;
+    SCAL_TRY(c->vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack(st).v(), &C->n_corner_stack));
     if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
         // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
         hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
     }
-    SCAL_TRY(c->vf.run(s, c->surf_in.cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack.v(), &C->n_surf_stack));
+    SCAL_TRY(c->vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack(st).v(), &C->n_surf_stack));
     hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, c->vf.meta.p, C, c->slot_cap);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
-// everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C
-int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full, int n_corner_bound,
-             int n_surf_bound, bool filters_done, double* q_out,
-             double* t_out, scal_map_stats* stats) {
+// insert + re-filter (:738-802) by a full stable sort of the pool
+static int insert_full_sort(scal_map* c, const MapParams& mp) {
+    hipStream_t s = c->stream;
+    MapCounters* C = c->d_C().p;
+    LMState* st = c->d_st.p;
+    for (int k = 0; k < 2; ++k) {
+        MapStore& M = c->map[k];
+        const int n_tot_max = std::min(c->map_cap, M.n + c->scan_cap);
+        const int nb = std::max(1, div_up(n_tot_max, 256));
+        MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
+        const CSoA4 stack = k == 0 ? c->corner_stack().cv() : c->surf_stack().cv();
+        const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
+                           c->keys.p, c->vals.p, C, k);
+        SortedPairs sp;
+        SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
+        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
+        launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
+        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
+    }
+    return SCAL_OK;
+}
+
+// waits for the insertion of the previous step (if any), redoes it with the full sort when the merge gave up, and publishes
+// the new map sizes.  Every entry point that touches the map calls this first.
+static int map_finish(scal_map* c) {
+    if (!c->insert_pending) return SCAL_OK;
+    c->insert_pending = false;
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipEventSynchronize(c->ev_done));
+    c->last_insert_path = c->insert_try_merge ? 1 : 0;
+    if (c->insert_try_merge && c->h_C.p->merge_fail && !c->h_C.p->error) {  // a case the merge does not cover: redo with the full sort
+        SCAL_TRY(insert_full_sort(c, c->pend_mp));
+        SCAL_HIP(hipGetLastError());
+        SCAL_HIP(hipMemcpyAsync(c->h_C.p, c->d_C().p, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+        c->last_insert_path = 0;
+    }
+    for (int k = 0; k < 2; ++k) c->map[k].cur ^= 1;
+    const MapCounters& H = *c->h_C.p;
+    for (int k = 0; k < 2; ++k) c->map[k].n = H.n_map_new[k];
+    if (H.error) {
+        set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
+        return H.error;
+    }
+    return SCAL_OK;
+}
+
+// Enqueues one process() pass: everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C.
+// ev_pose fires when the optimised pose has reached the host buffers, ev_done after insertion + registration.
+static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full,
+                       int n_corner_bound, int n_surf_bound, bool filters_done) {
+    SCAL_TRY(map_finish(c));
+    if (c->pose_pending) {
+        set_error("scal_map: the pose of the previous step has not been collected");
+        return SCAL_E_STATE;
+    }
+    if (!c->ev_pose) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pose, hipEventDisableTiming));
+    if (!c->ev_done) SCAL_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) c->pend_q_wodom[i] = q_wodom[i];
+    for (int i = 0; i < 3; ++i) c->pend_t_wodom[i] = t_wodom[i];
     hipStream_t s = c->stream;
     // transformAssociateToMap (:143-147)
     double x0[8] = {0};
@@ -1050,12 +1129,12 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     c->last_mp = mp;
     c->have_mp = true;
 
-    MapCounters* C = c->d_C.p;
+    MapCounters* C = c->d_C().p;
     LMState* st = c->d_st.p;
     for (int i = 0; i < 7; ++i) c->h_x0.p[i] = x0[i];
     SCAL_HIP(hipMemcpyAsync(st->x, c->h_x0.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));  // LMState::x is the first member
 
-    if (!filters_done) SCAL_TRY(enqueue_stack_filters(c, s, n_corner_bound, n_surf_bound));
+    if (!filters_done) SCAL_TRY(enqueue_stack_filters(c, s, n_corner_bound, n_surf_bound, c->set));
 
     // cell grids over the valid cubes
     for (int k = 0; k < 2; ++k) {
@@ -1072,17 +1151,23 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     const int assoc_blocks = std::max(1, div_up(c->slot_cap, 4));
     for (int outer = 0; outer < 2; ++outer) {
         {
-            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), mp, c->grid[0].cnt.p,
+            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack().cv(), c->surf_stack().cv(), mp, c->grid[0].cnt.p,
                                c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, c->nnbuf());
         }
         {
-            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack.cv(), c->surf_stack.cv(), c->nnbuf(),
+            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack().cv(), c->surf_stack().cv(), c->nnbuf(),
                                C, outer, F);
         }
         {
                         launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer);
         }
     }
+    // the pose and the statistics known so far go to the host now; the map update follows behind
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_C1.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipEventRecord(c->ev_pose, s));
+    c->pose_pending = true;
     // restore the zero invariant of the cell counters
     for (int k = 0; k < 2; ++k) {
         MapStore& M = c->map[k];
@@ -1090,24 +1175,6 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         hipLaunchKernelGGL(k_grid_clear, dim3(nb), dim3(256), 0, s, M.cloud(M.cur), M.n, mp, c->grid[k].rank.p, c->grid[k].cnt.p);
     }
     // insert + re-filter (:738-802)
-    auto insert_full_sort = [&]() -> int {
-        for (int k = 0; k < 2; ++k) {
-            MapStore& M = c->map[k];
-            const int n_tot_max = std::min(c->map_cap, M.n + c->scan_cap);
-            const int nb = std::max(1, div_up(n_tot_max, 256));
-            MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
-            const CSoA4 stack = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
-            const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-            hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
-                               c->keys.p, c->vals.p, C, k);
-            SortedPairs sp;
-            SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
-            hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
-            launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
-            hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
-        }
-        return SCAL_OK;
-    };
     const bool try_merge = c->merge_insert && window_same && c->map[0].n + MERGE_MAX <= c->map_cap && c->map[1].n + MERGE_MAX <= c->map_cap;
     if (try_merge) {
         MergeArgs a;
@@ -1115,7 +1182,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
             MapStore& M = c->map[k];
             a.in[k] = M.cloud(M.cur), a.out[k] = M.cloud(M.cur ^ 1);
             a.n_old[k] = M.n;
-            a.stack[k] = k == 0 ? c->corner_stack.cv() : c->surf_stack.cv();
+            a.stack[k] = k == 0 ? c->corner_stack().cv() : c->surf_stack().cv();
             a.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
             a.inv_leaf[k] = k == 0 ? mp.inv_line : mp.inv_plane;
             a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
@@ -1134,7 +1201,7 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
         hipLaunchKernelGGL(k_merge_prepare, dim3(2), dim3(1024), lds, s, a, C);
         hipLaunchKernelGGL(k_merge_write, dim3(grid), dim3(256), 0, s, a, C);
     } else {
-        SCAL_TRY(insert_full_sort());
+        SCAL_TRY(insert_full_sort(c, mp));
     }
     if (have_full) {
         const int nb = std::max(1, div_up(c->scan_cap, 256));
@@ -1142,28 +1209,32 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
     }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
-    c->last_insert_path = try_merge ? 1 : 0;
-    if (try_merge && c->h_C.p->merge_fail && !c->h_C.p->error) {  // a case the merge does not cover: redo with the full sort
-        SCAL_TRY(insert_full_sort());
-        SCAL_HIP(hipGetLastError());
-        SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
-        c->last_insert_path = 0;
+    SCAL_HIP(hipEventRecord(c->ev_done, s));
+    c->insert_pending = true, c->insert_try_merge = try_merge, c->pend_mp = mp;
+    return SCAL_OK;
+}
+
+// waits for the pose of the enqueued step; map sizes in `stats` are those before this step's insertion (insert_path = -1)
+static int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* stats) {
+    if (!c->pose_pending) {
+        set_error("scal_map_collect: no step enqueued");
+        return SCAL_E_STATE;
     }
-    for (int k = 0; k < 2; ++k) c->map[k].cur ^= 1;
-    const MapCounters& H = *c->h_C.p;
-    for (int k = 0; k < 2; ++k) c->map[k].n = H.n_map_new[k];
+    c->pose_pending = false;
+    SCAL_HIP(hipEventSynchronize(c->ev_pose));
+    const MapCounters& H = *c->h_C1.p;
     if (H.error) {
         set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
         return H.error;
     }
     if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+        (void)hipStreamSynchronize(c->stream);
         (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
     }
+    const double* q_wodom = c->pend_q_wodom;
+    const double* t_wodom = c->pend_t_wodom;
     const double* xf = c->h_st.p->x;
     for (int i = 0; i < 4; ++i) q_out[i] = xf[i];
     for (int i = 0; i < 3; ++i) t_out[i] = xf[4 + i];
@@ -1186,7 +1257,20 @@ int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool hav
             stats->cost_init[o] = H.solve_on ? L.log_cost_init[o] : 0.0, stats->cost_final[o] = H.solve_on ? L.log_cost_final[o] : 0.0;
         }
         stats->solved = H.solve_on;
-        stats->n_map_corner_total = H.n_map_new[0], stats->n_map_surf_total = H.n_map_new[1];
+        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
+        stats->insert_path = -1;
+    }
+    return SCAL_OK;
+}
+
+// synchronous form: enqueue, pose, insertion finished, final map sizes
+int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full, int n_corner_bound,
+             int n_surf_bound, bool filters_done, double* q_out, double* t_out, scal_map_stats* stats) {
+    SCAL_TRY(map_enqueue(c, q_wodom, t_wodom, have_full, full_view, d_n_full, n_corner_bound, n_surf_bound, filters_done));
+    SCAL_TRY(map_collect_pose(c, q_out, t_out, stats));
+    SCAL_TRY(map_finish(c));
+    if (stats) {
+        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
         stats->insert_path = c->last_insert_path;
     }
     return SCAL_OK;
@@ -1197,7 +1281,7 @@ int reset_counters(scal_map* c, int n_corner, int n_surf, int n_full) {
     std::memset(&z, 0, sizeof z);
     z.n_corner_in = n_corner, z.n_surf_in = n_surf;
     *c->h_C.p = z;
-    SCAL_HIP(hipMemcpyAsync(c->d_C.p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, c->stream));
+    SCAL_HIP(hipMemcpyAsync(c->d_C().p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, c->stream));
     c->h_misc.p[0] = n_full;
     SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, c->stream));
     return SCAL_OK;
@@ -1221,6 +1305,10 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     hipStream_t s = c->stream;
     const bool have_full = full_res != nullptr && n_full > 0;
     int nf = have_full ? n_full : 0;
+    SCAL_TRY(map_finish(c));  // a pending insertion of an asynchronous step still owns the current set
+    c->set ^= 1;
+    c->pending_prefetched = false;
+    c->prefetched_from = nullptr;
     // n_full lives in pinned-less host memory for the async copy: stage through the counters struct instead
     SCAL_TRY(reset_counters(c, n_corner, n_surf, nf));
     SCAL_HIP(hipStreamSynchronize(s));  // &nf must not be read after return
@@ -1231,8 +1319,8 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
         }
         return SCAL_OK;
     };
-    SCAL_TRY(up(corner_last, n_corner, c->corner_in));
-    SCAL_TRY(up(surf_last, n_surf, c->surf_in));
+    SCAL_TRY(up(corner_last, n_corner, c->corner_in()));
+    SCAL_TRY(up(surf_last, n_surf, c->surf_in()));
     if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
     SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, c->full_in.cv(), c->d_nfull.p, n_corner, n_surf, false, q_w_curr, t_w_curr, stats));
     if (have_full && registered) {
@@ -1245,10 +1333,10 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
 
 // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
 // read in place by the registration transform
-static int enqueue_gather(scal_map* c, const FeatDeviceView& v, hipStream_t s, int ls_cap, int cap) {
+static int enqueue_gather(scal_map* c, const FeatDeviceView& v, hipStream_t s, int ls_cap, int cap, int st) {
     const int nbc = std::max(1, div_up(ls_cap, 256));
     hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
-                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in.v(), c->surf_in.v(), c->d_C.p, c->scan_cap, nbc);
+                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st).v(), c->surf_in(st).v(), c->d_C(st).p, c->scan_cap, nbc);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -1269,12 +1357,41 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
     SCAL_TRY(features_wait_done(feat, c->side));
-    SCAL_TRY(enqueue_gather(c, v, c->side, ls_cap, cap));
-    SCAL_TRY(enqueue_stack_filters(c, c->side, ls_cap, cap));
+    // the step in flight owns set `c->set`; this one fills the other set.  The filter scratch (c->vf) is shared with a step that
+    // ran its filters on the main stream: wait for that step in that case.
+    if (c->insert_pending && !c->pending_prefetched) SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_done, 0));
+    const int nset = c->set ^ 1;
+    SCAL_TRY(enqueue_gather(c, v, c->side, ls_cap, cap, nset));
+    SCAL_TRY(enqueue_stack_filters(c, c->side, ls_cap, cap, nset));
     SCAL_HIP(hipEventRecord(c->ev_pre, c->side));
     SCAL_TRY(features_note_reader(feat, c->side));
     c->prefetched_from = feat;
     return SCAL_OK;
+}
+
+static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom) {
+    FeatDeviceView v = features_view(feat);
+    if (v.device != c->cfg.device) {
+        set_error("features context lives on device %d, map context on %d", v.device, c->cfg.device);
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(map_finish(c));  // the previous insertion still owns the counters and the stack buffers
+    hipStream_t s = c->stream;
+    const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
+    const int cap = std::min(c->scan_cap, v.cap);
+    const bool pre = c->prefetched_from == feat;
+    c->prefetched_from = nullptr;
+    c->set ^= 1;  // this step's set (the one a prefetch filled)
+    c->pending_prefetched = pre;
+    if (pre) {
+        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre, 0));  // inputs gathered and downsampled on the side stream
+    } else {
+        SCAL_TRY(features_wait_done(feat, s));
+        SCAL_TRY(enqueue_gather(c, v, s, ls_cap, cap, c->set));
+    }
+    SCAL_TRY(map_enqueue(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, pre));
+    return features_note_reader(feat, s);  // the registration transform reads the full-resolution cloud last
 }
 
 extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom, double* q_w_curr,
@@ -1283,24 +1400,37 @@ extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, cons
         set_error("scal_map_step_features: null argument");
         return SCAL_E_ARG;
     }
-    FeatDeviceView v = features_view(feat);
-    if (v.device != c->cfg.device) {
-        set_error("features context lives on device %d, map context on %d", v.device, c->cfg.device);
+    SCAL_TRY(map_enqueue_features(c, feat, q_wodom, t_wodom));
+    SCAL_TRY(map_collect_pose(c, q_w_curr, t_w_curr, stats));
+    SCAL_TRY(map_finish(c));
+    if (stats) {
+        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
+        stats->insert_path = c->last_insert_path;
+    }
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_enqueue_features(scal_map_t* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom) {
+    if (!c || !feat || !q_wodom || !t_wodom) {
+        set_error("scal_map_enqueue_features: null argument");
+        return SCAL_E_ARG;
+    }
+    return map_enqueue_features(c, feat, q_wodom, t_wodom);
+}
+
+extern "C" int scal_map_collect(scal_map_t* c, double* q_w_curr, double* t_w_curr, scal_map_stats* stats) {
+    if (!c || !q_w_curr || !t_w_curr) {
+        set_error("scal_map_collect: null argument");
         return SCAL_E_ARG;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    hipStream_t s = c->stream;
-    const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
-    const int cap = std::min(c->scan_cap, v.cap);
-    const bool pre = c->prefetched_from == feat;
-    c->prefetched_from = nullptr;
-    if (pre) {
-        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre, 0));  // inputs gathered and downsampled on the side stream
-    } else {
-        SCAL_TRY(features_wait_done(feat, s));
-        SCAL_TRY(enqueue_gather(c, v, s, ls_cap, cap));
-    }
-    return run_step(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, pre, q_w_curr, t_w_curr, stats);
+    return map_collect_pose(c, q_w_curr, t_w_curr, stats);
+}
+
+extern "C" int scal_map_finish(scal_map_t* c) {
+    if (!c) return SCAL_E_ARG;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    return map_finish(c);
 }
 
 extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int cap) {
@@ -1308,8 +1438,9 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
         set_error("scal_map_export: bad argument");
         return SCAL_E_ARG;
     }
-    if (!c->have_mp || c->map[which].n == 0) return 0;
     SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (map_finish(c) != SCAL_OK) return -1;
+    if (!c->have_mp || c->map[which].n == 0) return 0;
     hipStream_t s = c->stream;
     MapStore& M = c->map[which];
     int zero = 0;

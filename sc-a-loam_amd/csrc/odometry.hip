@@ -368,6 +368,7 @@ struct scal_odom {
     hipStream_t stream = nullptr;
     hipEvent_t ev = nullptr;
     int cap = 0, feat_cap = 0, slot_cap = 0;
+    int lane = 0;
     bool systemInited = false;
     bool pending = false, pending_solve = false;  // a step is enqueued and not collected yet
     double q_w_curr[4] = {0, 0, 0, 1}, t_w_curr[3] = {0, 0, 0};  // :93-94
@@ -415,7 +416,8 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->ring_tab.alloc(8 * RING_TAB));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
-    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
+    c->lane = stage_lane(STAGE_ODOM);
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         if (hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
@@ -437,7 +439,7 @@ extern "C" void scal_odom_destroy(scal_odom_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        release_stream(c->cfg.device);
+        release_stream(c->cfg.device, c->lane);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;
@@ -606,7 +608,9 @@ extern "C" int scal_odom_enqueue_features(scal_odom_t* c, scal_features_t* feat)
     a.o_sharp = c->sharp.v(), a.o_flat = c->flat.v(), a.o_less = c->less_sharp.v(), a.o_less_flat = c->less_flat.v();
     a.slot_cap = c->slot_cap, a.feat_cap = c->feat_cap, a.cap = std::min(c->cap, v.cap);
     a.nbs = std::max(1, div_up(c->slot_cap, 256)), a.nbf = std::max(1, div_up(c->feat_cap, 256));
+    SCAL_TRY(features_wait_done(feat, s));
     hipLaunchKernelGGL(k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
+    SCAL_TRY(features_note_reader(feat, s));  // everything stage B needs has been copied out of the features context
     return odom_enqueue(c);
 }
 

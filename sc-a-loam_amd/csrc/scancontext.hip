@@ -444,6 +444,7 @@ struct scal_sc {
     DevBuf<int> d_nds;
     int vf_cap = 0;
     hipEvent_t ev = nullptr;
+    int lane = 0;
     int detect_pending = 0;  // 1: search launched, 2: database too small (nothing launched)
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
     SCSlot staging() const { return SCSlot{qdesc.p, qrkey.p, qskey.p, qnorm.p}; }
@@ -479,7 +480,7 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->gcell.alloc(DESC));
     if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
     A(c->h_rec.alloc(4));
-    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->cfg.side_stream ? 1 : 0) != SCAL_OK) {
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane = (c->cfg.side_stream ? 1 : stage_lane(STAGE_SC))) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -496,7 +497,7 @@ extern "C" void scal_sc_destroy(scal_sc_t* c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
-        release_stream(c->cfg.device, c->cfg.side_stream ? 1 : 0);
+        release_stream(c->cfg.device, c->lane);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
     delete c;

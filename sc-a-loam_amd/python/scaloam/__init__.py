@@ -83,7 +83,8 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
+    "scal_set_stream_mode",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
@@ -146,6 +147,10 @@ def lib():
     L.scal_map_get_wmap_wodom.argtypes = [vp, _f64p, _f64p]
     L.scal_map_set_merge_insert.argtypes = [vp, C.c_int]
     L.scal_map_prefetch_features.argtypes = [vp, vp]
+    L.scal_map_enqueue_features.argtypes = [vp, vp, _f64p, _f64p]
+    L.scal_map_collect.argtypes = [vp, _f64p, _f64p, C.POINTER(MapStats)]
+    L.scal_map_finish.argtypes = [vp]
+    L.scal_set_stream_mode.argtypes = [C.c_int]
     L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
     L.scal_odom_destroy.argtypes = [vp]
     L.scal_odom_destroy.restype = None
@@ -174,6 +179,10 @@ def _f32(a):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def set_stream_mode(mode):
+    _check(lib().scal_set_stream_mode(int(mode)))
 
 
 def device_count():
@@ -432,6 +441,17 @@ class LaserMapping:
         out = np.zeros((max(n, 1), 4), np.float32)
         m = lib().scal_map_export(self.h, which, _p(out, _f32p), n)
         return out[:m]
+
+    def enqueue_features(self, feat, q_wodom, t_wodom):
+        _check(lib().scal_map_enqueue_features(self.h, feat.h, _p(_f64(q_wodom), _f64p), _p(_f64(t_wodom), _f64p)))
+
+    def collect(self):
+        qo, to, st = np.zeros(4), np.zeros(3), MapStats()
+        _check(lib().scal_map_collect(self.h, _p(qo, _f64p), _p(to, _f64p), C.byref(st)))
+        return qo, to, st
+
+    def finish(self):
+        _check(lib().scal_map_finish(self.h))
 
     def prefetch_features(self, feat):
         _check(lib().scal_map_prefetch_features(self.h, feat.h))

@@ -177,3 +177,57 @@ def test_sc_side_stream_overlap_is_ordered(O, S, hdl64_stream):
         assert np.array_equal(dg, do) and np.array_equal(kg.view(np.uint32), ko.view(np.uint32)), k
     for x in (reg, od, sc):
         x.close()
+
+
+def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
+    """scal_set_stream_mode(1): every stage on its own stream, consecutive scans overlapping like the reference's four nodes
+    (A of scan k+1 while C of scan k still runs; map insertion behind the pose).  Software-pipelined exactly as bench.py does
+    it, with two features contexts used alternately.  Every pose and every loop-closure answer must equal the oracle chain."""
+    n = 8
+    S.set_stream_mode(1)
+    try:
+        regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(2)]
+        od = S.LaserOdometry(max_points=200000)
+        mp = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+        sc = S.SCManager(dist_thres=0.4)
+        osc = O.SCManager(dist_thres=0.4)
+        rng = np.random.default_rng(11)
+        for i in range(40):
+            d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+            sc.saveScancontextAndKeys(d)
+            osc.saveScancontextAndKeys(d)
+        poses, loops = [], []
+        pending = None
+        for k in range(n):
+            reg = regs[k % 2]
+            reg.laserCloudHandler(hdl64_stream(k))
+            od.enqueue_features(reg)
+            mp.prefetch_features(reg)
+            sc.insert_features(reg)
+            sc.detect_enqueue()
+            qlc, tlc, qw, tw, ost = od.collect()
+            if pending is not None:
+                poses.append(mp.collect()[:2])
+            mp.enqueue_features(reg, qw, tw)
+            pending = k
+            loops.append(sc.detect_collect())
+        poses.append(mp.collect()[:2])
+        mp.finish()
+        oo, om = O.Odometry(), O.Mapper(0.4, 0.8)
+        for k in range(n):
+            fo = O.features(hdl64_stream(k), O.HDL64, 5.0)
+            co = fo["cloud"]
+            a = oo.step(co[fo["sharp"]], co[fo["less_sharp"]], co[fo["flat"]], fo["less_flat"])
+            qo, to, so, _ = om.step(co[fo["less_sharp"]], fo["less_flat"], co, a[2], a[3])
+            assert max(np.abs(poses[k][0] - qo).max(), np.abs(poses[k][1] - to).max()) <= 1e-6, k
+            ds, _ = O.voxel_grid(co, 0.4)
+            osc.makeAndSaveScancontextAndKeys(ds)
+            ro = osc.detectLoopClosureID()
+            assert loops[k]["loop_id"] == ro["loop_id"] and loops[k]["nn_idx"] == ro["nn_idx"], k
+            assert abs(loops[k]["min_dist"] - ro["min_dist"]) <= 1e-12, k
+        for which in (0, 1):
+            assert mp.export(which).shape == om.export(which).shape
+        for x in regs + [od, mp, sc]:
+            x.close()
+    finally:
+        S.set_stream_mode(0)
