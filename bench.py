@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# The stage pipeline keeps five HIP streams busy (A, B, C, C's prefetch, D) next to torch's; the runtime multiplexes streams
+# onto 4 hardware queues by default, which would serialise stages that share a queue.  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in ("oracle", os.path.join("sc-a-loam_amd", "python"), os.path.join("tools", "synth")):
     sys.path.insert(0, os.path.join(ROOT, p))
@@ -39,8 +43,9 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
+    ap.add_argument("--ring", type=int, default=3, help="features contexts used in turn by the stage pipeline")
     ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
-    ap.add_argument("--no-overlap", action="store_true", help="keep ScanContext on the pipeline's stream (no stage D overlap)")
+    ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
@@ -99,11 +104,16 @@ def main():
     d_scans = [torch.from_numpy(s).cuda(local) for s in scans]  # inputs resident in HBM before the timed region
     cap = max(npts) + 1024
 
-    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local)
+    pipelined = not a.no_overlap
+    # One stream per stage, consecutive scans overlapping like the reference's four ROS nodes (scanRegistration, laserOdometry,
+    # laserMapping, laserPosegraphOptimization run concurrently on different scans); two features contexts used alternately.
+    S.set_stream_mode(1 if pipelined else 0)
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range(a.ring if pipelined else 1)]
+    reg = regs[0]
     od = S.LaserOdometry(max_points=cap, device=local)
     mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
     sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=a.sc_db // world + total * world + 64, device=local,
-                     n_shards=world, shard=rank, side_stream=1 if (world == 1 and not a.no_overlap) else 0)
+                     n_shards=world, shard=rank)
     rng = np.random.default_rng(4242)
     for d in synth_descs(rng, a.sc_db):
         sc.saveScancontextAndKeys(d.T)  # every shard sees every insert and keeps the ones it owns
@@ -126,51 +136,80 @@ def main():
         host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
         return r
 
-    def step(k):
-        timed("A.run_device", reg.run_device, d_scans[k].data_ptr(), npts[k], 3)
-        if a.no_overlap:
-            qlc, tlc, qw, tw, ost = od.step_features(reg)
-        else:
-            # stage B is queued first (critical path), then everything that only needs stage A goes to the side stream while
-            # B runs: stage C's input gather + stack downsample, and stage D (insert + search) for single-GPU runs
-            timed("B.enqueue", od.enqueue_features, reg)
-            timed("C.prefetch", mp.prefetch_features, reg)
-            if world == 1:
-                timed("D.insert", sc.insert_features, reg)
-                timed("D.detect_enqueue", sc.detect_enqueue)
-            qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
-        qm, tm, mst = timed("C.process", mp.process_features, reg, qw, tw)
-        if world == 1:
-            if a.no_overlap:
-                sc.insert_features(reg)
-                r = sc.detectLoopClosureID()
-            else:
-                r = timed("D.detect_collect", sc.detect_collect)
-        else:
-            sc.make_features(reg, d_q.data_ptr())
-            all_gather(all_q, d_q)
-            torch.cuda.current_stream().synchronize()
-            for rr in range(world):  # global insertion order: rank 0..N-1 of this step
-                sc.insert_descriptor_device(all_q[rr].data_ptr())
-            sc_state["n_global"] += world
-            # detectLoopClosureID's tree period (Scancontext.cpp:353-365), one query per rank in global order
-            limits = []
-            for rr in range(world):
-                if sc_state["counter"] % 30 == 0:
-                    sc_state["size_at_rebuild"] = sc_state["n_global"]
-                sc_state["counter"] += 1
-                limits.append(sc_state["size_at_rebuild"])
-            sc.shard_query_device(all_q.data_ptr(), world, limits[rank], d_rec.data_ptr())
-            all_gather(all_rec, d_rec)
-            rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query
-            cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
-            r = S.merge_candidates(cands, 0.4)
+    def sc_sharded(reg):
+        """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records)"""
+        sc.make_features(reg, d_q.data_ptr())
+        all_gather(all_q, d_q)
+        torch.cuda.current_stream().synchronize()
+        for rr in range(world):  # global insertion order: rank 0..N-1 of this step
+            sc.insert_descriptor_device(all_q[rr].data_ptr())
+        sc_state["n_global"] += world
+        # detectLoopClosureID's tree period (Scancontext.cpp:353-365), one query per rank in global order
+        limits = []
+        for rr in range(world):
+            if sc_state["counter"] % 30 == 0:
+                sc_state["size_at_rebuild"] = sc_state["n_global"]
+            sc_state["counter"] += 1
+            limits.append(sc_state["size_at_rebuild"])
+        sc.shard_query_device(all_q.data_ptr(), world, limits[rank], d_rec.data_ptr())
+        all_gather(all_rec, d_rec)
+        rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query
+        cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
+        return S.merge_candidates(cands, 0.4)
+
+    def account(mst, r):
         stats["loops"] += r["loop_id"] >= 0
         stats["blocks"] += mst.n_edge[0] + mst.n_plane[0] + mst.n_edge[1] + mst.n_plane[1]
         stats["stack_pts"] += mst.n_corner_stack + mst.n_surf_stack
         stats["solved"] += mst.solved
         stats["map_pts"] += mst.n_map_corner_total + mst.n_map_surf_total
-        return qm, tm
+
+    def step_serial(k):
+        """one scan at a time: A -> B -> C -> D, each stage finished before the next starts"""
+        timed("A.run_device", reg.run_device, d_scans[k].data_ptr(), npts[k], 3)
+        qlc, tlc, qw, tw, ost = od.step_features(reg)
+        qm, tm, mst = timed("C.process", mp.process_features, reg, qw, tw)
+        if world == 1:
+            sc.insert_features(reg)
+            r = sc.detectLoopClosureID()
+        else:
+            r = sc_sharded(reg)
+        account(mst, r)
+
+    pipe = dict(map_pending=False, loop=None, a_queued=-1)
+
+    def step_pipelined(k, last):
+        """Software pipeline over the stage streams.  Per scan k: B is queued (A(k) was queued one step ahead), then everything
+        that only needs stage A (C's input gather + stack downsample, D's insert + search), then stage A of scan k+1 into
+        the other features context; B's pose is collected, the pose of the PREVIOUS scan's stage C is collected (its map
+        insertion continues behind it), and this scan's stage C is queued."""
+        r_ = regs[k % len(regs)]
+        if pipe["a_queued"] != k:
+            timed("A.run_device", r_.run_device, d_scans[k].data_ptr(), npts[k], 3)
+        timed("B.enqueue", od.enqueue_features, r_)
+        timed("C.prefetch", mp.prefetch_features, r_)
+        if world == 1:
+            timed("D.insert", sc.insert_features, r_)
+            timed("D.detect_enqueue", sc.detect_enqueue)
+        if k + 1 < last:
+            timed("A.run_device", regs[(k + 1) % len(regs)].run_device, d_scans[k + 1].data_ptr(), npts[k + 1], 3)
+            pipe["a_queued"] = k + 1
+        qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+        if pipe["map_pending"]:
+            qm, tm, mst = timed("C.collect", mp.collect)
+            account(mst, pipe["loop"])
+        timed("C.enqueue", mp.enqueue_features, r_, qw, tw)
+        pipe["map_pending"] = True
+        pipe["loop"] = timed("D.detect_collect", sc.detect_collect) if world == 1 else sc_sharded(r_)
+
+    def drain():
+        if pipe["map_pending"]:
+            qm, tm, mst = mp.collect()
+            account(mst, pipe["loop"])
+            pipe["map_pending"] = False
+        mp.finish()
+
+    step = step_pipelined if pipelined else (lambda k, last: step_serial(k))
 
     def fence():
         torch.cuda.synchronize()
@@ -179,7 +218,9 @@ def main():
         torch.cuda.synchronize()
 
     for k in range(W):
-        step(k)
+        step(k, W)
+    if pipelined:
+        drain()
     S.prof_reset()
     host_t.clear()
     for key in stats:
@@ -191,7 +232,9 @@ def main():
         on = a.prof_every > 0 and (k - W) % a.prof_every == 0
         S.prof_enable(on)  # per-kernel timestamps on the sampled steps of the timed region
         n_prof_steps += on
-        step(k)
+        step(k, W + K)
+    if pipelined:
+        drain()  # the last scan's pose and map insertion belong to the timed region
     fence()
     dt = time.perf_counter() - t0
     S.prof_enable(False)
@@ -224,7 +267,9 @@ def main():
                                    "scan-to-map: 2 outer x <=4 LM iterations edge+surf correspondence + JtJ, with stage A features, stage B "
                                    "odometry prior and ScanContext insert+detect per scan",
                        "points_per_scan_in": int(np.mean(npts)), "sc_db_keyframes": a.sc_db, "line_res": 0.4, "plane_res": 0.8,
-                       "parallelism": "replicas for A-C, SC database sharded i % N with RCCL all-gather" if world > 1 else "single GPU"},
+                       "parallelism": "replicas for A-C, SC database sharded i % N with RCCL all-gather" if world > 1 else "single GPU",
+                       "schedule": "stage-pipelined: one stream per stage, consecutive scans overlap as the reference's four nodes do" if pipelined
+                       else "serial: one scan at a time"},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: v[0] / max(1, n_prof_steps) for k, v in sorted(prof.items())}, "profiled_steps": n_prof_steps,
             "loops_detected": int(stats["loops"]), "input_gen_s": gen_s,
