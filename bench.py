@@ -141,8 +141,7 @@ def main():
         sc.make_features(reg, d_q.data_ptr())
         all_gather(all_q, d_q)
         torch.cuda.current_stream().synchronize()
-        for rr in range(world):  # global insertion order: rank 0..N-1 of this step
-            sc.insert_descriptor_device(all_q[rr].data_ptr())
+        sc.insert_descriptors_device(all_q.data_ptr(), world)  # global insertion order: rank 0..N-1 of this step, one launch
         sc_state["n_global"] += world
         # detectLoopClosureID's tree period (Scancontext.cpp:353-365), one query per rank in global order
         limits = []
@@ -151,7 +150,8 @@ def main():
                 sc_state["size_at_rebuild"] = sc_state["n_global"]
             sc_state["counter"] += 1
             limits.append(sc_state["size_at_rebuild"])
-        sc.shard_query_device(all_q.data_ptr(), world, limits[rank], d_rec.data_ptr())
+        sc.shard_query_batch_device(all_q.data_ptr(), limits, d_rec.data_ptr())  # every query against its own tree size
+        sc.sync()
         all_gather(all_rec, d_rec)
         rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query
         cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]

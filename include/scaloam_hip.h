@@ -153,6 +153,11 @@ int scal_sc_insert_features(scal_sc_t* ctx, scal_features_t* feat);
  * and NOT inserted: the sharded search exchanges descriptors first. */
 int scal_sc_make_features(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
 int scal_sc_insert_descriptor_device(scal_sc_t* ctx, const double* d_desc_colmajor);
+/* n (<= 64) device-resident descriptors in global order - the ranks' descriptors of one step after the all-gather - in one
+ * launch and without a host synchronisation; every shard keeps the ones it owns */
+int scal_sc_insert_descriptors_device(scal_sc_t* ctx, const double* d_descs_colmajor, int n);
+/* waits for everything queued on the context's stream (before a collective on another stream reads its device outputs) */
+int scal_sc_sync(scal_sc_t* ctx);
 /* makeScancontext only (no insert) */
 int scal_sc_make_descriptor(scal_sc_t* ctx, const float* xyzi, int n, double* desc_colmajor);
 /* detectLoopClosureID(): query = newest keyframe; reproduces the >=31 gate, the 30-query tree period,
@@ -179,6 +184,9 @@ typedef struct {
 int scal_sc_shard_query(scal_sc_t* ctx, const double* query_desc_colmajor, int global_size_at_rebuild, scal_sc_cand out[3]);
 /* batched form on device pointers: d_queries [nq][1200] doubles, d_out [nq][3] records; synchronous */
 int scal_sc_shard_query_device(scal_sc_t* ctx, const double* d_queries, int nq, int global_size_at_rebuild, scal_sc_cand* d_out);
+/* the same for a batch of nq (<= 64) queries, query q searched against the tree of size limits[q] (host array); three launches,
+ * the 3 * nq records stay in device memory (d_out) and nothing is synchronised: follow with scal_sc_sync */
+int scal_sc_shard_query_batch_device(scal_sc_t* ctx, const double* d_queries, int nq, const int* limits, scal_sc_cand* d_out);
 int scal_sc_merge_candidates(const scal_sc_cand* gathered, int n_records, double dist_thres, scal_sc_result* res);
 
 /* ------------------------------------------------------------------ stage C: scan-to-map

@@ -142,6 +142,7 @@ __global__ void __launch_bounds__(256) k_sc_store(SCSlot from, SCSlot to) {
 // keys / norms of a descriptor supplied by the caller (saveScancontextAndKeys, :236-246)
 __global__ void __launch_bounds__(128) k_sc_keys(const double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
                                                  double* __restrict__ cnorm) {
+    desc += static_cast<size_t>(blockIdx.x) * DESC, rkey += blockIdx.x * NR, skey += blockIdx.x * NS, cnorm += blockIdx.x * NS;  // one descriptor per block
     if (threadIdx.x < NR) {
         const int r = threadIdx.x;
         rkey[r] = static_cast<float>(eigen_sum4(NS, [&](int c) { return desc[r + NR * c]; }) / NS);
@@ -149,6 +150,26 @@ __global__ void __launch_bounds__(128) k_sc_keys(const double* __restrict__ desc
         const int c = threadIdx.x - 64;
         skey[c] = eigen_sum4(NR, [&](int r) { return desc[r + NR * c]; }) / NR;
         cnorm[c] = sqrt(eigen_sum4(NR, [&](int r) { return desc[r + NR * c] * desc[r + NR * c]; }));
+    }
+}
+
+// batch of descriptors (one per block): keys as in k_sc_keys, stored straight into the database slot slots[b] (< 0: not owned)
+struct SCSlotList {
+    int slot[64];
+};
+__global__ void __launch_bounds__(128) k_sc_store_batch(const double* __restrict__ descs, SCSlotList sl, SCSlot db /* slot 0 */) {
+    const int s = sl.slot[blockIdx.x];
+    if (s < 0) return;
+    const double* desc = descs + static_cast<size_t>(blockIdx.x) * DESC;
+    double* od = db.desc + static_cast<size_t>(s) * DESC;
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x) od[i] = desc[i];
+    if (threadIdx.x < NR) {
+        const int r = threadIdx.x;
+        db.rkey[static_cast<size_t>(s) * NR + r] = static_cast<float>(eigen_sum4(NS, [&](int c) { return desc[r + NR * c]; }) / NS);
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) {
+        const int c = threadIdx.x - 64;
+        db.skey[static_cast<size_t>(s) * NS + c] = eigen_sum4(NR, [&](int r) { return desc[r + NR * c]; }) / NR;
+        db.cnorm[static_cast<size_t>(s) * NS + c] = sqrt(eigen_sum4(NR, [&](int r) { return desc[r + NR * c] * desc[r + NR * c]; }));
     }
 }
 
@@ -180,9 +201,13 @@ __device__ __forceinline__ void block_top3(unsigned long long mine, unsigned lon
 
 // local slot s holds global keyframe index s * n_shards + shard
 __global__ void __launch_bounds__(256) k_sc_topk(const float* __restrict__ rkey, const float* __restrict__ query, int n_local, int n_shards,
-                                                 int shard, int global_limit, unsigned long long* __restrict__ block_best) {
+                                                 int shard, int global_limit, unsigned long long* __restrict__ block_best,
+                                                 const int* __restrict__ limits = nullptr) {
     __shared__ unsigned long long smem[16];
     __shared__ float q[NR];
+    // blockIdx.y = query of a batch (its own key, limit and result rows)
+    query += blockIdx.y * NR, block_best += static_cast<size_t>(blockIdx.y) * gridDim.x * 3;
+    if (limits) global_limit = limits[blockIdx.y];
     if (threadIdx.x < NR) q[threadIdx.x] = query[threadIdx.x];
     __syncthreads();
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,6 +323,9 @@ __global__ void __launch_bounds__(256) k_sc_detect(const unsigned long long* __r
                                                    const double* __restrict__ qnorm, int fill_missing_with_zero, SCRec* __restrict__ out) {
     __shared__ unsigned long long smem[16];
     __shared__ unsigned long long top[3];
+    // blockIdx.y = query of a batch
+    block_best += static_cast<size_t>(blockIdx.y) * n_blocks * 3, qdesc += static_cast<size_t>(blockIdx.y) * DESC;
+    qskey += blockIdx.y * NS, qnorm += blockIdx.y * NS, out += blockIdx.y * 3;
     __shared__ double scratch[3][7 * NS];
     unsigned long long mine = ~0ull;
     unsigned long long second = ~0ull, third = ~0ull;
@@ -445,6 +473,13 @@ struct scal_sc {
     int vf_cap = 0;
     hipEvent_t ev = nullptr;
     int lane = 0;
+    // batched shard queries
+    DevBuf<float> bq_rkey;
+    DevBuf<double> bq_skey, bq_norm;
+    DevBuf<unsigned long long> bq_best;
+    DevBuf<int> bq_limits;
+    PinBuf<int> bq_hlimits;
+    int bq_cap = 0, bq_nb = 0;
     int detect_pending = 0;  // 1: search launched, 2: database too small (nothing launched)
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
     SCSlot staging() const { return SCSlot{qdesc.p, qrkey.p, qskey.p, qnorm.p}; }
@@ -696,6 +731,76 @@ extern "C" int scal_sc_shard_query_device(scal_sc_t* c, const double* d_queries,
     }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+// saveScancontextAndKeys for a batch of device-resident descriptors in global order (the N ranks' descriptors of one step):
+// one launch, no host synchronisation; every shard keeps the ones it owns
+extern "C" int scal_sc_insert_descriptors_device(scal_sc_t* c, const double* d_descs, int n) {
+    if (!c || !d_descs || n < 0 || n > 64) {
+        set_error("scal_sc_insert_descriptors_device: bad argument (at most 64 descriptors per call)");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCSlotList sl;
+    int n_local = c->n_local;
+    for (int r = 0; r < 64; ++r) sl.slot[r] = -1;
+    for (int r = 0; r < n; ++r)
+        if (c->owns(c->n_global + r)) {
+            if (n_local >= c->cap) {
+                set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
+                return SCAL_E_CAPACITY;
+            }
+            sl.slot[r] = n_local++;
+        }
+    if (n > 0) hipLaunchKernelGGL(k_sc_store_batch, dim3(n), dim3(128), 0, c->stream, d_descs, sl, c->slot(0));
+    SCAL_HIP(hipGetLastError());
+    c->n_local = n_local;
+    c->n_global += n;
+    return SCAL_OK;
+}
+
+// scal_sc_shard_query_device for a batch: query q uses limits[q] (the tree size at its rebuild, Scancontext.cpp:353-365);
+// three launches for the whole batch, results stay on the device (d_out[3 * nq]), no host synchronisation
+extern "C" int scal_sc_shard_query_batch_device(scal_sc_t* c, const double* d_queries, int nq, const int* limits, scal_sc_cand* d_out) {
+    if (!c || !d_queries || !d_out || !limits || nq < 0 || nq > 64) {
+        set_error("scal_sc_shard_query_batch_device: bad argument (at most 64 queries per call)");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const int nb = std::max(1, div_up(c->n_local, 256));
+    if (c->bq_cap < nq || c->bq_nb < nb) {
+        SCAL_HIP(hipStreamSynchronize(s));
+        const int cq = std::max(nq, 8), cb = std::max(nb, c->bq_nb);
+        SCAL_TRY(c->bq_rkey.alloc((size_t)cq * NR));
+        SCAL_TRY(c->bq_skey.alloc((size_t)cq * NS));
+        SCAL_TRY(c->bq_norm.alloc((size_t)cq * NS));
+        SCAL_TRY(c->bq_best.alloc((size_t)cq * cb * 3));
+        SCAL_TRY(c->bq_limits.alloc(cq));
+        SCAL_TRY(c->bq_hlimits.alloc(64));
+        c->bq_cap = cq, c->bq_nb = cb;
+    }
+    for (int q = 0; q < nq; ++q) c->bq_hlimits.p[q] = limits[q] - 30;  // NUM_EXCLUDE_RECENT
+    SCAL_HIP(hipMemcpyAsync(c->bq_limits.p, c->bq_hlimits.p, sizeof(int) * nq, hipMemcpyHostToDevice, s));
+    if (nq > 0) {
+        hipLaunchKernelGGL(k_sc_keys, dim3(nq), dim3(128), 0, s, d_queries, c->bq_rkey.p, c->bq_skey.p, c->bq_norm.p);
+        hipLaunchKernelGGL(k_sc_topk, dim3(nb, nq), dim3(256), 0, s, c->rkey.p, c->bq_rkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, 0,
+                           c->bq_best.p, c->bq_limits.p);
+        hipLaunchKernelGGL(k_sc_detect, dim3(1, nq), dim3(256), 0, s, c->bq_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, d_queries, c->bq_skey.p,
+                           c->bq_norm.p, 1, reinterpret_cast<SCRec*>(d_out));
+    }
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_sync(scal_sc_t* c) {
+    if (!c) return SCAL_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
     return SCAL_OK;
 }
 

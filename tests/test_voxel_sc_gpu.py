@@ -176,3 +176,58 @@ def test_sc_sharded_equals_single(O, S):
     for sh in shards:
         sh.close()
     single.close()
+
+
+def test_sc_sharded_batch_equals_single(O, S):
+    """The batched multi-GPU form (bench.py --gpus N): per step, N descriptors arrive in global order, every shard inserts the
+    ones it owns in ONE launch and answers all N queries in three launches, each query against its own tree size.  Query q of a
+    step must get the single-database answer the reference would give right after inserting descriptor q."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    G = 4
+    rng = np.random.default_rng(13)
+    steps = 14
+    descs = _random_descs(rng, G * steps)
+    single = S.SCManager(dist_thres=0.3)
+    shards = [S.SCManager(dist_thres=0.3, n_shards=G, shard=s) for s in range(G)]
+    d_q, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_q), G * 1200 * 8) == 0 and hip.hipMalloc(ctypes.byref(d_out), G * 3 * 24) == 0
+    counter, size_at_rebuild, n_global = 0, 0, 0
+    for st in range(steps):
+        batch = descs[st * G:(st + 1) * G]
+        # reference semantics: insert, detect, insert, detect ... in global order
+        refs, limits = [], []
+        for d in batch:
+            single.saveScancontextAndKeys(d)
+            n_global += 1
+            refs.append(single.detectLoopClosureID())
+            if n_global >= 31:
+                if counter % 30 == 0:
+                    size_at_rebuild = n_global
+                counter += 1
+            limits.append(size_at_rebuild)
+        host = np.ascontiguousarray(np.stack([d.T.reshape(-1) for d in batch]), np.float64)  # column-major 20x60 each
+        assert hip.hipMemcpy(d_q, host.ctypes.data, host.nbytes, 1) == 0
+        recs = []
+        for sh in shards:
+            sh.insert_descriptors_device(d_q, G)
+            sh.shard_query_batch_device(d_q, limits, d_out)
+            sh.sync()
+            buf = np.zeros(G * 3 * 24, np.uint8)
+            assert hip.hipMemcpy(buf.ctypes.data, d_out, buf.nbytes, 2) == 0
+            recs.append(buf.reshape(G, 3, 24))
+        for q in range(G):
+            if n_global - (G - 1 - q) < 31:
+                continue
+            cands = [S.SCCand.from_buffer_copy(recs[s][q, j].tobytes()) for s in range(G) for j in range(3)]
+            got = S.merge_candidates(cands, 0.3)
+            # descriptors q+1.. of this step are already in the shards but newer than every tree: they cannot be candidates
+            assert got["loop_id"] == refs[q]["loop_id"] and got["nn_idx"] == refs[q]["nn_idx"], (st, q)
+            assert abs(got["min_dist"] - refs[q]["min_dist"]) <= 1e-12, (st, q)
+    hip.hipFree(d_q), hip.hipFree(d_out)
+    for sh in shards:
+        sh.close()
+    single.close()
