@@ -134,22 +134,16 @@ __global__ void __launch_bounds__(256) k_grid_clear(MapCloud m, int n, MapParams
 }
 
 // ---------------------------------------------------------------------------------------------- association
-struct Knn5 {
-    float d[5];
-    int id[5];
-    float px[5], py[5], pz[5];
-};
 
 // Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE:
 // lanes 0..26 each own a neighbour cell (one round trip for the 27 (count, start) pairs), the candidates are written
 // into a per-wave LDS list as 64-bit (f32 distance bits, map index) keys, and five wave-argmin rounds pick the result.
-// Every lane returns the same Knn5.
+// Every lane returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
 constexpr int KNN_CHUNK = 256;
 __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g,
-                                          float qx, float qy, float qz, unsigned long long* skey, int* spos, Knn5& r) {
+                                          float qx, float qy, float qz, unsigned long long* skey, int* spos, unsigned long long (&bk)[5],
+                                          int (&bp)[5]) {
     const int lane = lane_id();
-    unsigned long long bk[5];
-    int bp[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) bk[k] = ~0ull, bp[k] = -1;
     const int cx = static_cast<int>(floorf(qx)) - mp.ox, cy = static_cast<int>(floorf(qy)) - mp.oy, cz = static_cast<int>(floorf(qz)) - mp.oz;
@@ -216,16 +210,6 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
             bk[0] = c0 ? best : bk[0], bp[0] = c0 ? pos : bp[0];
         }
         __builtin_amdgcn_wave_barrier();
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        if (bp[k] >= 0) {
-            r.d[k] = __uint_as_float(static_cast<unsigned>(bk[k] >> 32));
-            r.id[k] = static_cast<int>(bk[k] & 0xffffffffu);
-            r.px[k] = g.x[bp[k]], r.py[k] = g.y[bp[k]], r.pz[k] = g.z[bp[k]];
-        } else {
-            r.d[k] = 3.4e38f, r.id[k] = 0x7fffffff, r.px[k] = r.py[k] = r.pz[k] = 0.f;
-        }
     }
 }
 
@@ -375,28 +359,39 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams
     __shared__ int spos[4][KNN_CHUNK];
     if (!C->solve_on) return;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const int i = blockIdx.x * 4 + wave_id();
-    if (i >= nc + ns || i >= nb.cap) return;
+    const int n = min(nc + ns, nb.cap);
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-    const bool is_edge = i < nc;
-    const int j = is_edge ? i : i - nc;
-    const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
-    float sel[3];
-    associate_to_map(x7, ox, oy, oz, sel);
-    Knn5 nn;
-    if (is_edge)
-        knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
-    else
-        knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], nn);
     const int lane = lane_id();
-    if (lane < 5) {
-        nb.px[lane * nb.cap + i] = nn.px[lane];
-        nb.py[lane * nb.cap + i] = nn.py[lane];
-        nb.pz[lane * nb.cap + i] = nn.pz[lane];
+    // bounded grid, wave-stride loop over the slots: a grid sized for the capacity would be ~95 % empty workgroups
+    for (int i = blockIdx.x * 4 + wave_id(); i < n; i += gridDim.x * 4) {
+        const bool is_edge = i < nc;
+        const int j = is_edge ? i : i - nc;
+        const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
+        float sel[3];
+        associate_to_map(x7, ox, oy, oz, sel);
+        unsigned long long bk[5];
+        int bp[5];
+        const GridPts& g = is_edge ? cg : sg;
+        if (is_edge)
+            knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], bk, bp);
+        else
+            knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], bk, bp);
+        // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
+        int mine = bp[0];
+#pragma unroll
+        for (int k = 1; k < 5; ++k)
+            if (lane == k) mine = bp[k];
+        if (lane < 5) {
+            const bool have = mine >= 0;
+            nb.px[lane * nb.cap + i] = have ? g.x[mine] : 0.f;
+            nb.py[lane * nb.cap + i] = have ? g.y[mine] : 0.f;
+            nb.pz[lane * nb.cap + i] = have ? g.z[mine] : 0.f;
+        }
+        if (lane == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
+        __builtin_amdgcn_wave_barrier();  // the wave's LDS candidate buffers are reused by its next slot
     }
-    if (lane == 0) nb.d5[i] = nn.d[4];
 }
 
 __global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, MapCounters* C, int outer, FactorSoA f) {
@@ -1148,7 +1143,7 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
     }
     // two outer iterations (:563)
     FactorSoA F = c->factors();
-    const int assoc_blocks = std::max(1, div_up(c->slot_cap, 4));
+    const int assoc_blocks = std::max(1, std::min(2048, div_up(c->slot_cap, 4)));
     for (int outer = 0; outer < 2; ++outer) {
         {
             SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack().cv(), c->surf_stack().cv(), mp, c->grid[0].cnt.p,

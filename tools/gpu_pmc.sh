@@ -2,9 +2,9 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0 > $R/gpurun_out/pmc_fetch.log 2>&1
 echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 > $R/gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0 > $R/gpurun_out/pmc_write.log 2>&1
 echo write rc=$?
 ls $R/gpurun_out/pmc_fetch/* | head; 
 # keep only the per-kernel aggregates (the raw counter CSVs are large)
