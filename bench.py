@@ -309,8 +309,18 @@ def roofline_of(prof, K, c):
         return None
     avg_s = ms / cnt * 1e-3
     ach = per_launch_bytes[name] / avg_s / 1e9
+    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of
+    # this benchmark; bench.py cannot collect counters on itself).  FETCH_SIZE is reported raw, see the file's note.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_v3.json")))["kernels"].get(name)
+        if pmc:
+            traffic = (pmc["fetch_kb_per_dispatch_raw"] + pmc["write_kb_per_dispatch"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": per_launch_bytes[name],
+            "traffic": traffic, "traffic_source": "profiles/r01_pmc_fetch_write_v3.json (bytes per launch, FETCH_SIZE raw + WRITE_SIZE)" if traffic else None,
+            "avg_launch_us": avg_s * 1e6, "launches": cnt, "algorithmic_bytes_per_launch": per_launch_bytes[name],
             "share_of_step": ms / K, "all_kernels_ms_per_step": {k: v[0] / K for k, v in sorted(prof.items())}}
 
 
