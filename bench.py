@@ -136,9 +136,12 @@ def main():
         host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
         return r
 
-    def sc_sharded(reg):
+    def sc_sharded(reg, queued=False):
         """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records)"""
-        sc.make_features(reg, d_q.data_ptr())
+        if queued:
+            sc.sync()  # the descriptor was queued right behind stage A
+        else:
+            sc.make_features(reg, d_q.data_ptr())
         all_gather(all_q, d_q)
         torch.cuda.current_stream().synchronize()
         sc.insert_descriptors_device(all_q.data_ptr(), world)  # global insertion order: rank 0..N-1 of this step, one launch
@@ -191,6 +194,8 @@ def main():
         if world == 1:
             timed("D.insert", sc.insert_features, r_)
             timed("D.detect_enqueue", sc.detect_enqueue)
+        else:
+            timed("D.make", sc.make_features_enqueue, r_, d_q.data_ptr())
         if k + 1 < last:
             timed("A.run_device", regs[(k + 1) % len(regs)].run_device, d_scans[k + 1].data_ptr(), npts[k + 1], 3)
             pipe["a_queued"] = k + 1
@@ -200,7 +205,7 @@ def main():
             account(mst, pipe["loop"])
         timed("C.enqueue", mp.enqueue_features, r_, qw, tw)
         pipe["map_pending"] = True
-        pipe["loop"] = timed("D.detect_collect", sc.detect_collect) if world == 1 else sc_sharded(r_)
+        pipe["loop"] = timed("D.detect_collect", sc.detect_collect) if world == 1 else timed("D.sharded", sc_sharded, r_, True)
 
     def drain():
         if pipe["map_pending"]:

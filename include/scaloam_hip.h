@@ -152,6 +152,8 @@ int scal_sc_insert_features(scal_sc_t* ctx, scal_features_t* feat);
 /* same front end but the 20x60 descriptor is only written to d_desc (device memory, 1200 doubles, column-major)
  * and NOT inserted: the sharded search exchanges descriptors first. */
 int scal_sc_make_features(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
+/* the same without waiting: d_desc is valid after scal_sc_sync */
+int scal_sc_make_features_enqueue(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
 int scal_sc_insert_descriptor_device(scal_sc_t* ctx, const double* d_desc_colmajor);
 /* n (<= 64) device-resident descriptors in global order - the ranks' descriptors of one step after the all-gather - in one
  * launch and without a host synchronisation; every shard keeps the ones it owns */

@@ -681,7 +681,7 @@ extern "C" int scal_sc_insert_features(scal_sc_t* c, scal_features_t* feat) {
     return make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, true);
 }
 
-extern "C" int scal_sc_make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc) {
+static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bool wait) {
     if (!c || !feat || !d_desc) {
         set_error("scal_sc_make_features: null argument");
         return SCAL_E_ARG;
@@ -693,9 +693,11 @@ extern "C" int scal_sc_make_features(scal_sc_t* c, scal_features_t* feat, double
     SCAL_TRY(ds_features(c, feat, &d_n, &cap));
     SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, false));
     SCAL_HIP(hipMemcpyAsync(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    if (wait) SCAL_HIP(hipStreamSynchronize(c->stream));
     return SCAL_OK;
 }
+extern "C" int scal_sc_make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc) { return make_features(c, feat, d_desc, true); }
+extern "C" int scal_sc_make_features_enqueue(scal_sc_t* c, scal_features_t* feat, double* d_desc) { return make_features(c, feat, d_desc, false); }
 
 extern "C" int scal_sc_insert_descriptor_device(scal_sc_t* c, const double* d_desc) {
     if (!c || !d_desc) {
