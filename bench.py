@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
-    ap.add_argument("--ring", type=int, default=3, help="features contexts used in turn by the stage pipeline")
+    ap.add_argument("--side-thread", type=int, default=1, help="queue the side-stream work from a second host thread (0/1)")
+    ap.add_argument("--ring", type=int, default=4, help="features contexts used in turn by the stage pipeline")
     ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
@@ -119,7 +120,7 @@ def main():
         sc.saveScancontextAndKeys(d.T)  # every shard sees every insert and keeps the ones it owns
 
     if world > 1:
-        d_q = torch.zeros(1200, dtype=torch.float64, device="cuda")
+        d_q = [torch.zeros(1200, dtype=torch.float64, device="cuda") for _ in range(2)]  # scan k+1's descriptor is queued early
         all_q = torch.zeros(world, 1200, dtype=torch.float64, device="cuda")
         d_rec = torch.zeros(world * 3 * 24, dtype=torch.uint8, device="cuda")
         all_rec = torch.zeros(world, world * 3 * 24, dtype=torch.uint8, device="cuda")
@@ -136,13 +137,13 @@ def main():
         host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
         return r
 
-    def sc_sharded(reg, queued=False):
+    def sc_sharded(k, queued=False):
         """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records)"""
         if queued:
             sc.sync()  # the descriptor was queued right behind stage A
         else:
-            sc.make_features(reg, d_q.data_ptr())
-        all_gather(all_q, d_q)
+            sc.make_features(reg, d_q[k % 2].data_ptr())
+        all_gather(all_q, d_q[k % 2])
         torch.cuda.current_stream().synchronize()
         sc.insert_descriptors_device(all_q.data_ptr(), world)  # global insertion order: rank 0..N-1 of this step, one launch
         sc_state["n_global"] += world
@@ -176,36 +177,77 @@ def main():
             sc.insert_features(reg)
             r = sc.detectLoopClosureID()
         else:
-            r = sc_sharded(reg)
+            r = sc_sharded(k)
         account(mst, r)
 
     pipe = dict(map_pending=False, loop=None, a_queued=-1)
 
-    def step_pipelined(k, last):
-        """Software pipeline over the stage streams.  Per scan k: B is queued (A(k) was queued one step ahead), then everything
-        that only needs stage A (C's input gather + stack downsample, D's insert + search), then stage A of scan k+1 into
-        the other features context; B's pose is collected, the pose of the PREVIOUS scan's stage C is collected (its map
-        insertion continues behind it), and this scan's stage C is queued."""
+    # A second host thread queues the side-stream work (the library calls release the GIL): the launch calls of one scan
+    # cost the host ~330 us, more than any single stage costs the GPU.
+    import queue
+    import threading
+    side_q, side_done = queue.Queue(), queue.Queue()
+
+    def side_worker():
+        while True:
+            job = side_q.get()
+            if job is None:
+                return
+            try:
+                for fn, args in job:
+                    fn(*args)
+                side_done.put(None)
+            except Exception as e:  # surfaced in the main thread
+                side_done.put(e)
+
+    side_thread = threading.Thread(target=side_worker, daemon=True) if (pipelined and a.side_thread) else None
+    if side_thread:
+        side_thread.start()
+
+    def queue_front(k, last):
+        """everything of scan k that does not need a pose: stage B, the side-stream work, and stage A of scan k+1"""
         r_ = regs[k % len(regs)]
-        if pipe["a_queued"] != k:
+        if pipe["a_queued"] < k:
             timed("A.run_device", r_.run_device, d_scans[k].data_ptr(), npts[k], 3)
-        timed("B.enqueue", od.enqueue_features, r_)
-        timed("C.prefetch", mp.prefetch_features, r_)
+            pipe["a_queued"] = k
+        side = [(mp.prefetch_features, (r_,))]
         if world == 1:
-            timed("D.insert", sc.insert_features, r_)
-            timed("D.detect_enqueue", sc.detect_enqueue)
+            side += [(sc.insert_features, (r_,)), (sc.detect_enqueue, ())]
         else:
-            timed("D.make", sc.make_features_enqueue, r_, d_q.data_ptr())
+            side += [(sc.make_features_enqueue, (r_, d_q[k % 2].data_ptr()))]
+        if side_thread:
+            side_q.put(side)
+        timed("B.enqueue", od.enqueue_features, r_)
+        if not side_thread:
+            for fn, args in side:
+                timed("side." + fn.__name__, fn, *args)
         if k + 1 < last:
             timed("A.run_device", regs[(k + 1) % len(regs)].run_device, d_scans[k + 1].data_ptr(), npts[k + 1], 3)
             pipe["a_queued"] = k + 1
+        pipe["front"] = k
+
+    def step_pipelined(k, last):
+        """Software pipeline over the stage streams.  The front of scan k (stage B, the work that only needs stage A - C's input
+        gather + stack downsample, D's insert + search - and stage A of the next scan) was queued during the previous step.
+        Here: B's pose is collected and the front of scan k+1 is queued at once, so stage B never idles; then the pose of the
+        PREVIOUS scan's stage C is collected (its map insertion continues behind it) and this scan's stage C is queued."""
+        r_ = regs[k % len(regs)]
+        if pipe.get("front", -1) < k:
+            queue_front(k, last)
         qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+        if side_thread:
+            err = timed("side.join", side_done.get)  # scan k's side work is queued (stage C waits for the prefetch event)
+            if err is not None:
+                raise err
+        loop = timed("D.detect_collect", sc.detect_collect) if world == 1 else None
+        if k + 1 < last:
+            queue_front(k + 1, last)
         if pipe["map_pending"]:
             qm, tm, mst = timed("C.collect", mp.collect)
             account(mst, pipe["loop"])
         timed("C.enqueue", mp.enqueue_features, r_, qw, tw)
         pipe["map_pending"] = True
-        pipe["loop"] = timed("D.detect_collect", sc.detect_collect) if world == 1 else timed("D.sharded", sc_sharded, r_, True)
+        pipe["loop"] = loop if world == 1 else timed("D.sharded", sc_sharded, k, True)
 
     def drain():
         if pipe["map_pending"]:

@@ -18,6 +18,7 @@
 // Data layout: SoA x[] y[] z[] intensity[] in HBM (coalesced 4 B/lane loads; the whole scan is < 2 MB and lives
 // in L2).  All f32 arithmetic that feeds a comparison is compiled without FMA contraction.
 #include "common.hpp"
+#include <mutex>
 #include "device_utils.hpp"
 #include "features_dev.hpp"
 #include <cmath>
@@ -677,7 +678,8 @@ struct scal_features {
     bool reader_pending[MAX_READERS] = {};
     hipEvent_t done_ev = nullptr;    // end of the most recent run, recorded on demand
     bool done_recorded = false;
-    bool cross_stream_consumers = false;  // seen once: record done_ev right behind every run, before later main-stream work
+    bool cross_stream_consumers = false;
+    std::mutex ev_mu;  // consumers may register from different host threads  // seen once: record done_ev right behind every run, before later main-stream work
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
     DevBuf<signed char> d_ring;
@@ -715,6 +717,7 @@ FeatDeviceView features_view(scal_features* c) {
 }
 int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     if (consumer_stream == c->stream) return SCAL_OK;
+    std::lock_guard<std::mutex> lk(c->ev_mu);
     if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
     c->cross_stream_consumers = true;
     if (!c->done_recorded) {
@@ -726,6 +729,7 @@ int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
 }
 int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
     if (consumer_stream == c->stream) return SCAL_OK;
+    std::lock_guard<std::mutex> lk(c->ev_mu);
     int slot = -1;
     for (int i = 0; i < scal_features::MAX_READERS && slot < 0; ++i)
         if (c->reader_stream[i] == consumer_stream || c->reader_stream[i] == nullptr) slot = i;
@@ -831,12 +835,14 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     k.thres2 = thres * thres;
     const int nb = max(1, div_up(n, TILE));
     FeatParams* P = c->d_P.p;
+    std::unique_lock<std::mutex> ev_lk(c->ev_mu);
     for (int i = 0; i < scal_features::MAX_READERS; ++i)
         if (c->reader_pending[i]) {  // a consumer on another stream may still be reading the previous scan's outputs
             SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev[i], 0));
             c->reader_pending[i] = false;
         }
     c->done_recorded = false;
+    ev_lk.unlock();
     hipLaunchKernelGGL(k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
     hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
     hipLaunchKernelGGL(k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
@@ -854,10 +860,12 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     hipLaunchKernelGGL(k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->f_sharp.p, c->f_less.p, c->f_flat.p);
     SCAL_HIP(hipGetLastError());
+    ev_lk.lock();
     if (c->cross_stream_consumers) {  // the event must sit right behind stage A, not behind whatever the stream gets next
         SCAL_HIP(hipEventRecord(c->done_ev, s));
         c->done_recorded = true;
     }
+    ev_lk.unlock();
     c->ran = true;
     c->last_n = n;
     return SCAL_OK;

@@ -20,6 +20,7 @@
 //                                      the 5x5x3 valid set keep raw points in arrival order, as the reference does
 //   registration (:845-849)            k_transform_cloud
 #include "common.hpp"
+#include <mutex>
 #include "device_utils.hpp"
 #include "voxel_dev.hpp"
 #include "radix_sort.hpp"
@@ -863,8 +864,17 @@ struct scal_map {
     int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // side stream for scal_map_prefetch_features (lazily acquired)
-    hipEvent_t ev = nullptr, ev_pre = nullptr;
-    scal_features_t* prefetched_from = nullptr;
+    hipEvent_t ev = nullptr;
+    // prefetches queued ahead of their step (at most two: the bench queues scan k+1's before scan k's step starts)
+    static constexpr int NSETS = 3;
+    struct Prefetch {
+        scal_features_t* feat;
+        int set;
+    };
+    std::mutex pf_mu;  // prefetches may come from a second host thread
+    Prefetch pf[2];
+    int n_pf = 0;
+    hipEvent_t ev_pre[NSETS] = {};
     // asynchronous step: pose first (ev_pose), insertion + registration behind it (ev_done)
     hipEvent_t ev_pose = nullptr, ev_done = nullptr;
     bool pose_pending = false, insert_pending = false, insert_try_merge = false, pending_prefetched = false;
@@ -879,10 +889,10 @@ struct scal_map {
     bool have_mp = false;
     // device
     DevBuf<float> aos;  // upload staging
-    // Per-step inputs are double buffered ("sets"): the side stream may gather + downsample scan k+1 (set ^ 1) while scan k's
-    // association and insertion still read set; a step flips `set` when it starts.
+    // Per-step inputs live in a ring of three "sets": the side stream may gather + downsample scans k+1 and k+2 while scan k's
+    // association and insertion still read theirs; a step takes the set its prefetch filled (or the next free one).
     int set = 0;
-    SoAStore corner_in2[2], surf_in2[2], corner_stack2[2], surf_stack2[2];
+    SoAStore corner_in2[NSETS], surf_in2[NSETS], corner_stack2[NSETS], surf_stack2[NSETS];
     SoAStore full_in, full_out;
     SoAStore& corner_in(int st = -1) { return corner_in2[st < 0 ? set : st]; }
     SoAStore& surf_in(int st = -1) { return surf_in2[st < 0 ? set : st]; }
@@ -910,7 +920,7 @@ struct scal_map {
     DevBuf<float> nnx, nny, nnz, nnd5;
     NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
-    DevBuf<MapCounters> d_C2[2];
+    DevBuf<MapCounters> d_C2[NSETS];
     DevBuf<MapCounters>& d_C(int st = -1) { return d_C2[st < 0 ? set : st]; }
     DevBuf<double> d_x0;
     DevBuf<int> d_nfull;
@@ -941,7 +951,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
     const size_t sc = c->scan_cap, mc = c->map_cap;
     A(c->aos.alloc(sc * 4));
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < scal_map::NSETS; ++k) {
         A(c->corner_in2[k].alloc(sc)); A(c->surf_in2[k].alloc(sc)); A(c->corner_stack2[k].alloc(sc)); A(c->surf_stack2[k].alloc(sc));
         A(c->d_C2[k].alloc(1));
     }
@@ -998,7 +1008,8 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
         release_stream(c->cfg.device, 2);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
-    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
+    for (int k = 0; k < scal_map::NSETS; ++k)
+        if (c->ev_pre[k]) (void)hipEventDestroy(c->ev_pre[k]);
     if (c->ev_pose) (void)hipEventDestroy(c->ev_pose);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     delete c;
@@ -1301,9 +1312,12 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     const bool have_full = full_res != nullptr && n_full > 0;
     int nf = have_full ? n_full : 0;
     SCAL_TRY(map_finish(c));  // a pending insertion of an asynchronous step still owns the current set
-    c->set ^= 1;
+    {
+        std::lock_guard<std::mutex> lk(c->pf_mu);
+        c->n_pf = 0;  // queued prefetches belong to a features context: not used by this entry point
+        c->set = (c->set + 1) % scal_map::NSETS;
+    }
     c->pending_prefetched = false;
-    c->prefetched_from = nullptr;
     // n_full lives in pinned-less host memory for the async copy: stage through the counters struct instead
     SCAL_TRY(reset_counters(c, n_corner, n_surf, nf));
     SCAL_HIP(hipStreamSynchronize(s));  // &nf must not be read after return
@@ -1348,19 +1362,25 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, 2));
-    if (!c->ev_pre) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming));
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
+    std::lock_guard<std::mutex> lk(c->pf_mu);
+    if (c->n_pf >= 2) {
+        set_error("scal_map_prefetch_features: two prefetches are already queued ahead of their steps");
+        return SCAL_E_STATE;
+    }
+    // the step in flight owns set `c->set`, queued prefetches own the following ones; this one takes the next in the ring
+    const int nset = ((c->n_pf ? c->pf[c->n_pf - 1].set : c->set) + 1) % scal_map::NSETS;
+    if (!c->ev_pre[nset]) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], hipEventDisableTiming));
     SCAL_TRY(features_wait_done(feat, c->side));
-    // the step in flight owns set `c->set`; this one fills the other set.  The filter scratch (c->vf) is shared with a step that
-    // ran its filters on the main stream: wait for that step in that case.
+    // The filter scratch (c->vf) is shared with a step that ran its filters on the main stream: wait for that step in that case.
     if (c->insert_pending && !c->pending_prefetched) SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_done, 0));
-    const int nset = c->set ^ 1;
     SCAL_TRY(enqueue_gather(c, v, c->side, ls_cap, cap, nset));
     SCAL_TRY(enqueue_stack_filters(c, c->side, ls_cap, cap, nset));
-    SCAL_HIP(hipEventRecord(c->ev_pre, c->side));
+    SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
     SCAL_TRY(features_note_reader(feat, c->side));
-    c->prefetched_from = feat;
+    c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
+    c->n_pf++;
     return SCAL_OK;
 }
 
@@ -1375,12 +1395,22 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
     hipStream_t s = c->stream;
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
-    const bool pre = c->prefetched_from == feat;
-    c->prefetched_from = nullptr;
-    c->set ^= 1;  // this step's set (the one a prefetch filled)
+    bool pre = false;
+    {
+        std::lock_guard<std::mutex> lk(c->pf_mu);
+        if (c->n_pf > 0 && c->pf[0].feat == feat) {  // the oldest queued prefetch belongs to this step: take its set
+            pre = true;
+            c->set = c->pf[0].set;
+            c->pf[0] = c->pf[1];
+            c->n_pf--;
+        } else {  // no (matching) prefetch: drop what was queued and take the next set of the ring
+            c->set = ((c->n_pf ? c->pf[c->n_pf - 1].set : c->set) + 1) % scal_map::NSETS;
+            c->n_pf = 0;
+        }
+    }
     c->pending_prefetched = pre;
     if (pre) {
-        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre, 0));  // inputs gathered and downsampled on the side stream
+        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[c->set], 0));  // inputs gathered and downsampled on the side stream
     } else {
         SCAL_TRY(features_wait_done(feat, s));
         SCAL_TRY(enqueue_gather(c, v, s, ls_cap, cap, c->set));
