@@ -506,11 +506,9 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 4);
-        if (tid == 0) {  // the serial tail runs on a register copy of the state
-            LMState R = L;
-            if (phase == 0) R.log_n_edge[outer] = static_cast<int>(tot[28]), R.log_n_plane[outer] = static_cast<int>(tot[29]);
-            lm_tail(&R, tot, phase);
-            L = R;
+        if (tid == 0) {  // the serial tail works on the LDS copy of the state (a private copy would live in scratch)
+            if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
+            lm_tail(&L, tot, phase);
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 5);

@@ -90,48 +90,70 @@ struct MapCloud {
 };
 
 // ---------------------------------------------------------------------------------------------- grid build
-__global__ void __launch_bounds__(256) k_grid_count(MapCloud m, int n, MapParams mp, int* __restrict__ cnt, int* __restrict__ rank,
-                                                    MapCounters* C, int cls) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Both feature classes per launch: blocks [0, nb0) bin the corner map, the rest the surf map.
+struct GridPts {
+    float *x, *y, *z;
+    int* idx;
+};
+struct GridArgs {
+    MapCloud m[2];
+    int n[2], nb0;
+    int* cnt[2];
+    int* rank[2];
+    int* start[2];
+    GridPts g[2];
+};
+__device__ __forceinline__ bool grid_part(const GridArgs& a, int& cls, int& i) {
+    int b = blockIdx.x;
+    cls = b < a.nb0 ? 0 : 1;
+    if (cls) b -= a.nb0;
+    i = b * blockDim.x + threadIdx.x;
+    return i < a.n[cls];
+}
+
+__global__ void __launch_bounds__(256) k_grid_count(GridArgs a, MapParams mp, MapCounters* C) {
+    int cls, i;
+    const bool in = grid_part(a, cls, i);
+    const MapCloud& m = a.m[cls];
     bool v = false;
-    if (i < n && cube_valid(mp, m.cube[i])) {
+    if (in && cube_valid(mp, m.cube[i])) {
         v = true;
-        rank[i] = atomicAdd(&cnt[grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
-    } else if (i < n) {
-        rank[i] = -1;
+        a.rank[cls][i] = atomicAdd(&a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
+    } else if (in) {
+        a.rank[cls][i] = -1;
     }
     const uint64_t b = __ballot(v);
     if (lane_id() == 0 && b) atomicAdd(&C->n_valid[cls], __popcll(b));
 }
 
-__global__ void __launch_bounds__(256) k_grid_alloc(MapCloud m, int n, MapParams mp, const int* __restrict__ cnt, const int* __restrict__ rank,
-                                                    int* __restrict__ start, MapCounters* C, int cls) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && rank[i] == 0) {
+__global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, MapParams mp, MapCounters* C) {
+    int cls, i;
+    const bool in = grid_part(a, cls, i);
+    const MapCloud& m = a.m[cls];
+    if (in && a.rank[cls][i] == 0) {
         const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-        start[c] = atomicAdd(&C->cursor[cls], cnt[c]);
+        a.start[cls][c] = atomicAdd(&C->cursor[cls], a.cnt[cls][c]);
     }
-    if (i == 0 && cls == 1) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555 (corner grid was counted first)
+    if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555
 }
 
-struct GridPts {
-    float *x, *y, *z;
-    int* idx;
-};
-
-__global__ void __launch_bounds__(256) k_grid_fill(MapCloud m, int n, MapParams mp, const int* __restrict__ rank, const int* __restrict__ start,
-                                                   GridPts g) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && rank[i] >= 0) {
+__global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, MapParams mp) {
+    int cls, i;
+    const bool in = grid_part(a, cls, i);
+    const MapCloud& m = a.m[cls];
+    if (in && a.rank[cls][i] >= 0) {
         const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-        const int p = start[c] + rank[i];
+        const int p = a.start[cls][c] + a.rank[cls][i];
+        const GridPts& g = a.g[cls];
         g.x[p] = m.x[i], g.y[p] = m.y[i], g.z[p] = m.z[i], g.idx[p] = i;
     }
 }
 
-__global__ void __launch_bounds__(256) k_grid_clear(MapCloud m, int n, MapParams mp, const int* __restrict__ rank, int* __restrict__ cnt) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && rank[i] >= 0) cnt[grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
+__global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, MapParams mp) {
+    int cls, i;
+    const bool in = grid_part(a, cls, i);
+    const MapCloud& m = a.m[cls];
+    if (in && a.rank[cls][i] >= 0) a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------- association
@@ -586,6 +608,7 @@ __global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* _
 // points - raises MapCounters::merge_fail and the host redoes the insertion with the full sort.
 constexpr int MERGE_MAX = 8192;
 constexpr int MERGE_IDX_BITS = 13;
+constexpr int MERGE_SAMPLES = 4096;  // old keys staged in LDS for the two-level lookup
 
 struct MergeNew {            // per class, MERGE_MAX entries
     float *x, *y, *z, *w;    // new points in the map frame, arrival order
@@ -651,6 +674,7 @@ __global__ void __launch_bounds__(256) k_merge_keys(MergeArgs a, const LMState* 
 __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters* C) {
     extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX keys
     __shared__ unsigned char s_hm[MERGE_MAX];
+    __shared__ unsigned long long s_samp[MERGE_SAMPLES];
     __shared__ int s_scan[17];
     const int cls = blockIdx.x;
     const MergeNew nw = a.nw[cls];
@@ -659,6 +683,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
     const int n_old = a.n_old[cls];
     const unsigned long long* okeys = a.okeys[cls];
     const int np2 = max(512, next_pow2(n_new));
+    if (cls == 1 && tid == 0) SCAL_STAMP(0);
     int mine = 0;
     for (int t = tid; t < np2; t += 1024) {
         unsigned long long k = ~0ull;
@@ -670,7 +695,9 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
     }
     int n_eff = 0;
     block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
+    if (cls == 1 && tid == 0) SCAL_STAMP(1);
     block_sort_u64(sk, np2, n_new);
+    if (cls == 1 && tid == 0) SCAL_STAMP(2);
     // heads + lookups; element t = e * 1024 + tid, so the eight binary searches of a thread advance in lock step
     constexpr int PER = MERGE_MAX / 1024;
     unsigned long long key[PER];
@@ -686,6 +713,28 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
             head[e] = nom[e] || t == 0 || (sk[t - 1] >> MERGE_IDX_BITS) != key[e];
             if (head[e] && !nom[e]) hi[e] = n_old;       // lower bound among the old keys
             if (nom[e]) lo[e] = hi[e] = n_old;           // behind every old point (NOMERGE is the largest old key)
+        }
+    }
+    if (cls == 1 && tid == 0) SCAL_STAMP(3);
+    // Two-level lower bound: every `stride`-th old key is staged in LDS (one coalesced pass), the search over the samples
+    // runs at LDS latency and leaves a window of <= stride old keys for the last few global steps.
+    int stride = 32;
+    while ((n_old + stride - 1) / stride > MERGE_SAMPLES) stride <<= 1;
+    const int n_samp = (n_old + stride - 1) / stride;
+    for (int j = tid; j < n_samp; j += 1024) s_samp[j] = okeys[static_cast<size_t>(j) * stride];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        if (lo[e] < hi[e]) {  // heads that need a lookup
+            int a = 0, b = n_samp;  // number of samples < key
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (s_samp[mid] < key[e]) a = mid + 1;
+                else b = mid;
+            }
+            lo[e] = a > 0 ? (a - 1) * stride + 1 : 0;
+            hi[e] = min(n_old, a * stride);
+            if (lo[e] > hi[e]) lo[e] = hi[e];
         }
     }
     for (int step = 0; step < 32; ++step) {
@@ -711,6 +760,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
         }
     }
     __syncthreads();
+    if (cls == 1 && tid == 0) SCAL_STAMP(4);
     // inserted runs in front of every sorted position
     const int c0 = min(n_eff, tid * PER), c1 = min(n_eff, c0 + PER);
     int ins = 0;
@@ -723,6 +773,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
         nw.hm[t] = s_hm[t];
         nw.sorted[t] = sk[t];
     }
+    if (cls == 1 && tid == 0) SCAL_STAMP(5);
     if (tid == 0) {
         nw.pre[n_eff] = total;
         C->merge_neff[cls] = n_eff;
@@ -1142,16 +1193,19 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
 
     if (!filters_done) SCAL_TRY(enqueue_stack_filters(c, s, n_corner_bound, n_surf_bound, c->set));
 
-    // cell grids over the valid cubes
+    // cell grids over the valid cubes (both classes per launch)
+    GridArgs ga;
     for (int k = 0; k < 2; ++k) {
         MapStore& M = c->map[k];
         GridStore& G = c->grid[k];
-        const int nb = std::max(1, div_up(M.n, 256));
-        MapCloud mc = M.cloud(M.cur);
-        hipLaunchKernelGGL(k_grid_count, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.cnt.p, G.rank.p, C, k);
-        hipLaunchKernelGGL(k_grid_alloc, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.cnt.p, G.rank.p, G.start.p, C, k);
-        hipLaunchKernelGGL(k_grid_fill, dim3(nb), dim3(256), 0, s, mc, M.n, mp, G.rank.p, G.start.p, G.pts());
+        ga.m[k] = M.cloud(M.cur), ga.n[k] = M.n;
+        ga.cnt[k] = G.cnt.p, ga.rank[k] = G.rank.p, ga.start[k] = G.start.p, ga.g[k] = G.pts();
     }
+    ga.nb0 = std::max(1, div_up(c->map[0].n, 256));
+    const int grid_blocks = ga.nb0 + std::max(1, div_up(c->map[1].n, 256));
+    hipLaunchKernelGGL(k_grid_count, dim3(grid_blocks), dim3(256), 0, s, ga, mp, C);
+    hipLaunchKernelGGL(k_grid_alloc, dim3(grid_blocks), dim3(256), 0, s, ga, mp, C);
+    hipLaunchKernelGGL(k_grid_fill, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
     // two outer iterations (:563)
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(2048, div_up(c->slot_cap, 4)));
@@ -1175,11 +1229,7 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
     SCAL_HIP(hipEventRecord(c->ev_pose, s));
     c->pose_pending = true;
     // restore the zero invariant of the cell counters
-    for (int k = 0; k < 2; ++k) {
-        MapStore& M = c->map[k];
-        const int nb = std::max(1, div_up(M.n, 256));
-        hipLaunchKernelGGL(k_grid_clear, dim3(nb), dim3(256), 0, s, M.cloud(M.cur), M.n, mp, c->grid[k].rank.p, c->grid[k].cnt.p);
-    }
+    hipLaunchKernelGGL(k_grid_clear, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
     // insert + re-filter (:738-802)
     const bool try_merge = c->merge_insert && window_same && c->map[0].n + MERGE_MAX <= c->map_cap && c->map[1].n + MERGE_MAX <= c->map_cap;
     if (try_merge) {
