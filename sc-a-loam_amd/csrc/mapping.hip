@@ -112,6 +112,9 @@ __device__ __forceinline__ bool grid_part(const GridArgs& a, int& cls, int& i) {
 }
 
 __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, MapParams mp, MapCounters* C) {
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
     int cls, i;
     const bool in = grid_part(a, cls, i);
     const MapCloud& m = a.m[cls];
@@ -122,18 +125,31 @@ __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, MapParams mp, Ma
     } else if (in) {
         a.rank[cls][i] = -1;
     }
+    // one global atomic per workgroup: a per-wave atomic on the same word was most of this kernel's time
     const uint64_t b = __ballot(v);
-    if (lane_id() == 0 && b) atomicAdd(&C->n_valid[cls], __popcll(b));
+    if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
 }
 
+// every non-empty cell gets a slice of the point pool: the cells' sizes are summed per workgroup (the point with rank 0
+// speaks for its cell), one cursor atomic per workgroup
 __global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, MapParams mp, MapCounters* C) {
+    __shared__ int s_scan[17];
+    __shared__ int s_base;
     int cls, i;
     const bool in = grid_part(a, cls, i);
     const MapCloud& m = a.m[cls];
+    int c = -1, mine = 0;
     if (in && a.rank[cls][i] == 0) {
-        const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-        a.start[cls][c] = atomicAdd(&C->cursor[cls], a.cnt[cls][c]);
+        c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
+        mine = a.cnt[cls][c];
     }
+    int total = 0;
+    const int off = block_exclusive_scan(mine, s_scan, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&C->cursor[cls], total) : 0;
+    __syncthreads();
+    if (c >= 0) a.start[cls][c] = s_base + off;
     if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555
 }
 
