@@ -180,7 +180,8 @@ def main():
             r = sc_sharded(k)
         account(mst, r)
 
-    pipe = dict(map_pending=False, loop=None, a_queued=-1)
+    pipe = dict(map_pending=False, loop=None, a_queued=-1, accounts=[])
+    PENDING = object()
 
     # A second host thread queues the side-stream work (the library calls release the GIL): the launch calls of one scan
     # cost the host ~330 us, more than any single stage costs the GPU.
@@ -204,6 +205,35 @@ def main():
     if side_thread:
         side_thread.start()
 
+    # N > 1: the sharded ScanContext step blocks on two collectives and a few synchronisations per scan; a third host thread
+    # runs it (same order on every rank) so that stages A-C of the following scans keep being queued meanwhile.
+    xchg_q, loop_q = queue.Queue(), queue.Queue()
+
+    def xchg_worker():
+        torch.cuda.set_device(local)
+        while True:
+            job = xchg_q.get()
+            if job is None:
+                return
+            k, r_ = job
+            try:
+                sc.make_features_enqueue(r_, d_q[k % 2].data_ptr())
+                loop_q.put(sc_sharded(k, True))
+            except Exception as e:
+                loop_q.put(e)
+
+    xchg_thread = threading.Thread(target=xchg_worker, daemon=True) if (pipelined and world > 1) else None
+    if xchg_thread:
+        xchg_thread.start()
+
+    def loop_result(v):
+        if v is not PENDING:
+            return v
+        r = loop_q.get()
+        if isinstance(r, Exception):
+            raise r
+        return r
+
     def queue_front(k, last):
         """everything of scan k that does not need a pose: stage B, the side-stream work, and stage A of scan k+1"""
         r_ = regs[k % len(regs)]
@@ -214,7 +244,7 @@ def main():
         if world == 1:
             side += [(sc.insert_features, (r_,)), (sc.detect_enqueue, ())]
         else:
-            side += [(sc.make_features_enqueue, (r_, d_q[k % 2].data_ptr()))]
+            xchg_q.put((k, r_))
         if side_thread:
             side_q.put(side)
         timed("B.enqueue", od.enqueue_features, r_)
@@ -244,16 +274,22 @@ def main():
             queue_front(k + 1, last)
         if pipe["map_pending"]:
             qm, tm, mst = timed("C.collect", mp.collect)
-            account(mst, pipe["loop"])
+            pipe["accounts"].append((mst, pipe["loop"]))
+            while len(pipe["accounts"]) > 2:  # the exchange thread may lag two scans behind (their features contexts are still intact)
+                m_, l_ = pipe["accounts"].pop(0)
+                account(m_, timed("D.loop_result", loop_result, l_))
         timed("C.enqueue", mp.enqueue_features, r_, qw, tw)
         pipe["map_pending"] = True
-        pipe["loop"] = loop if world == 1 else timed("D.sharded", sc_sharded, k, True)
+        pipe["loop"] = loop if world == 1 else PENDING
 
     def drain():
         if pipe["map_pending"]:
             qm, tm, mst = mp.collect()
-            account(mst, pipe["loop"])
+            pipe["accounts"].append((mst, pipe["loop"]))
             pipe["map_pending"] = False
+        for m_, l_ in pipe["accounts"]:
+            account(m_, loop_result(l_))
+        pipe["accounts"] = []
         mp.finish()
 
     step = step_pipelined if pipelined else (lambda k, last: step_serial(k))
