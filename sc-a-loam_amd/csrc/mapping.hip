@@ -175,13 +175,14 @@ __global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, MapParams mp) {
 // ---------------------------------------------------------------------------------------------- association
 
 // Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE:
-// lanes 0..26 each own a neighbour cell (one round trip for the 27 (count, start) pairs), the candidates are written
-// into a per-wave LDS list as 64-bit (f32 distance bits, map index) keys, and five wave-argmin rounds pick the result.
+// lanes 0..26 each own a neighbour cell (one round trip for the 27 (count, start) pairs); the candidates of all cells form
+// one virtual list that the 64 lanes read side by side (lane j finds the cell of candidate j from the cells' running
+// counts, 27 uniform compares), so a chunk of 256 candidates costs one more round trip; their 64-bit (f32 distance bits,
+// map index) keys stay in registers and five wave-argmin rounds per chunk pick the result.
 // Every lane returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
 constexpr int KNN_CHUNK = 256;
 __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g,
-                                          float qx, float qy, float qz, unsigned long long* skey, int* spos, unsigned long long (&bk)[5],
-                                          int (&bp)[5]) {
+                                          float qx, float qy, float qz, unsigned long long (&bk)[5], int (&bp)[5]) {
     const int lane = lane_id();
 #pragma unroll
     for (int k = 0; k < 5; ++k) bk[k] = ~0ull, bp[k] = -1;
@@ -198,30 +199,28 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
         }
     }
     const int incl = wave_inclusive_scan(my_cnt);
-    const int off = incl - my_cnt;
+    const int rel = my_start - (incl - my_cnt);  // grid position of candidate j of my cell = rel + j
     const int T = __shfl(incl, 63, 64);
     for (int base = 0; base < T; base += KNN_CHUNK) {
-        for (int k = 0; k < my_cnt; ++k) {
-            const int j = off + k - base;
-            if (j >= 0 && j < KNN_CHUNK) {
-                const int t = my_start + k;
+        unsigned long long k0[4];
+        int p0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = base + lane + 64 * u;
+            int c = 0;  // cell of candidate j: the first one whose running count exceeds j
+#pragma unroll
+            for (int cc = 0; cc < 26; ++cc) c += __builtin_amdgcn_readlane(incl, cc) <= j ? 1 : 0;
+            const int t = __shfl(rel, c, 64) + j;
+            k0[u] = ~0ull, p0[u] = -1;
+            if (j < T) {
                 // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
                 const float dx = qx - g.x[t], dy = qy - g.y[t], dz = qz - g.z[t];
                 float dist = dx * dx;
                 dist += dy * dy;
                 dist += dz * dz;
-                skey[j] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(g.idx[t]);
-                spos[j] = t;
+                k0[u] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(g.idx[t]);
+                p0[u] = t;
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const int m = min(KNN_CHUNK, T - base);
-        unsigned long long k0[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = lane + 64 * u;
-            k0[u] = j < m ? skey[j] : ~0ull;
         }
         for (int round = 0; round < 5; ++round) {
             unsigned long long mine = k0[0];
@@ -233,11 +232,15 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
             if (best == ~0ull) break;
             const uint64_t own = __ballot(mine == best);
             const int owner = __ffsll(static_cast<long long>(own)) - 1;
-            const int pos = __shfl(spos[min(lane + 64 * mu, KNN_CHUNK - 1)], owner, 64);
+            int pm = p0[0];  // compile-time indices: the candidate list stays in registers
+#pragma unroll
+            for (int u = 1; u < 4; ++u)
+                if (mu == u) pm = p0[u];
+            const int pos = __shfl(pm, owner, 64);
             if (lane == owner) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (u == mu) k0[u] = ~0ull;  // compile-time indices: the candidate list stays in registers
+                    if (u == mu) k0[u] = ~0ull;
             }
             if (!(best < bk[4])) break;  // chunk keys come out ascending: nothing smaller is left in this chunk
             // insert (best, pos) into the running ascending list, branch-free and statically indexed
@@ -248,7 +251,6 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
             bk[1] = c0 ? bk[0] : (c1 ? best : bk[1]), bp[1] = c0 ? bp[0] : (c1 ? pos : bp[1]);
             bk[0] = c0 ? best : bk[0], bp[0] = c0 ? pos : bp[0];
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -394,8 +396,6 @@ struct NNBuf {
 __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
                                                    GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
                                                    const LMState* __restrict__ st, const MapCounters* __restrict__ C, NNBuf nb) {
-    __shared__ unsigned long long skey[4][KNN_CHUNK];
-    __shared__ int spos[4][KNN_CHUNK];
     if (!C->solve_on) return;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
     const int n = min(nc + ns, nb.cap);
@@ -414,9 +414,9 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams
         int bp[5];
         const GridPts& g = is_edge ? cg : sg;
         if (is_edge)
-            knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], bk, bp);
+            knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], bk, bp);
         else
-            knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], skey[wave_id()], spos[wave_id()], bk, bp);
+            knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], bk, bp);
         // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
         int mine = bp[0];
 #pragma unroll
@@ -429,7 +429,6 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams
             nb.pz[lane * nb.cap + i] = have ? g.z[mine] : 0.f;
         }
         if (lane == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
-        __builtin_amdgcn_wave_barrier();  // the wave's LDS candidate buffers are reused by its next slot
     }
 }
 
