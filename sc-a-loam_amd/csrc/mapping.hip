@@ -92,8 +92,7 @@ struct MapCloud {
 // ---------------------------------------------------------------------------------------------- grid build
 // Both feature classes per launch: blocks [0, nb0) bin the corner map, the rest the surf map.
 struct GridPts {
-    float *x, *y, *z;
-    int* idx;
+    float4* p;  // (x, y, z, map index as bits): one 16-byte gather per candidate instead of four 4-byte ones
 };
 struct GridArgs {
     MapCloud m[2];
@@ -161,7 +160,7 @@ __global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, MapParams mp) {
         const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
         const int p = a.start[cls][c] + a.rank[cls][i];
         const GridPts& g = a.g[cls];
-        g.x[p] = m.x[i], g.y[p] = m.y[i], g.z[p] = m.z[i], g.idx[p] = i;
+        g.p[p] = make_float4(m.x[i], m.y[i], m.z[i], __int_as_float(i));
     }
 }
 
@@ -214,11 +213,12 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
             k0[u] = ~0ull, p0[u] = -1;
             if (j < T) {
                 // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
-                const float dx = qx - g.x[t], dy = qy - g.y[t], dz = qz - g.z[t];
+                const float4 pt = g.p[t];
+                const float dx = qx - pt.x, dy = qy - pt.y, dz = qz - pt.z;
                 float dist = dx * dx;
                 dist += dy * dy;
                 dist += dz * dz;
-                k0[u] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(g.idx[t]);
+                k0[u] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(__float_as_int(pt.w));
                 p0[u] = t;
             }
         }
@@ -424,9 +424,10 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams
             if (lane == k) mine = bp[k];
         if (lane < 5) {
             const bool have = mine >= 0;
-            nb.px[lane * nb.cap + i] = have ? g.x[mine] : 0.f;
-            nb.py[lane * nb.cap + i] = have ? g.y[mine] : 0.f;
-            nb.pz[lane * nb.cap + i] = have ? g.z[mine] : 0.f;
+            const float4 pt = have ? g.p[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
+            nb.px[lane * nb.cap + i] = pt.x;
+            nb.py[lane * nb.cap + i] = pt.y;
+            nb.pz[lane * nb.cap + i] = pt.z;
         }
         if (lane == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
     }
@@ -915,9 +916,8 @@ struct MapStore {
 
 struct GridStore {
     DevBuf<int> cnt, start, rank;
-    SoAStore g;  // only x,y,z used
-    DevBuf<int> idx;
-    GridPts pts() { return GridPts{g.x.p, g.y.p, g.z.p, idx.p}; }
+    DevBuf<float4> g;
+    GridPts pts() { return GridPts{g.p}; }
 };
 
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
@@ -1029,7 +1029,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
             A(c->map[k].cube[b].alloc(mc));
         }
         A(c->grid[k].cnt.alloc(GCELLS)); A(c->grid[k].start.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
-        A(c->grid[k].g.x.alloc(mc)); A(c->grid[k].g.y.alloc(mc)); A(c->grid[k].g.z.alloc(mc)); A(c->grid[k].idx.alloc(mc));
+        A(c->grid[k].g.alloc(mc));
     }
     A(c->sorter.init(c->map_cap));
     A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
