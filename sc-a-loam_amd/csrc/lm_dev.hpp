@@ -426,7 +426,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         const int phase = round ? 1 : 0;
         if (phase && L.done) break;  // identical in every workgroup
         rounds = round + 1;
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 0);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 0);
         double xl[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) xl[k] = phase ? L.cand[k] : L.x[k];
@@ -443,7 +443,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
                 acc[29] += f.kind[i] == 0 ? 0.0 : 1.0;  // association kernels
             }
         }
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 1);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 1);
         // wave reduction through LDS: conflict-free stores per lane, then lane k sums row k in lane order (fixed order =>
         // reproducible).  Six dependent cross-lane shuffle steps for each of the doubles would be the slow part otherwise.
         {
@@ -465,7 +465,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             __hip_atomic_store(&mine[tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 2);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 2);
         if (tid == 0) {  // grid barrier
             __hip_atomic_fetch_add(&sync->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // data already written through
             const unsigned target = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(round + 1);
@@ -486,7 +486,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             __syncthreads();
             break;
         }
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 3);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 3);
         {   // sum the per-workgroup partials: 8 groups of workgroups in parallel (independent sc1 loads), fixed order
             double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
             const double* all = partials + static_cast<size_t>(round & 1) * LM_GRID * LM_NACC;
@@ -505,13 +505,13 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             }
         }
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 4);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 4);
         if (tid == 0) {  // the serial tail works on the LDS copy of the state (a private copy would live in scratch)
             if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
             lm_tail(&L, tot, phase);
         }
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0 && round < 5) SCAL_STAMP(round * 6 + 5);
+        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 5);
     }
     if (blockIdx.x == 0 && tid == 0) {
         L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;

@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
     const int n_old = a.n_old[cls];
     const unsigned long long* okeys = a.okeys[cls];
     const int np2 = max(512, next_pow2(n_new));
-    if (cls == 1 && tid == 0) SCAL_STAMP(0);
+    if (cls == 1 && tid == 0) SCAL_STAMP(26);
     int mine = 0;
     for (int t = tid; t < np2; t += 1024) {
         unsigned long long k = ~0ull;
@@ -711,9 +711,9 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
     }
     int n_eff = 0;
     block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
-    if (cls == 1 && tid == 0) SCAL_STAMP(1);
+    if (cls == 1 && tid == 0) SCAL_STAMP(27);
     block_sort_u64(sk, np2, n_new);
-    if (cls == 1 && tid == 0) SCAL_STAMP(2);
+    if (cls == 1 && tid == 0) SCAL_STAMP(28);
     // heads + lookups; element t = e * 1024 + tid, so the eight binary searches of a thread advance in lock step
     constexpr int PER = MERGE_MAX / 1024;
     unsigned long long key[PER];
@@ -731,7 +731,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
             if (nom[e]) lo[e] = hi[e] = n_old;           // behind every old point (NOMERGE is the largest old key)
         }
     }
-    if (cls == 1 && tid == 0) SCAL_STAMP(3);
+    if (cls == 1 && tid == 0) SCAL_STAMP(29);
     // Two-level lower bound: every `stride`-th old key is staged in LDS (one coalesced pass), the search over the samples
     // runs at LDS latency and leaves a window of <= stride old keys for the last few global steps.
     int stride = 32;
@@ -776,7 +776,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
         }
     }
     __syncthreads();
-    if (cls == 1 && tid == 0) SCAL_STAMP(4);
+    if (cls == 1 && tid == 0) SCAL_STAMP(30);
     // inserted runs in front of every sorted position
     const int c0 = min(n_eff, tid * PER), c1 = min(n_eff, c0 + PER);
     int ins = 0;
@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters
         nw.hm[t] = s_hm[t];
         nw.sorted[t] = sk[t];
     }
-    if (cls == 1 && tid == 0) SCAL_STAMP(5);
+    if (cls == 1 && tid == 0) SCAL_STAMP(31);
     if (tid == 0) {
         nw.pre[n_eff] = total;
         C->merge_neff[cls] = n_eff;

@@ -18,8 +18,8 @@ for k in range(8):
     qlc, tlc, qw, tw, st = od.step_features(reg)
     qm, tm, ms = mp.process_features(reg, qw, tw)
     lib.scal_debug_stamps_map(buf)
-    st = np.array(buf[:30], dtype=np.int64).reshape(5, 6)
+    st = np.array(buf[:24], dtype=np.int64).reshape(4, 6)
     if k >= 4:
-        for r in range(5):
+        for r in range(4):
             d = np.diff(st[r]) * 0.01
             print(k, 'round', r, ' '.join(f'{n}={v:.2f}' for n, v in zip(names, d)), 'total', (st[r, 5] - st[r, 0]) * 0.01, 'blocks', list(ms.n_edge), list(ms.n_plane), list(ms.lm_iters))

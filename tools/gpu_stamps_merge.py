@@ -18,6 +18,6 @@ for k in range(8):
     qlc, tlc, qw, tw, st = od.step_features(reg)
     qm, tm, ms = mp.process_features(reg, qw, tw)
     lib.scal_debug_stamps_map(buf)
-    st = np.array(buf[:6], dtype=np.int64)
+    st = np.array(buf[26:32], dtype=np.int64)
     if k >= 3:
         print(k, ' '.join(f'{n}={v:.2f}' for n, v in zip(names, np.diff(st) * 0.01)), 'total', (st[5] - st[0]) * 0.01, 'stack', ms.n_surf_stack, 'map', ms.n_map_surf_total, 'path', ms.insert_path)
