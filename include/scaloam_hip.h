@@ -223,7 +223,8 @@ int scal_map_step(scal_map_t* ctx, const float* corner_last, int n_corner, const
 int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom,
                            double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
 /* Optional: start the pose-independent part of the next scal_map_step_features(ctx, feat, ...) - input gather and the stack
- * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately. */
+ * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately.  Up to two
+ * prefetches may be queued ahead of their steps (three rotating input sets); steps consume them in order. */
 int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
 /* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns as soon as the optimised pose is on
  * the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it - the next enqueue,
