@@ -521,6 +521,24 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
     }
 }
 
+// Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
+// memory instead of one blit kernel per hipMemcpyAsync.  The host reads them after waiting on an event recorded behind this.
+static __global__ void __launch_bounds__(256) k_publish(const void* a, void* host_a, int words_a, const void* b, void* host_b, int words_b) {
+    const unsigned* sa = static_cast<const unsigned*>(a);
+    unsigned* da = static_cast<unsigned*>(host_a);
+    for (int i = threadIdx.x; i < words_a; i += blockDim.x) da[i] = sa[i];
+    const unsigned* sb = static_cast<const unsigned*>(b);
+    unsigned* db = static_cast<unsigned*>(host_b);
+    for (int i = threadIdx.x; i < words_b; i += blockDim.x) db[i] = sb[i];
+}
+template <class A, class B>
+inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* host_b) {
+    static_assert(sizeof(A) % 4 == 0 && sizeof(B) % 4 == 0, "word copies");
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, static_cast<const void*>(a), static_cast<void*>(host_a),
+                       a ? static_cast<int>(sizeof(A) / 4) : 0, static_cast<const void*>(b), static_cast<void*>(host_b),
+                       b ? static_cast<int>(sizeof(B) / 4) : 0);
+}
+
 // host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
                             int outer) {

@@ -645,6 +645,8 @@ struct MergeArgs {
     MergeNew nw[2];
     int nbo[2];                    // blocks over the old points
     int cap;
+    int* grid_cnt[2];              // cell counters of the neighbour grid: restored to zero here (saves a launch)
+    const int* grid_rank[2];
 };
 constexpr int MERGE_NEW_BLOCKS = MERGE_MAX / 256;
 
@@ -663,6 +665,7 @@ __global__ void __launch_bounds__(256) k_merge_keys(MergeArgs a, const LMState* 
         if (i >= a.n_old[cls]) return;
         const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
         a.okeys[cls][i] = k;
+        if (a.grid_rank[cls][i] >= 0) a.grid_cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;  // zero invariant of the cell grid
         bool bad = k == ~0ull;
         if (i > 0) {
             const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
@@ -1239,14 +1242,13 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
     }
     // the pose and the statistics known so far go to the host now; the map update follows behind
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_C1.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    launch_publish(s, st, c->h_st.p, C, c->h_C1.p);
     SCAL_HIP(hipEventRecord(c->ev_pose, s));
     c->pose_pending = true;
-    // restore the zero invariant of the cell counters
-    hipLaunchKernelGGL(k_grid_clear, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
     // insert + re-filter (:738-802)
     const bool try_merge = c->merge_insert && window_same && c->map[0].n + MERGE_MAX <= c->map_cap && c->map[1].n + MERGE_MAX <= c->map_cap;
+    // restore the zero invariant of the cell counters (the merge insert does it in its key kernel)
+    if (!try_merge) hipLaunchKernelGGL(k_grid_clear, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
     if (try_merge) {
         MergeArgs a;
         for (int k = 0; k < 2; ++k) {
@@ -1259,6 +1261,7 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
             a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
             a.nw[k] = c->merge_new(k);
             a.nbo[k] = std::max(1, div_up(M.n, 256));
+            a.grid_cnt[k] = c->grid[k].cnt.p, a.grid_rank[k] = c->grid[k].rank.p;
         }
         a.cap = c->map_cap;
         const int grid = a.nbo[0] + a.nbo[1] + 2 * MERGE_NEW_BLOCKS;
@@ -1278,8 +1281,8 @@ static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom
         const int nb = std::max(1, div_up(c->scan_cap, 256));
         hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, full_view, d_n_full, c->scan_cap, st, c->full_out.v());
     }
+    launch_publish(s, C, c->h_C.p, static_cast<const MapCounters*>(nullptr), static_cast<MapCounters*>(nullptr));
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipEventRecord(c->ev_done, s));
     c->insert_pending = true, c->insert_try_merge = try_merge, c->pend_mp = mp;
     return SCAL_OK;

@@ -498,8 +498,8 @@ int odom_enqueue(scal_odom* c) {
         c->tab_cur ^= 1;
     }
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(OdomCounters), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(c->h_st.p, st, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    launch_publish(s, st, c->h_st.p, static_cast<const OdomCounters*>(C), c->h_C.p);
+    SCAL_HIP(hipGetLastError());
     c->pending = true, c->pending_solve = solve;
     return SCAL_OK;
 }
