@@ -263,6 +263,28 @@ int scal_odom_enqueue_features(scal_odom_t* ctx, scal_features_t* feat);
 int scal_odom_collect(scal_odom_t* ctx, double* q_last_curr, double* t_last_curr, double* q_w_curr, double* t_w_curr,
                       scal_odom_stats* stats);
 
+/* ------------------------------------------------------------------ offline dense map merge
+ * Replaces the loop body of utils/python/makeMergedMap.py:83-133: keyframe cloud x SE(3) pose -> global frame (f64), removal of
+ * points whose LOCAL range is <= near_thres (:109-116, 2 m in the script), concatenation in keyframe order, f32 xyzi out
+ * (:145-147).  In-process analogues: local2global (laserPosegraphOptimization.cpp:338-359), transformPointCloud (:446-470). */
+typedef struct {
+    long long max_points;  /* capacity of the merged map */
+    int max_frame_points;  /* largest keyframe given to scal_mapmerge_add */
+    int device;
+} scal_mapmerge_config;
+typedef struct scal_mapmerge scal_mapmerge_t;
+int scal_mapmerge_create(const scal_mapmerge_config* cfg, scal_mapmerge_t** ctx);
+void scal_mapmerge_destroy(scal_mapmerge_t* ctx);
+int scal_mapmerge_reset(scal_mapmerge_t* ctx);
+/* one keyframe: xyzi host records, pose12 = one line of optimized_poses.txt (row-major top 3x4 of the SE(3) matrix, :48-56) */
+int scal_mapmerge_add(scal_mapmerge_t* ctx, const float* xyzi, int n, const double* pose12, double near_thres);
+/* n_frames keyframes already in device memory, back to back: frame f = records [offsets[f], offsets[f+1]) (host arrays) */
+int scal_mapmerge_add_batch_device(scal_mapmerge_t* ctx, const float* d_xyzi, const int* offsets, const double* poses12,
+                                   int n_frames, double near_thres);
+long long scal_mapmerge_size(scal_mapmerge_t* ctx);                                 /* points merged so far (waits), <0 = error */
+int scal_mapmerge_download(scal_mapmerge_t* ctx, float* out_xyzi, long long cap_points);
+const float* scal_mapmerge_device_points(scal_mapmerge_t* ctx);                     /* the merged xyzi records in device memory */
+
 /* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
  * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,
  * for a host that keeps ceres::Problem orchestration.  kind: 0 LidarEdgeFactor(a,b),

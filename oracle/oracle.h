@@ -41,6 +41,8 @@ typedef struct {
 int orc_features_run(const OrcFeatureConfig* cfg, const float* xyz, int n, int stride_floats, OrcFeatureOut* out);
 
 int orc_voxel_grid(const float* xyzi, int n, float leaf, int order_mode, float* out_xyzi, int* n_out, int* guard_hit);
+/* one keyframe of the offline map merge (makeMergedMap.py:95-133): f64 rigid transform, near-range removal, f32 out; returns count */
+int orc_mapmerge_frame(const float* xyzi, int n, const double* pose12, double near_thres, float* out_xyzi);
 
 /* ---- stage D: ScanContext ---- */
 typedef struct {

@@ -149,6 +149,20 @@ def voxel_grid(xyzi, leaf, order_mode=1):
     return out[:n_out.value].copy(), guard.value
 
 
+def mapmerge(frames, poses12, near_thres=2.0):
+    """makeMergedMap.py: concatenation of the transformed, near-range-filtered keyframes (list of [n,4] f32, [k,12] f64)"""
+    L = lib()
+    L.orc_mapmerge_frame.argtypes = [_f32p, C.c_int, _f64p, C.c_double, _f32p]
+    out = []
+    for f, p in zip(frames, poses12):
+        f = _f32(f)
+        p = np.ascontiguousarray(p, np.float64)
+        o = np.zeros((max(1, f.shape[0]), 4), np.float32)
+        m = L.orc_mapmerge_frame(_p(f, _f32p), f.shape[0], _p(p, _f64p), float(near_thres), _p(o, _f32p))
+        out.append(o[:m].copy())
+    return np.concatenate(out) if out else np.zeros((0, 4), np.float32)
+
+
 # ---------------------------------------------------------------------------------------------- stage D
 class SCManager:
     def __init__(self, max_radius=80.0, dist_thres=0.2, float_math=0, cr_libm=1):

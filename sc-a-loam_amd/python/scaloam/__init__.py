@@ -64,6 +64,10 @@ class MapStats(C.Structure):
                 ("n_map_corner_total", C.c_int), ("n_map_surf_total", C.c_int), ("insert_path", C.c_int)]
 
 
+class MapMergeConfig(C.Structure):
+    _fields_ = [("max_points", C.c_longlong), ("max_frame_points", C.c_int), ("device", C.c_int)]
+
+
 class OdomConfig(C.Structure):
     _fields_ = [("max_points", C.c_int), ("device", C.c_int)]
 
@@ -84,7 +88,8 @@ EXPORTED_SYMBOLS = [
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
-    "scal_set_stream_mode",
+    "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
+    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
@@ -155,6 +160,17 @@ def lib():
     L.scal_map_collect.argtypes = [vp, _f64p, _f64p, C.POINTER(MapStats)]
     L.scal_map_finish.argtypes = [vp]
     L.scal_set_stream_mode.argtypes = [C.c_int]
+    L.scal_mapmerge_create.argtypes = [C.POINTER(MapMergeConfig), C.POINTER(vp)]
+    L.scal_mapmerge_destroy.argtypes = [vp]
+    L.scal_mapmerge_destroy.restype = None
+    L.scal_mapmerge_reset.argtypes = [vp]
+    L.scal_mapmerge_add.argtypes = [vp, _f32p, C.c_int, _f64p, C.c_double]
+    L.scal_mapmerge_add_batch_device.argtypes = [vp, vp, C.POINTER(C.c_int), _f64p, C.c_int, C.c_double]
+    L.scal_mapmerge_size.argtypes = [vp]
+    L.scal_mapmerge_size.restype = C.c_longlong
+    L.scal_mapmerge_download.argtypes = [vp, _f32p, C.c_longlong]
+    L.scal_mapmerge_device_points.argtypes = [vp]
+    L.scal_mapmerge_device_points.restype = vp
     L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
     L.scal_odom_destroy.argtypes = [vp]
     L.scal_odom_destroy.restype = None
@@ -519,6 +535,50 @@ class LaserOdometry:
         st = OdomStats()
         _check(lib().scal_odom_step_features(self.h, feat.h, _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
         return qlc, tlc, qw, tw, st
+
+
+class MapMerge:
+    """Offline dense map merge (utils/python/makeMergedMap.py:83-133): transform, near-range removal, concatenation."""
+
+    def __init__(self, max_points=40000000, max_frame_points=400000, device=0):
+        self.h = C.c_void_p()
+        cfg = MapMergeConfig(max_points, max_frame_points, device)
+        _check(lib().scal_mapmerge_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_mapmerge_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(lib().scal_mapmerge_reset(self.h))
+
+    def add(self, xyzi, pose12, near_thres=2.0):
+        a = _f32(xyzi)
+        p = _f64(np.asarray(pose12).reshape(-1))
+        _check(lib().scal_mapmerge_add(self.h, _p(a, _f32p), a.shape[0], _p(p, _f64p), float(near_thres)))
+
+    def add_batch_device(self, d_ptr, offsets, poses12, near_thres=2.0):
+        off = (C.c_int * len(offsets))(*[int(v) for v in offsets])
+        p = _f64(np.asarray(poses12).reshape(-1))
+        _check(lib().scal_mapmerge_add_batch_device(self.h, d_ptr, off, _p(p, _f64p), len(offsets) - 1, float(near_thres)))
+
+    def size(self):
+        n = lib().scal_mapmerge_size(self.h)
+        if n < 0:
+            _check(int(n))
+        return int(n)
+
+    def download(self):
+        n = self.size()
+        out = np.zeros((max(n, 1), 4), np.float32)
+        _check(lib().scal_mapmerge_download(self.h, _p(out, _f32p), n))
+        return out[:n]
+
+    def device_points(self):
+        return lib().scal_mapmerge_device_points(self.h)
 
 
 def factors_eval(kind, cp, pa, pb, x7, device=0):

@@ -277,3 +277,28 @@ def test_oracle_golden_vectors(O, golden):
         for j in range(5):
             d, s = O.sc_distance(descs[i], descs[j])
             assert abs(d - G["sc_dist"][i, j]) <= 1e-12 and s == G["sc_shift"][i, j]
+
+
+def test_mapmerge_oracle_properties(O, golden):
+    """Offline map merge (makeMergedMap.py:83-133) restatement: equals a plain numpy f64 evaluation, keeps the order, drops
+    exactly the points within 2 m of the sensor, and a rigid transform preserves point-to-point distances."""
+    names = ["Seosan01_000000.npy", "Seosan01_000011.npy"]
+    frames = [golden(n) for n in names]
+    poses = golden("Seosan01_poses21.npy")[[0, 11]]
+    m = O.mapmerge(frames, poses, 2.0)
+    ref = []
+    for f, p in zip(frames, poses):
+        x = f[:, :3].astype(np.float64)
+        keep = np.sqrt((x * x).sum(1)) > 2.0
+        T = p.reshape(3, 4)
+        ref.append(np.hstack([(x[keep] @ T[:, :3].T + T[:, 3]).astype(np.float32), f[keep, 3:4]]))
+    ref = np.concatenate(ref)
+    assert m.shape == ref.shape
+    assert np.abs(m - ref).max() <= 1e-5  # summation order of the 4x4 product differs from numpy's matmul by <= 1 f32 ulp
+    assert np.array_equal(m[:, 3], ref[:, 3])
+    n0 = int((np.sqrt((frames[0][:, :3].astype(np.float64) ** 2).sum(1)) > 2.0).sum())
+    a, b = m[:n0][::997], frames[0][np.sqrt((frames[0][:, :3].astype(np.float64) ** 2).sum(1)) > 2.0][::997]
+    da = np.linalg.norm(a[1:, :3].astype(np.float64) - a[:-1, :3], axis=1)
+    db = np.linalg.norm(b[1:, :3].astype(np.float64) - b[:-1, :3], axis=1)
+    assert np.abs(da - db).max() <= 2e-3  # optimized_poses.txt rotations are orthonormal to ~1e-6
+    assert O.mapmerge([], np.zeros((0, 12))).shape == (0, 4)

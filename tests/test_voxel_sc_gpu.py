@@ -231,3 +231,42 @@ def test_sc_sharded_batch_equals_single(O, S):
     for sh in shards:
         sh.close()
     single.close()
+
+
+def test_mapmerge_matches_oracle(O, S, golden):
+    """Offline dense map merge: frame-by-frame adds and the batched device path against the oracle, bit for bit
+    (same f64 operation order, compiled without FMA contraction), including an empty frame and a frame that is dropped whole."""
+    import ctypes
+    names = ["KAIST03_000000.npy", "KAIST03_000007.npy", "KAIST03_000020.npy"]
+    frames = [golden(n) for n in names] + [np.zeros((0, 4), np.float32), np.full((300, 4), 0.5, np.float32)]
+    poses = np.concatenate([golden("KAIST03_poses21.npy")[[0, 7, 20]], golden("KAIST03_poses21.npy")[[1, 2]]])
+    want = O.mapmerge(frames, poses, 2.0)
+    mm = S.MapMerge(max_points=1000000, max_frame_points=200000)
+    for f, p in zip(frames, poses):
+        mm.add(f, p, 2.0)
+    got = mm.download()
+    assert got.shape == want.shape and np.array_equal(_bits(got), _bits(want))
+    # batched, device-resident input
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    cat = np.ascontiguousarray(np.concatenate(frames), np.float32)
+    offs = np.concatenate([[0], np.cumsum([f.shape[0] for f in frames])]).astype(int)
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), cat.nbytes) == 0 and hip.hipMemcpy(d, cat.ctypes.data, cat.nbytes, 1) == 0
+    mm.reset()
+    mm.add_batch_device(d, offs, poses, 2.0)
+    got2 = mm.download()
+    assert np.array_equal(_bits(got2), _bits(want))
+    # appending continues behind what is there
+    mm.add(frames[0], poses[0], 2.0)
+    assert mm.size() == want.shape[0] + int((np.sqrt((frames[0][:, :3].astype(np.float64) ** 2).sum(1)) > 2.0).sum())
+    hip.hipFree(d)
+    small = S.MapMerge(max_points=1000, max_frame_points=200000)
+    small.add(frames[0], poses[0], 2.0)
+    with pytest.raises(S.ScalError) as e:
+        small.size()
+    assert e.value.code == S.E_CAPACITY
+    small.close()
+    mm.close()
