@@ -9,7 +9,7 @@
 //   k_mm_scan   exclusive prefix of the workgroup counts on top of the running total (one workgroup)
 //   k_mm_write  flags again (cheaper than storing them: the point is needed anyway), rigid transform in f64 in the order of
 //               a column-major 4x4 product, ballot-ranked stable write of xyzi records
-// A workgroup handles 256 consecutive points of ONE frame; a batch of frames is one launch of each kernel.
+// A workgroup handles 1024 consecutive points of ONE frame; a batch of frames is one launch of each kernel.
 #include "common.hpp"
 #include "device_utils.hpp"
 #include <vector>
@@ -28,37 +28,54 @@ __device__ __forceinline__ bool mm_keep(const float4& p, double thres) {
     return sqrt((x * x + y * y) + z * z) > thres;  // LA.norm(local, axis=1) > thres_near_removal (makeMergedMap.py:109, :112)
 }
 
+constexpr int MM_ITEMS = 4;                 // points per thread
+constexpr int MM_TILE = 256 * MM_ITEMS;    // points per workgroup; point (j, t) of a workgroup = first + j*256 + t
+
 __global__ void __launch_bounds__(256) k_mm_count(const float4* __restrict__ in, const MMBlock* __restrict__ blocks, double thres,
                                                   int* __restrict__ blkcnt) {
     __shared__ int s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const MMBlock b = blocks[blockIdx.x];
-    const int i = b.first + threadIdx.x;
-    const bool keep = i < b.end && mm_keep(in[i], thres);
-    const uint64_t m = __ballot(keep);
-    if (lane_id() == 0 && m) atomicAdd(&s_cnt, __popcll(m));
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < MM_ITEMS; ++j) {
+        const int i = b.first + j * 256 + threadIdx.x;
+        const bool keep = i < b.end && mm_keep(in[i], thres);
+        mine += __popcll(__ballot(keep));
+    }
+    if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
     __syncthreads();
     if (threadIdx.x == 0) blkcnt[blockIdx.x] = s_cnt;
 }
 
-// in-place exclusive scan of cnt[0..nb) by one workgroup, offset by the running total, which it advances
+// in-place exclusive scan of cnt[0..nb) by one workgroup (16-byte loads, every thread owns a contiguous multiple of four
+// entries; cnt is padded to a multiple of 4096), offset by nothing: the running total is added by the write pass.
 __global__ void __launch_bounds__(1024) k_mm_scan(int* __restrict__ cnt, int nb, long long* __restrict__ d_total, long long cap, int* __restrict__ d_error) {
     __shared__ int smem[17];
-    const int per = (nb + 1023) / 1024;
-    const int b0 = min(nb, static_cast<int>(threadIdx.x) * per), b1 = min(nb, b0 + per);
+    const int per4 = ((nb + 1023) / 1024 + 3) / 4;  // int4 groups per thread
+    int4* c4 = reinterpret_cast<int4*>(cnt) + static_cast<size_t>(threadIdx.x) * per4;
+    const int first = threadIdx.x * per4 * 4;
     int sum = 0;
-    for (int i = b0; i < b1; ++i) sum += cnt[i];
+    for (int g = 0; g < per4; ++g) {
+        const int4 v = c4[g];
+        const int e = first + 4 * g;
+        sum += (e < nb ? v.x : 0) + (e + 1 < nb ? v.y : 0) + (e + 2 < nb ? v.z : 0) + (e + 3 < nb ? v.w : 0);
+    }
     int total;
     int run = block_exclusive_scan(sum, smem, &total);
-    const long long base = *d_total;
-    for (int i = b0; i < b1; ++i) {
-        const int v = cnt[i];
-        cnt[i] = run;
-        run += v;
+    for (int g = 0; g < per4; ++g) {
+        const int4 v = c4[g];
+        const int e = first + 4 * g;
+        int4 o;
+        o.x = run, run += e < nb ? v.x : 0;
+        o.y = run, run += e + 1 < nb ? v.y : 0;
+        o.z = run, run += e + 2 < nb ? v.z : 0;
+        o.w = run, run += e + 3 < nb ? v.w : 0;
+        c4[g] = o;
     }
-    __syncthreads();
     if (threadIdx.x == 0) {
+        const long long base = *d_total;
         if (base + total > cap) *d_error = SCAL_E_CAPACITY;
         *d_total = base + total;
     }
@@ -67,32 +84,43 @@ __global__ void __launch_bounds__(1024) k_mm_scan(int* __restrict__ cnt, int nb,
 __global__ void __launch_bounds__(256) k_mm_write(const float4* __restrict__ in, const MMBlock* __restrict__ blocks, const double* __restrict__ poses,
                                                   double thres, const int* __restrict__ blkoff, long long base, long long cap,
                                                   float4* __restrict__ out) {
-    __shared__ int s_wave[4];
+    __shared__ int s_cnt[MM_ITEMS][4];
     const MMBlock b = blocks[blockIdx.x];
-    const int i = b.first + threadIdx.x;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool keep = false;
-    if (i < b.end) {
-        p = in[i];
-        keep = mm_keep(p, thres);
-    }
-    const uint64_t m = __ballot(keep);
     const int w = wave_id();
-    if (lane_id() == 0) s_wave[w] = __popcll(m);
+    float4 p[MM_ITEMS];
+    bool keep[MM_ITEMS];
+    int rank[MM_ITEMS];
+#pragma unroll
+    for (int j = 0; j < MM_ITEMS; ++j) {
+        const int i = b.first + j * 256 + threadIdx.x;
+        keep[j] = false;
+        if (i < b.end) {
+            p[j] = in[i];
+            keep[j] = mm_keep(p[j], thres);
+        }
+        const uint64_t m = __ballot(keep[j]);
+        rank[j] = __popcll(m & lanemask_lt());
+        if (lane_id() == 0) s_cnt[j][w] = __popcll(m);
+    }
     __syncthreads();
-    int before = 0;
-    for (int q = 0; q < w; ++q) before += s_wave[q];
-    if (!keep) return;
-    const long long o = base + blkoff[blockIdx.x] + before + __popcll(m & lanemask_lt());
-    if (o >= cap) return;  // k_mm_scan has flagged the overflow
     const double* T = poses + 12 * b.frame;
-    const double x = p.x, y = p.y, z = p.z;
-    float4 g;  // T * [x y z 1]^T, column-major product order; the 4th row is (0 0 0 1), so the division by w is by 1
-    g.x = static_cast<float>(((T[0] * x + T[1] * y) + T[2] * z) + T[3]);
-    g.y = static_cast<float>(((T[4] * x + T[5] * y) + T[6] * z) + T[7]);
-    g.z = static_cast<float>(((T[8] * x + T[9] * y) + T[10] * z) + T[11]);
-    g.w = p.w;
-    out[o] = g;
+    int before = 0;  // kept points of the workgroup in front of (j, wave w)
+#pragma unroll
+    for (int j = 0; j < MM_ITEMS; ++j) {
+        int mine = before;
+        for (int q = 0; q < w; ++q) mine += s_cnt[j][q];
+        before += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
+        if (!keep[j]) continue;
+        const long long o = base + blkoff[blockIdx.x] + mine + rank[j];
+        if (o >= cap) continue;  // k_mm_scan has flagged the overflow
+        const double x = p[j].x, y = p[j].y, z = p[j].z;
+        float4 g;  // T * [x y z 1]^T, column-major product order; the 4th row is (0 0 0 1), so the division by w is by 1
+        g.x = static_cast<float>(((T[0] * x + T[1] * y) + T[2] * z) + T[3]);
+        g.y = static_cast<float>(((T[4] * x + T[5] * y) + T[6] * z) + T[7]);
+        g.z = static_cast<float>(((T[8] * x + T[9] * y) + T[10] * z) + T[11]);
+        g.w = p[j].w;
+        out[o] = g;
+    }
 }
 
 }  // namespace scal
@@ -165,13 +193,13 @@ static int merge_batch(scal_mapmerge* c, const float4* d_in, const int* offsets,
     hipStream_t s = c->stream;
     std::vector<MMBlock> hb;
     for (int f = 0; f < n_frames; ++f)
-        for (int i = offsets[f]; i < offsets[f + 1]; i += 256) hb.push_back(MMBlock{i, offsets[f + 1], f});
+        for (int i = offsets[f]; i < offsets[f + 1]; i += MM_TILE) hb.push_back(MMBlock{i, offsets[f + 1], f});
     const int nb = static_cast<int>(hb.size());
     if (nb == 0) return SCAL_OK;
     if (nb > c->nb_cap) {
         SCAL_HIP(hipStreamSynchronize(s));
         SCAL_TRY(c->blocks.alloc(nb));
-        SCAL_TRY(c->blkcnt.alloc(nb));
+        SCAL_TRY(c->blkcnt.alloc(static_cast<size_t>(nb) + 8192));  // k_mm_scan reads whole 16-byte groups per thread
         c->nb_cap = nb;
     }
     if (n_frames > c->pose_cap) {
