@@ -1,0 +1,65 @@
+"""On-disk formats against files the reference itself wrote: a keyframe PCD saved by
+pcl::io::savePCDFileBinary, the first lines of optimized_poses.txt and times.txt (utils/sample_data/KAIST03)."""
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+
+
+def _fmt():
+    import importlib.util
+    p = os.path.join(HERE, "..", "sc-a-loam_amd", "python", "scaloam", "formats.py")
+    spec = importlib.util.spec_from_file_location("scaloam_formats", p)  # no GPU library needed for this module
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_pcd_binary_roundtrip_is_byte_exact(tmp_path):
+    F = _fmt()
+    src = os.path.join(G, "KAIST03_000005.pcd")
+    a = F.read_pcd(src)
+    assert a.shape == (35976, 4) and a.dtype == np.float32
+    assert np.isfinite(a).all() and np.abs(a[:, :3]).max() < 300
+    raw = open(src, "rb").read()
+    assert F.pcd_binary_bytes(a) == raw  # header, packed records and PCL's zero tail
+    out = tmp_path / "k.pcd"
+    F.write_pcd_binary(out, a)
+    assert np.array_equal(F.read_pcd(out).view(np.uint32), a.view(np.uint32))
+    # empty cloud and ascii variant
+    F.write_pcd_binary(out, np.zeros((0, 4), np.float32))
+    assert F.read_pcd(out).shape == (0, 4)
+    asc = tmp_path / "a.pcd"
+    asc.write_text("VERSION 0.7\nFIELDS intensity x y z\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n"
+                   "7 1 2 3\n9 4 5 6\n")
+    assert np.array_equal(F.read_pcd(asc), np.array([[1, 2, 3, 7], [4, 5, 6, 9]], np.float32))
+
+
+def test_pose_and_time_text_roundtrip():
+    F = _fmt()
+    src = os.path.join(G, "KAIST03_optimized_poses_head5.txt")
+    lines = open(src).read().splitlines()
+    P = F.read_poses(src)
+    assert P.shape == (5, 12)
+    assert [F.format_pose_line(p) for p in P] == lines  # C++ default formatting reproduced
+    R = P[1].reshape(3, 4)[:, :3]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-5
+    ts = open(os.path.join(G, "KAIST03_times_head5.txt")).read().splitlines()
+    t = F.read_times(os.path.join(G, "KAIST03_times_head5.txt"))
+    assert [F.format_time(v) for v in t] == ts
+
+
+def test_scd_and_kitti_bin(tmp_path):
+    F = _fmt()
+    rng = np.random.default_rng(0)
+    d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+    txt = F.scd_text(d)
+    assert txt.count("\n") == 19 and not txt.endswith("\n")
+    back = F.read_scd(txt)
+    assert back.shape == (20, 60) and np.abs(back - d).max() <= 0.05 + 1e-9  # three significant digits
+    assert F.scd_text(np.array([[0.0, 12.3456, -0.001234, 100000.0]])) == "0 12.3 -0.00123 1e+05"
+    p = tmp_path / "v.bin"
+    a = rng.normal(size=(1000, 4)).astype(np.float32)
+    F.write_kitti_bin(p, a)
+    assert np.array_equal(F.read_kitti_bin(p), a)
