@@ -245,15 +245,20 @@ def main():
             side += [(sc.insert_features, (r_,)), (sc.detect_enqueue, ())]
         else:
             xchg_q.put((k, r_))
+        nxt = None
+        if k + 1 < last:
+            nxt = (regs[(k + 1) % len(regs)].run_device, (d_scans[k + 1].data_ptr(), npts[k + 1], 3))
+            pipe["a_queued"] = k + 1
         if side_thread:
-            side_q.put(side)
+            # stage A of the NEXT scan goes to the side thread as well (its last job): nothing on the main thread needs it before
+            # the join of this job, which precedes the next scan's B.enqueue
+            side_q.put(side[:1] + ([nxt] if nxt else []) + side[1:])  # prefetch (stage C waits for it), then A, then stage D
         timed("B.enqueue", od.enqueue_features, r_)
         if not side_thread:
             for fn, args in side:
                 timed("side." + fn.__name__, fn, *args)
-        if k + 1 < last:
-            timed("A.run_device", regs[(k + 1) % len(regs)].run_device, d_scans[k + 1].data_ptr(), npts[k + 1], 3)
-            pipe["a_queued"] = k + 1
+            if nxt:
+                timed("A.run_device", nxt[0], *nxt[1])
         pipe["front"] = k
 
     def step_pipelined(k, last):
