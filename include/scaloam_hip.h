@@ -285,6 +285,32 @@ long long scal_mapmerge_size(scal_mapmerge_t* ctx);                             
 int scal_mapmerge_download(scal_mapmerge_t* ctx, float* out_xyzi, long long cap_points);
 const float* scal_mapmerge_device_points(scal_mapmerge_t* ctx);                     /* the merged xyzi records in device memory */
 
+/* ------------------------------------------------------------------ loop-closure verification ICP
+ * Replaces the pcl::IterativeClosestPoint call of doICPVirtualRelative, laserPosegraphOptimization.cpp:518-535.  The caller
+ * builds the two clouds as the reference does (:504-507: keyframes moved by one root pose, VoxelGrid 0.4) with scal_mapmerge_*
+ * and scal_voxel_*, and applies the acceptance test of :532 (converged && fitness <= 0.3) to the result. */
+typedef struct {
+    double max_corr_dist;           /* setMaxCorrespondenceDistance, 150 (:520) */
+    double transformation_epsilon;  /* setTransformationEpsilon, 1e-6 (:522) */
+    double fitness_epsilon;         /* setEuclideanFitnessEpsilon, 1e-6 (:523) */
+    int max_iterations;             /* setMaximumIterations, 100 (:521) */
+    int max_source, max_target;     /* capacities */
+    int device;
+} scal_icp_config;
+typedef struct {
+    int converged;          /* icp.hasConverged() */
+    int iterations;
+    int state;              /* 1 iteration cap, 2 transformation epsilon, 3 absolute MSE, 4 relative MSE, 5 too few correspondences */
+    int n_correspondences;  /* of the last iteration */
+    double fitness;         /* icp.getFitnessScore() */
+    double T[16];           /* icp.getFinalTransformation(), row-major, f32 values */
+} scal_icp_result;
+typedef struct scal_icp scal_icp_t;
+int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** ctx);
+void scal_icp_destroy(scal_icp_t* ctx);
+/* icp.setInputSource(src); icp.setInputTarget(tgt); icp.align(): xyzi host records */
+int scal_icp_align(scal_icp_t* ctx, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, scal_icp_result* res);
+
 /* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
  * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,
  * for a host that keeps ceres::Problem orchestration.  kind: 0 LidarEdgeFactor(a,b),

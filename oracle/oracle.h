@@ -42,6 +42,10 @@ int orc_features_run(const OrcFeatureConfig* cfg, const float* xyz, int n, int s
 
 int orc_voxel_grid(const float* xyzi, int n, float leaf, int order_mode, float* out_xyzi, int* n_out, int* guard_hit);
 /* one keyframe of the offline map merge (makeMergedMap.py:95-133): f64 rigid transform, near-range removal, f32 out; returns count */
+/* loop-closure verification ICP (laserPosegraphOptimization.cpp:497-548, pcl::IterativeClosestPoint restated); returns hasConverged() */
+int orc_icp_align(const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, double max_corr, int max_iter, double trans_eps,
+                  double fit_eps, double* T16_out, double* fitness, int* iterations, int* state);
+void orc_icp_transform_from_sums(const double* sums16, double* T16);
 int orc_mapmerge_frame(const float* xyzi, int n, const double* pose12, double near_thres, float* out_xyzi);
 
 /* ---- stage D: ScanContext ---- */

@@ -149,6 +149,20 @@ def voxel_grid(xyzi, leaf, order_mode=1):
     return out[:n_out.value].copy(), guard.value
 
 
+def icp_align(src, tgt, max_corr=150.0, max_iter=100, trans_eps=1e-6, fit_eps=1e-6):
+    """doICPVirtualRelative's pcl::IterativeClosestPoint call (:518-531) -> dict(converged, T, fitness, iterations, state)"""
+    L = lib()
+    L.orc_icp_align.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, _f64p, _f64p,
+                                C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    s, t = _f32(src), _f32(tgt)
+    T = np.zeros(16)
+    fit = np.zeros(1)
+    it, st = C.c_int(0), C.c_int(0)
+    conv = L.orc_icp_align(_p(s, _f32p), s.shape[0], _p(t, _f32p), t.shape[0], max_corr, max_iter, trans_eps, fit_eps, _p(T, _f64p),
+                           _p(fit, _f64p), C.byref(it), C.byref(st))
+    return dict(converged=bool(conv), T=T.reshape(4, 4), fitness=float(fit[0]), iterations=it.value, state=st.value)
+
+
 def mapmerge(frames, poses12, near_thres=2.0):
     """makeMergedMap.py: concatenation of the transformed, near-range-filtered keyframes (list of [n,4] f32, [k,12] f64)"""
     L = lib()

@@ -1,0 +1,336 @@
+// Loop-closure verification ICP on gfx950.  Replaces the pcl::IterativeClosestPoint call of
+// doICPVirtualRelative, /root/reference/src/laserPosegraphOptimization.cpp:518-535 (setMaxCorrespondenceDistance(150),
+// setMaximumIterations(100), setTransformationEpsilon(1e-6), setEuclideanFitnessEpsilon(1e-6), setRANSACIterations(0),
+// hasConverged(), getFitnessScore()).  The submaps that feed it (:472-494: keyframes moved by ONE root pose, concatenated,
+// VoxelGrid 0.4) are scal_mapmerge_* + scal_voxel_*.
+//
+// Per iteration (PCL icp.hpp computeTransformation, restated in oracle/icp.cpp):
+//   k_icp_nn      exact nearest target point of every current source point: 64 queries x 2048 targets per workgroup, targets
+//                 staged in LDS and read as wave-wide broadcasts, (f32 squared distance, target index) keys merged across
+//                 target chunks with 64-bit atomicMin (= smallest distance, lowest index on ties)
+//   k_icp_reduce  correspondences within max distance -> n, sum p, sum q, sum q p^T, sum d^2 in f64: fixed-order workgroup
+//                 partials, summed in workgroup order by the last kernel and written to pinned host memory
+//   host          Horn's closed form of the rigid least-squares fit (what TransformationEstimationSVD / Eigen::umeyama solve),
+//                 PCL's DefaultConvergenceCriteria
+//   k_icp_apply   the increment applied to the source cloud in place, f32 as PCL does
+// The reference pays a kd-tree query per point and iteration on the CPU; here one iteration is a dense 20k x 200k distance
+// sweep (~2 ms) - brute force, but exact and branch-free.  A cell grid is the obvious next step.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace scal {
+
+constexpr int ICP_QT = 64;     // queries per workgroup
+constexpr int ICP_TC = 2048;   // targets per workgroup
+constexpr int ICP_NSUM = 17;   // n, sum p[3], sum q[3], sum q p^T[9], sum d^2
+
+__global__ void __launch_bounds__(256) k_icp_nn(const float4* __restrict__ cur, int n_src, const float4* __restrict__ tgt, int n_tgt,
+                                                unsigned long long* __restrict__ best) {
+    __shared__ float4 st[ICP_TC];
+    __shared__ unsigned long long red[4][ICP_QT];
+    const int t0 = blockIdx.y * ICP_TC;
+    const int tn = min(ICP_TC, n_tgt - t0);
+    for (int i = threadIdx.x; i < tn; i += 256) st[i] = tgt[t0 + i];
+    __syncthreads();
+    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int qi = blockIdx.x * ICP_QT + ql;
+    unsigned long long mine = ~0ull;
+    if (qi < n_src) {
+        const float4 q = cur[qi];
+        const int per = (tn + 3) / 4;
+        const int b0 = part * per, b1 = min(tn, b0 + per);
+        float bd = 3.4e38f;
+        int bi = -1;
+#pragma unroll 4
+        for (int t = b0; t < b1; ++t) {
+            const float4 p = st[t];
+            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+            float d = dx * dx;  // FLANN L2_Simple<float>, the metric of pcl::KdTreeFLANN
+            d += dy * dy;
+            d += dz * dz;
+            if (d < bd) bd = d, bi = t;  // ascending t: the lowest index of equal distances is kept
+        }
+        if (bi >= 0) mine = (static_cast<unsigned long long>(__float_as_uint(bd)) << 32) | static_cast<unsigned>(t0 + bi);
+    }
+    red[part][ql] = mine;
+    __syncthreads();
+    if (part == 0 && qi < n_src) {
+        unsigned long long b = red[0][ql];
+        for (int p = 1; p < 4; ++p) b = red[p][ql] < b ? red[p][ql] : b;
+        if (b != ~0ull) atomicMin(&best[qi], b);
+    }
+}
+
+// partial sums of one workgroup of 256 source points; resets the keys for the next sweep
+__global__ void __launch_bounds__(256) k_icp_reduce(const float4* __restrict__ cur, int n_src, const float4* __restrict__ tgt,
+                                                    unsigned long long* __restrict__ best, float max2, double* __restrict__ partials) {
+    __shared__ double red[4][ICP_NSUM];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v[ICP_NSUM];
+#pragma unroll
+    for (int k = 0; k < ICP_NSUM; ++k) v[k] = 0.0;
+    if (i < n_src) {
+        const unsigned long long key = best[i];
+        best[i] = ~0ull;
+        const float d = __uint_as_float(static_cast<unsigned>(key >> 32));
+        if (key != ~0ull && !(d > max2)) {
+            const float4 p = cur[i];
+            const float4 q = tgt[static_cast<unsigned>(key & 0xffffffffu)];
+            v[0] = 1.0;
+            v[1] = p.x, v[2] = p.y, v[3] = p.z;
+            v[4] = q.x, v[5] = q.y, v[6] = q.z;
+            const double qq[3] = {q.x, q.y, q.z}, pp[3] = {p.x, p.y, p.z};
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[7 + 3 * r + c] = qq[r] * pp[c];
+            v[16] = d;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ICP_NSUM; ++k) {
+        const double s = wave_sum(v[k]);
+        if (lane_id() == 0) red[wave_id()][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ICP_NSUM) partials[blockIdx.x * ICP_NSUM + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// sums the workgroup partials in workgroup order and hands them to the host (pinned, device-visible memory)
+__global__ void __launch_bounds__(64) k_icp_final(const double* __restrict__ partials, int nb, double* __restrict__ host_out) {
+    if (threadIdx.x < ICP_NSUM) {
+        double s = 0.0;
+        for (int b = 0; b < nb; ++b) s += partials[b * ICP_NSUM + threadIdx.x];
+        host_out[threadIdx.x] = s;
+    }
+}
+
+struct Mat34f {
+    float m[12];
+};
+__global__ void __launch_bounds__(256) k_icp_apply(const float4* __restrict__ in, float4* __restrict__ out, int n, Mat34f T) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    float4 o;
+    o.x = ((T.m[0] * p.x + T.m[1] * p.y) + T.m[2] * p.z) + T.m[3];
+    o.y = ((T.m[4] * p.x + T.m[5] * p.y) + T.m[6] * p.z) + T.m[7];
+    o.z = ((T.m[8] * p.x + T.m[9] * p.y) + T.m[10] * p.z) + T.m[11];
+    o.w = p.w;
+    out[i] = o;
+}
+
+__global__ void k_icp_fill(unsigned long long* __restrict__ best, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) best[i] = ~0ull;
+}
+
+namespace {
+// largest eigenpair of a symmetric 4x4 by cyclic Jacobi -> unit quaternion (w, x, y, z)
+void eig4_max(double a[4][4], double q[4]) {
+    double v[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) (i == j ? diag : off) += a[i][j] * a[i][j];
+        if (off <= 1e-40 * diag || off == 0.0) break;
+        for (int p = 0; p < 3; ++p)
+            for (int r = p + 1; r < 4; ++r) {
+                if (a[p][r] == 0.0) continue;
+                const double theta = (a[r][r] - a[p][p]) / (2.0 * a[p][r]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 4; ++k) {
+                    const double akp = a[k][p], akr = a[k][r];
+                    a[k][p] = c * akp - s * akr, a[k][r] = s * akp + c * akr;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double apk = a[p][k], ark = a[r][k];
+                    a[p][k] = c * apk - s * ark, a[r][k] = s * apk + c * ark;
+                }
+                for (int k = 0; k < 4; ++k) {
+                    const double vkp = v[k][p], vkr = v[k][r];
+                    v[k][p] = c * vkp - s * vkr, v[k][r] = s * vkp + c * vkr;
+                }
+            }
+    }
+    int best = 0;
+    for (int i = 1; i < 4; ++i)
+        if (a[i][i] > a[best][best]) best = i;
+    double nrm = 0;
+    for (int k = 0; k < 4; ++k) nrm += v[k][best] * v[k][best];
+    nrm = std::sqrt(nrm);
+    for (int k = 0; k < 4; ++k) q[k] = v[k][best] / nrm;
+}
+
+// rigid increment (as the Matrix4f PCL keeps) from the correspondence sums: Horn's quaternion form of the Umeyama problem
+void transform_from_sums(const double* sums, float* T) {
+    const double n = sums[0];
+    double mp[3], mq[3], S[3][3];
+    for (int k = 0; k < 3; ++k) mp[k] = sums[1 + k] / n, mq[k] = sums[4 + k] / n;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) S[c][r] = sums[7 + 3 * r + c] / n - mq[r] * mp[c];
+    double N[4][4] = {{S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+                      {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+                      {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+                      {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+    double q[4];
+    eig4_max(N, q);
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                            {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                            {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+    for (int r = 0; r < 3; ++r) {
+        double t = mq[r];
+        for (int c = 0; c < 3; ++c) {
+            T[4 * r + c] = static_cast<float>(R[r][c]);
+            t -= R[r][c] * mp[c];
+        }
+        T[4 * r + 3] = static_cast<float>(t);
+    }
+    T[12] = T[13] = T[14] = 0.f, T[15] = 1.f;
+}
+}  // namespace
+
+}  // namespace scal
+
+using namespace scal;
+
+struct scal_icp {
+    scal_icp_config cfg;
+    hipStream_t stream = nullptr;
+    DevBuf<float4> src, cur, tgt;
+    DevBuf<unsigned long long> best;
+    DevBuf<double> partials;
+    PinBuf<double> h_sums;
+};
+
+extern "C" int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** out) {
+    if (!cfg || !out || cfg->max_source <= 0 || cfg->max_target <= 0 || cfg->max_iterations <= 0 || !(cfg->max_corr_dist > 0)) {
+        set_error("scal_icp_create: bad argument");
+        return SCAL_E_ARG;
+    }
+    *out = nullptr;
+    SCAL_TRY(select_device(cfg->device));
+    auto* c = new scal_icp();
+    c->cfg = *cfg;
+    int rc = SCAL_OK;
+    auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
+    A(c->src.alloc(cfg->max_source)); A(c->cur.alloc(cfg->max_source)); A(c->tgt.alloc(cfg->max_target));
+    A(c->best.alloc(cfg->max_source));
+    A(c->partials.alloc(static_cast<size_t>(ICP_NSUM) * (div_up(cfg->max_source, 256) + 1)));
+    A(c->h_sums.alloc(ICP_NSUM));
+    if (rc == SCAL_OK && acquire_stream(cfg->device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
+    if (rc != SCAL_OK) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return SCAL_OK;
+}
+
+extern "C" void scal_icp_destroy(scal_icp_t* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) {
+        (void)hipStreamSynchronize(c->stream);
+        release_stream(c->cfg.device);
+    }
+    delete c;
+}
+
+// one correspondence sweep of `pts` against the target: sums -> c->h_sums (waits)
+static int icp_sweep(scal_icp* c, const float4* pts, int n_src, int n_tgt, float max2) {
+    hipStream_t s = c->stream;
+    const int nb = div_up(n_src, 256);
+    SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt, c->best.p);
+    hipLaunchKernelGGL(k_icp_reduce, dim3(nb), dim3(256), 0, s, pts, n_src, c->tgt.p, c->best.p, max2, c->partials.p);
+    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(64), 0, s, c->partials.p, nb, c->h_sums.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, scal_icp_result* res) {
+    if (!c || !res || n_src < 0 || n_tgt < 0 || (n_src && !src_xyzi) || (n_tgt && !tgt_xyzi)) {
+        set_error("scal_icp_align: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_src > c->cfg.max_source || n_tgt > c->cfg.max_target) {
+        set_error("scal_icp_align: cloud larger than the context capacity (source %d, target %d)", c->cfg.max_source, c->cfg.max_target);
+        return SCAL_E_TOO_MANY;
+    }
+    std::memset(res, 0, sizeof *res);
+    float F[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    for (int k = 0; k < 16; ++k) res->T[k] = F[k];
+    res->fitness = std::numeric_limits<double>::max();
+    if (n_src == 0 || n_tgt == 0) {  // pcl::Registration::align refuses empty clouds: not converged
+        res->state = 5;
+        return SCAL_OK;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->src.p, src_xyzi, sizeof(float) * 4 * n_src, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->cur.p, src_xyzi, sizeof(float) * 4 * n_src, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->tgt.p, tgt_xyzi, sizeof(float) * 4 * n_tgt, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_icp_fill, dim3(div_up(n_src, 256)), dim3(256), 0, s, c->best.p, n_src);
+    const float max2 = static_cast<float>(c->cfg.max_corr_dist * c->cfg.max_corr_dist);
+    const double te = c->cfg.transformation_epsilon, fe = c->cfg.fitness_epsilon;
+    int it = 0, st = 0;
+    bool converged = false;
+    double prev_mse = std::numeric_limits<double>::max();
+    while (!converged) {
+        SCAL_TRY(icp_sweep(c, c->cur.p, n_src, n_tgt, max2));
+        const double* sums = c->h_sums.p;
+        res->n_correspondences = static_cast<int>(sums[0]);
+        if (sums[0] < 3) {  // icp.hpp: "Not enough correspondences found"
+            st = 5;
+            break;
+        }
+        float T[16];
+        transform_from_sums(sums, T);
+        Mat34f M;
+        std::memcpy(M.m, T, sizeof M.m);
+        hipLaunchKernelGGL(k_icp_apply, dim3(div_up(n_src, 256)), dim3(256), 0, s, c->cur.p, c->cur.p, n_src, M);
+        float G[16];
+        for (int r = 0; r < 4; ++r)
+            for (int cc = 0; cc < 4; ++cc) G[4 * r + cc] = ((T[4 * r] * F[cc] + T[4 * r + 1] * F[4 + cc]) + T[4 * r + 2] * F[8 + cc]) + T[4 * r + 3] * F[12 + cc];
+        std::memcpy(F, G, sizeof F);
+        ++it;
+        // DefaultConvergenceCriteria::hasConverged (PCL 1.8)
+        if (it >= c->cfg.max_iterations) {
+            st = 1, converged = true;
+            break;
+        }
+        const double cos_angle = 0.5 * (static_cast<double>(T[0]) + T[5] + T[10] - 1.0);
+        const double tr2 = static_cast<double>(T[3]) * T[3] + static_cast<double>(T[7]) * T[7] + static_cast<double>(T[11]) * T[11];
+        if (cos_angle >= 1.0 - te && tr2 <= te) {
+            st = 2, converged = true;
+            break;
+        }
+        const double mse = sums[16] / sums[0];
+        if (std::fabs(mse - prev_mse) < 1e-12) {
+            st = 3, converged = true;
+            break;
+        }
+        if (std::fabs(mse - prev_mse) / prev_mse < fe) {
+            st = 4, converged = true;
+            break;
+        }
+        prev_mse = mse;
+    }
+    // getFitnessScore(): the original source moved by the final transform, no distance cap
+    Mat34f M;
+    std::memcpy(M.m, F, sizeof M.m);
+    hipLaunchKernelGGL(k_icp_apply, dim3(div_up(n_src, 256)), dim3(256), 0, s, c->src.p, c->cur.p, n_src, M);
+    SCAL_TRY(icp_sweep(c, c->cur.p, n_src, n_tgt, 3.4e38f));
+    res->converged = converged ? 1 : 0;
+    res->iterations = it;
+    res->state = st;
+    res->fitness = c->h_sums.p[0] > 0 ? c->h_sums.p[16] / c->h_sums.p[0] : std::numeric_limits<double>::max();
+    for (int k = 0; k < 16; ++k) res->T[k] = F[k];
+    return SCAL_OK;
+}

@@ -64,6 +64,16 @@ class MapStats(C.Structure):
                 ("n_map_corner_total", C.c_int), ("n_map_surf_total", C.c_int), ("insert_path", C.c_int)]
 
 
+class ICPConfig(C.Structure):
+    _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double), ("fitness_epsilon", C.c_double),
+                ("max_iterations", C.c_int), ("max_source", C.c_int), ("max_target", C.c_int), ("device", C.c_int)]
+
+
+class ICPResult(C.Structure):
+    _fields_ = [("converged", C.c_int), ("iterations", C.c_int), ("state", C.c_int), ("n_correspondences", C.c_int),
+                ("fitness", C.c_double), ("T", C.c_double * 16)]
+
+
 class MapMergeConfig(C.Structure):
     _fields_ = [("max_points", C.c_longlong), ("max_frame_points", C.c_int), ("device", C.c_int)]
 
@@ -89,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
-    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points",
+    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_icp_create", "scal_icp_destroy", "scal_icp_align",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
@@ -160,6 +170,10 @@ def lib():
     L.scal_map_collect.argtypes = [vp, _f64p, _f64p, C.POINTER(MapStats)]
     L.scal_map_finish.argtypes = [vp]
     L.scal_set_stream_mode.argtypes = [C.c_int]
+    L.scal_icp_create.argtypes = [C.POINTER(ICPConfig), C.POINTER(vp)]
+    L.scal_icp_destroy.argtypes = [vp]
+    L.scal_icp_destroy.restype = None
+    L.scal_icp_align.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, C.POINTER(ICPResult)]
     L.scal_mapmerge_create.argtypes = [C.POINTER(MapMergeConfig), C.POINTER(vp)]
     L.scal_mapmerge_destroy.argtypes = [vp]
     L.scal_mapmerge_destroy.restype = None
@@ -535,6 +549,30 @@ class LaserOdometry:
         st = OdomStats()
         _check(lib().scal_odom_step_features(self.h, feat.h, _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
         return qlc, tlc, qw, tw, st
+
+
+class LoopICP:
+    """pcl::IterativeClosestPoint as doICPVirtualRelative configures it (laserPosegraphOptimization.cpp:518-531)."""
+
+    def __init__(self, max_source=200000, max_target=2000000, max_corr_dist=150.0, max_iterations=100, transformation_epsilon=1e-6,
+                 fitness_epsilon=1e-6, device=0):
+        self.h = C.c_void_p()
+        cfg = ICPConfig(max_corr_dist, transformation_epsilon, fitness_epsilon, max_iterations, max_source, max_target, device)
+        _check(lib().scal_icp_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_icp_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def align(self, src, tgt):
+        s, t = _f32(src), _f32(tgt)
+        r = ICPResult()
+        _check(lib().scal_icp_align(self.h, _p(s, _f32p), s.shape[0], _p(t, _f32p), t.shape[0], C.byref(r)))
+        return dict(converged=bool(r.converged), iterations=r.iterations, state=r.state, n_correspondences=r.n_correspondences,
+                    fitness=r.fitness, T=np.array(r.T[:]).reshape(4, 4))
 
 
 class MapMerge:

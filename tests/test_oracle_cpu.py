@@ -302,3 +302,28 @@ def test_mapmerge_oracle_properties(O, golden):
     db = np.linalg.norm(b[1:, :3].astype(np.float64) - b[:-1, :3], axis=1)
     assert np.abs(da - db).max() <= 2e-3  # optimized_poses.txt rotations are orthonormal to ~1e-6
     assert O.mapmerge([], np.zeros((0, 12))).shape == (0, 4)
+
+
+def test_icp_oracle_recovers_motion_and_gates(O, golden):
+    """pcl::IterativeClosestPoint restatement (laserPosegraphOptimization.cpp:518-535): a known rigid motion of a real keyframe
+    is recovered, the closed-form increment is a proper rotation, and the gates (iteration cap, too few correspondences,
+    correspondence distance) behave as PCL's do."""
+    a, _ = O.voxel_grid(golden("Seosan01_000000.npy"), 0.4)
+    th = 0.03
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([-0.3, 0.2, 0.1])
+    src = a.copy()
+    src[:, :3] = (a[:, :3].astype(np.float64) @ R.T + t).astype(np.float32)
+    r = O.icp_align(src, a)
+    Ti = np.eye(4)
+    Ti[:3, :3], Ti[:3, 3] = R.T, -R.T @ t
+    assert r["converged"] and r["state"] in (2, 3, 4) and r["iterations"] < 40
+    assert np.abs(r["T"] - Ti).max() <= 1e-5 and r["fitness"] <= 1e-9
+    Rf = r["T"][:3, :3]
+    assert abs(np.linalg.det(Rf) - 1.0) <= 1e-5 and np.abs(Rf @ Rf.T - np.eye(3)).max() <= 1e-5
+    capped = O.icp_align(src, a, max_iter=1)
+    assert capped["converged"] and capped["state"] == 1 and capped["iterations"] == 1
+    few = O.icp_align(src[:2], a)
+    assert not few["converged"] and few["state"] == 5
+    far = O.icp_align(src + np.array([1000, 0, 0, 0], np.float32), a, max_corr=1.0)
+    assert not far["converged"] and far["state"] == 5

@@ -270,3 +270,42 @@ def test_mapmerge_matches_oracle(O, S, golden):
     assert e.value.code == S.E_CAPACITY
     small.close()
     mm.close()
+
+
+def test_loop_icp_matches_oracle(O, S, golden):
+    """Loop-closure verification ICP (SURVEY 8f-2): the HIP path against the oracle's restatement of pcl::IterativeClosestPoint
+    on real keyframes downsampled at 0.4 m as doICPVirtualRelative prepares them.  Nearest neighbours are exact on both sides;
+    the f64 correspondence sums are added in a different order, so transforms agree to ~1e-6, not bit for bit."""
+    vg = S.VoxelGrid()
+    icp = S.LoopICP(max_source=100000, max_target=400000)
+    a = vg.filter(golden("KAIST03_000000.npy"), 0.4)
+    # (1) a known rigid motion is recovered
+    th = 0.04
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    t = np.array([0.4, -0.25, 0.05])
+    src = a.copy()
+    src[:, :3] = (a[:, :3].astype(np.float64) @ R.T + t).astype(np.float32)
+    rg, ro = icp.align(src, a), O.icp_align(src, a)
+    Ti = np.eye(4)
+    Ti[:3, :3], Ti[:3, 3] = R.T, -R.T @ t
+    assert rg["converged"] and ro["converged"] and rg["state"] == ro["state"]
+    assert np.abs(rg["T"] - Ti).max() <= 1e-5 and np.abs(rg["T"] - ro["T"]).max() <= 1e-5
+    assert rg["fitness"] <= 1e-9 and abs(rg["iterations"] - ro["iterations"]) <= 1
+    # (2) two different keyframes of the sample session (what the verification really sees: partial overlap)
+    b = vg.filter(golden("KAIST03_000007.npy"), 0.4)
+    tgt = np.concatenate([a, vg.filter(golden("KAIST03_000020.npy"), 0.4)])
+    rg, ro = icp.align(b, tgt), O.icp_align(b, tgt)
+    assert rg["converged"] == ro["converged"]
+    assert np.abs(rg["T"] - ro["T"]).max() <= 2e-3, (rg["T"], ro["T"])
+    assert abs(rg["fitness"] - ro["fitness"]) <= 1e-3 * max(1.0, ro["fitness"]), (rg["fitness"], ro["fitness"])
+    # (3) iteration cap, too few points, empty clouds
+    capped = S.LoopICP(max_source=100000, max_target=400000, max_iterations=2)
+    rc, rco = capped.align(b, tgt), O.icp_align(b, tgt, max_iter=2)
+    assert rc["iterations"] == 2 and rc["state"] == 1 and rc["converged"] and rco["state"] == 1
+    assert np.abs(rc["T"] - rco["T"]).max() <= 1e-5
+    r2 = icp.align(b[:2], tgt)
+    assert not r2["converged"] and r2["state"] == 5
+    r0 = icp.align(np.zeros((0, 4), np.float32), tgt)
+    assert not r0["converged"]
+    for x in (vg, icp, capped):
+        x.close()
