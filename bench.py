@@ -161,6 +161,8 @@ def main():
         cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
         return S.merge_candidates(cands, 0.4)
 
+    last_pose = {}
+
     def account(mst, r):
         stats["loops"] += r["loop_id"] >= 0
         stats["blocks"] += mst.n_edge[0] + mst.n_plane[0] + mst.n_edge[1] + mst.n_plane[1]
@@ -173,6 +175,7 @@ def main():
         timed("A.run_device", reg.run_device, d_scans[k].data_ptr(), npts[k], 3)
         qlc, tlc, qw, tw, ost = od.step_features(reg)
         qm, tm, mst = timed("C.process", mp.process_features, reg, qw, tw)
+        last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
         if world == 1:
             sc.insert_features(reg)
             r = sc.detectLoopClosureID()
@@ -279,6 +282,7 @@ def main():
             queue_front(k + 1, last)
         if pipe["map_pending"]:
             qm, tm, mst = timed("C.collect", mp.collect)
+            last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
             pipe["accounts"].append((mst, pipe["loop"]))
             while len(pipe["accounts"]) > 2:  # the exchange thread may lag two scans behind (their features contexts are still intact)
                 m_, l_ = pipe["accounts"].pop(0)
@@ -290,6 +294,7 @@ def main():
     def drain():
         if pipe["map_pending"]:
             qm, tm, mst = mp.collect()
+            last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
             pipe["accounts"].append((mst, pipe["loop"]))
             pipe["map_pending"] = False
         for m_, l_ in pipe["accounts"]:
@@ -360,7 +365,7 @@ def main():
                        else "serial: one scan at a time"},
             "roofline": roofline, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: v[0] / max(1, n_prof_steps) for k, v in sorted(prof.items())}, "profiled_steps": n_prof_steps,
-            "loops_detected": int(stats["loops"]), "input_gen_s": gen_s,
+            "loops_detected": int(stats["loops"]), "input_gen_s": gen_s, "final_map_pose": last_pose,
             "host_us_per_step": {k: v / K * 1e6 for k, v in host_t.items()} if a.host_timing else None,
         }
         print(json.dumps(out))
