@@ -5,8 +5,8 @@
 // VoxelGrid 0.4) are scal_mapmerge_* + scal_voxel_*.
 //
 // Per iteration (PCL icp.hpp computeTransformation, restated in oracle/icp.cpp):
-//   k_icp_nn      exact nearest target point of every current source point: 64 queries x 2048 targets per workgroup, targets
-//                 staged in LDS and read as wave-wide broadcasts, (f32 squared distance, target index) keys merged across
+//   k_icp_nn      exact nearest target point of every current source point: 1024 queries x 2048 targets per workgroup (4 queries
+//                 per thread), targets staged in LDS and read as wave-wide broadcasts, (f32 squared distance, target index) keys merged across
 //                 target chunks with 64-bit atomicMin (= smallest distance, lowest index on ties)
 //   k_icp_reduce  correspondences within max distance -> n, sum p, sum q, sum q p^T, sum d^2 in f64: fixed-order workgroup
 //                 partials, summed in workgroup order by the last kernel and written to pinned host memory
@@ -23,44 +23,44 @@
 
 namespace scal {
 
-constexpr int ICP_QT = 64;     // queries per workgroup
+constexpr int ICP_QPT = 4;     // queries per thread
+constexpr int ICP_QT = 256 * ICP_QPT;  // queries per workgroup
 constexpr int ICP_TC = 2048;   // targets per workgroup
 constexpr int ICP_NSUM = 17;   // n, sum p[3], sum q[3], sum q p^T[9], sum d^2
 
 __global__ void __launch_bounds__(256) k_icp_nn(const float4* __restrict__ cur, int n_src, const float4* __restrict__ tgt, int n_tgt,
                                                 unsigned long long* __restrict__ best) {
     __shared__ float4 st[ICP_TC];
-    __shared__ unsigned long long red[4][ICP_QT];
     const int t0 = blockIdx.y * ICP_TC;
     const int tn = min(ICP_TC, n_tgt - t0);
     for (int i = threadIdx.x; i < tn; i += 256) st[i] = tgt[t0 + i];
     __syncthreads();
-    const int ql = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int qi = blockIdx.x * ICP_QT + ql;
-    unsigned long long mine = ~0ull;
-    if (qi < n_src) {
-        const float4 q = cur[qi];
-        const int per = (tn + 3) / 4;
-        const int b0 = part * per, b1 = min(tn, b0 + per);
-        float bd = 3.4e38f;
-        int bi = -1;
-#pragma unroll 4
-        for (int t = b0; t < b1; ++t) {
-            const float4 p = st[t];
-            const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+    // every thread owns ICP_QPT queries and walks the whole chunk: one LDS broadcast read feeds ICP_QPT distance evaluations
+    float qx[ICP_QPT], qy[ICP_QPT], qz[ICP_QPT], bd[ICP_QPT];
+    int bi[ICP_QPT];
+#pragma unroll
+    for (int u = 0; u < ICP_QPT; ++u) {
+        const int qi = blockIdx.x * ICP_QT + u * 256 + threadIdx.x;
+        const float4 q = qi < n_src ? cur[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qx[u] = q.x, qy[u] = q.y, qz[u] = q.z, bd[u] = 3.4e38f, bi[u] = -1;
+    }
+#pragma unroll 2
+    for (int t = 0; t < tn; ++t) {
+        const float4 p = st[t];
+#pragma unroll
+        for (int u = 0; u < ICP_QPT; ++u) {
+            const float dx = qx[u] - p.x, dy = qy[u] - p.y, dz = qz[u] - p.z;
             float d = dx * dx;  // FLANN L2_Simple<float>, the metric of pcl::KdTreeFLANN
             d += dy * dy;
             d += dz * dz;
-            if (d < bd) bd = d, bi = t;  // ascending t: the lowest index of equal distances is kept
+            if (d < bd[u]) bd[u] = d, bi[u] = t;  // ascending t: the lowest index of equal distances is kept
         }
-        if (bi >= 0) mine = (static_cast<unsigned long long>(__float_as_uint(bd)) << 32) | static_cast<unsigned>(t0 + bi);
     }
-    red[part][ql] = mine;
-    __syncthreads();
-    if (part == 0 && qi < n_src) {
-        unsigned long long b = red[0][ql];
-        for (int p = 1; p < 4; ++p) b = red[p][ql] < b ? red[p][ql] : b;
-        if (b != ~0ull) atomicMin(&best[qi], b);
+#pragma unroll
+    for (int u = 0; u < ICP_QPT; ++u) {
+        const int qi = blockIdx.x * ICP_QT + u * 256 + threadIdx.x;
+        if (qi < n_src && bi[u] >= 0)
+            atomicMin(&best[qi], (static_cast<unsigned long long>(__float_as_uint(bd[u])) << 32) | static_cast<unsigned>(t0 + bi[u]));
     }
 }
 
