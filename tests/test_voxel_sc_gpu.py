@@ -309,3 +309,77 @@ def test_loop_icp_matches_oracle(O, S, golden):
     assert not r0["converged"]
     for x in (vg, icp, capped):
         x.close()
+
+
+def test_sc_5k_database_8_shards(S):
+    """BASELINE config #4 shape: a 5000-keyframe database sharded 8 ways (keyframe i on shard i % 8), batched insert + query per
+    step exactly as bench.py --gpus 8 issues them, against ONE context holding the whole database (the path validated against
+    the oracle above).  Every 25th step is compared: loop id, best candidate and its distance."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    G, steps = 8, 625
+    rng = np.random.default_rng(17)
+    base = rng.uniform(-2.0, 18.0, (64, 20, 60)) * (rng.uniform(size=(64, 20, 60)) < 0.5)
+    single = S.SCManager(dist_thres=0.3, max_keyframes=5100)
+    shards = [S.SCManager(dist_thres=0.3, max_keyframes=700, n_shards=G, shard=s) for s in range(G)]
+    d_q, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_q), G * 1200 * 8) == 0 and hip.hipMalloc(ctypes.byref(d_out), G * 3 * 24) == 0
+    counter, size_at_rebuild, n_global, hits, checked = 0, 0, 0, 0, 0
+    for st in range(steps):
+        batch = []
+        for q in range(G):
+            i = st * G + q
+            if i >= 100 and i % 9 == 0:   # a revisit: an old place seen again, rotated
+                d = np.roll(batch_hist[int(rng.integers(0, len(batch_hist) - 60))], int(rng.integers(0, 60)), axis=1)
+                d = d + rng.normal(0, 0.03, d.shape) * (d != 0)
+            else:
+                d = base[i % 64] * (rng.uniform(size=(20, 60)) < 0.97) + rng.normal(0, 0.4, (20, 60)) * (base[i % 64] != 0)
+                d = np.roll(d, int(rng.integers(0, 60)), axis=1) * rng.uniform(0.6, 1.4)
+            batch.append(d)
+        if st == 0:
+            batch_hist = []
+        batch_hist.extend(batch)
+        refs, limits = [], []
+        check = st % 25 == 24
+        for d in batch:
+            single.saveScancontextAndKeys(d)
+            n_global += 1
+            if check:
+                refs.append(single.detectLoopClosureID())
+            elif n_global >= 31:  # keep the single context's tree period in step with the reference sequence
+                refs.append(single.detectLoopClosureID())
+            else:
+                refs.append(None)
+            if n_global >= 31:
+                if counter % 30 == 0:
+                    size_at_rebuild = n_global
+                counter += 1
+            limits.append(size_at_rebuild)
+        host = np.ascontiguousarray(np.stack([d.T.reshape(-1) for d in batch]), np.float64)
+        assert hip.hipMemcpy(d_q, host.ctypes.data, host.nbytes, 1) == 0
+        recs = []
+        for sh in shards:
+            sh.insert_descriptors_device(d_q, G)
+            if check:
+                sh.shard_query_batch_device(d_q, limits, d_out)
+                sh.sync()
+                buf = np.zeros(G * 3 * 24, np.uint8)
+                assert hip.hipMemcpy(buf.ctypes.data, d_out, buf.nbytes, 2) == 0
+                recs.append(buf.reshape(G, 3, 24))
+        if check:
+            for q in range(G):
+                cands = [S.SCCand.from_buffer_copy(recs[s][q, j].tobytes()) for s in range(G) for j in range(3)]
+                got = S.merge_candidates(cands, 0.3)
+                assert got["loop_id"] == refs[q]["loop_id"] and got["nn_idx"] == refs[q]["nn_idx"], (st, q)
+                assert abs(got["min_dist"] - refs[q]["min_dist"]) <= 1e-12, (st, q)
+                hits += got["loop_id"] >= 0
+                checked += 1
+    assert single.size() == 5000 and sum(sh.size() for sh in shards) == 5000 * G  # every shard counts every global insert
+    assert checked == 200 and hits > 5
+    hip.hipFree(d_q), hip.hipFree(d_out)
+    for sh in shards:
+        sh.close()
+    single.close()
