@@ -58,7 +58,8 @@ __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int
 
 __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
                                                     const int* __restrict__ d_n, int shift, const int* __restrict__ d_used_bits,
-                                                    const int* __restrict__ hist, unsigned long long* __restrict__ okeys, int* __restrict__ ovals) {
+                                                    const int* __restrict__ hist, unsigned long long* __restrict__ okeys, int* __restrict__ ovals,
+                                                    int scanned) {
     if (!pass_active(d_used_bits, shift)) return;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
@@ -68,8 +69,11 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
     // scatter base of digit d for this block = (exclusive prefix of the digit totals)[d] + sum_{b < block} hist[d][b]
-    int before[2] = {0, 0}, totals[2] = {0, 0};
-    {
+    if (scanned) {  // large sorts: the histogram matrix has been turned into scatter bases by the hierarchical scan
+        sbase[2 * threadIdx.x] = hist[(2 * threadIdx.x) * nb + blockIdx.x];
+        sbase[2 * threadIdx.x + 1] = hist[(2 * threadIdx.x + 1) * nb + blockIdx.x];
+    } else {
+        int before[2] = {0, 0}, totals[2] = {0, 0};
         // both rows are read in batches of 8 independent loads: one dependent load per block column would serialise
         // ~2 x nb L2 round trips in front of the scatter
         const int* row0 = hist + (2 * threadIdx.x) * nb;
@@ -89,11 +93,11 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
                 if (b0 + q < me) before[0] += v0[q], before[1] += v1[q];
             }
         }
+        int dummy;
+        const int pre = block_exclusive_scan(totals[0] + totals[1], smem, &dummy);
+        sbase[2 * threadIdx.x] = pre + before[0];
+        sbase[2 * threadIdx.x + 1] = pre + totals[0] + before[1];
     }
-    int dummy;
-    const int pre = block_exclusive_scan(totals[0] + totals[1], smem, &dummy);
-    sbase[2 * threadIdx.x] = pre + before[0];
-    sbase[2 * threadIdx.x + 1] = pre + totals[0] + before[1];
     for (int i = threadIdx.x; i < 4 * RS_BINS; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
@@ -128,11 +132,77 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     }
 }
 
+// ---- hierarchical exclusive scan of the flattened histogram matrix (digit-major: exactly the scatter base of (digit, block)),
+// used when the sort has too many blocks for every scatter workgroup to sum the matrix rows itself.  m = BINS * nb.
+constexpr int HS_TILE = 4096;
+__global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data, const int* __restrict__ d_n, int shift,
+                                                     const int* __restrict__ d_used_bits, int* __restrict__ tile_sum) {
+    if (!pass_active(d_used_bits, shift)) return;
+    __shared__ int smem[17];
+    const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
+    const int m = RS_BINS * nb;
+    const int base = blockIdx.x * HS_TILE;
+    if (base >= m) return;
+    int sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = base + q * 1024 + threadIdx.x;
+        sum += i < m ? data[i] : 0;
+    }
+    int total;
+    block_exclusive_scan(sum, smem, &total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, const int* __restrict__ d_n, int shift,
+                                                    const int* __restrict__ d_used_bits) {
+    if (!pass_active(d_used_bits, shift)) return;
+    __shared__ int smem[17];
+    const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
+    const int nt = (RS_BINS * nb + HS_TILE - 1) / HS_TILE;
+    const int per = (nt + 1023) / 1024;
+    const int b0 = min(nt, static_cast<int>(threadIdx.x) * per), b1 = min(nt, b0 + per);
+    int sum = 0;
+    for (int i = b0; i < b1; ++i) sum += tile_sum[i];
+    int total;
+    int run = block_exclusive_scan(sum, smem, &total);
+    for (int i = b0; i < b1; ++i) {
+        const int v = tile_sum[i];
+        tile_sum[i] = run;
+        run += v;
+    }
+}
+__global__ void __launch_bounds__(1024) k_hs_apply(int* __restrict__ data, const int* __restrict__ d_n, int shift, const int* __restrict__ d_used_bits,
+                                                    const int* __restrict__ tile_off) {
+    if (!pass_active(d_used_bits, shift)) return;
+    __shared__ int smem[17];
+    const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
+    const int m = RS_BINS * nb;
+    const int base = blockIdx.x * HS_TILE;
+    if (base >= m) return;
+    // thread t owns elements base + 4t .. base + 4t + 3 (consecutive), so one block scan orders the whole tile
+    int v[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = base + 4 * threadIdx.x + q;
+        v[q] = i < m ? data[i] : 0;
+        sum += v[q];
+    }
+    int total;
+    int run = tile_off[blockIdx.x] + block_exclusive_scan(sum, smem, &total);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = base + 4 * threadIdx.x + q;
+        if (i < m) data[i] = run;
+        run += v[q];
+    }
+}
+
 int RadixSort::init(int capacity) {
     cap = capacity;
     SCAL_TRY(keys_alt.alloc(cap));
     SCAL_TRY(vals_alt.alloc(cap));
     SCAL_TRY(hist.alloc((size_t)BINS * div_up(cap, TILE) + BINS));
+    SCAL_TRY(tile_sum.alloc(div_up(BINS * div_up(cap, TILE), HS_TILE) + 1));
     return SCAL_OK;
 }
 
@@ -141,12 +211,20 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     unsigned long long* kb[2] = {keys, keys_alt.p};
     int* vb[2] = {vals, vals_alt.p};
     const int nb = max(1, div_up(min(cap, max(n_bound, 1)), TILE));
+    const bool big = nb > 256;  // every scatter workgroup summing 2 x nb matrix entries per thread stops paying off
+    const int nt = div_up(BINS * nb, HS_TILE);
     int pass = 0;
     for (int shift = 0; shift < max_bits; shift += DIGIT, ++pass) {
         const int in = pass & 1, o = in ^ 1;
         hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p);
+        if (big) {
+            hipLaunchKernelGGL(k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, shift, d_used_bits, tile_sum.p);
+            hipLaunchKernelGGL(k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, shift, d_used_bits);
+            hipLaunchKernelGGL(k_hs_apply, dim3(nt), dim3(1024), 0, s, hist.p, d_n, shift, d_used_bits, tile_sum.p);
+        }
         {
-            SCAL_LAUNCH_PROF("k_rs_scatter", k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o]);
+            SCAL_LAUNCH_PROF("k_rs_scatter", k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o],
+                             big ? 1 : 0);
         }
     }
     out->keys[0] = kb[0], out->keys[1] = kb[1];

@@ -24,6 +24,7 @@ struct RadixSort {
     DevBuf<unsigned long long> keys_alt;
     DevBuf<int> vals_alt;
     DevBuf<int> hist;  // [BINS][nb]
+    DevBuf<int> tile_sum;  // hierarchical scan of hist for large sorts
 
     int init(int capacity);
     // Sorts the first *d_n pairs (*d_n <= n_bound, host-known) by bits [0, max_bits) of the key, ascending, stable.

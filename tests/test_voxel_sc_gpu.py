@@ -383,3 +383,21 @@ def test_sc_5k_database_8_shards(S):
     for sh in shards:
         sh.close()
     single.close()
+
+
+def test_voxel_large_cloud(O, S):
+    """A cloud large enough (1.5 M points) for the radix sort's hierarchical histogram scan: still the PCL order and the ordered
+    f32 centroids, bit for bit."""
+    rng = np.random.default_rng(21)
+    n = 1500000
+    p = np.empty((n, 4), np.float32)
+    p[:, :3] = rng.uniform(-150, 150, (n, 3)).astype(np.float32)
+    p[:, 2] *= 0.1
+    p[:, 3] = rng.uniform(0, 64, n).astype(np.float32)
+    p[: n // 4] = p[n // 2: n // 2 + n // 4] + np.float32(0.01)  # dense voxels too
+    vg = S.VoxelGrid(max_points=1600000)
+    g = vg.filter(p, 0.5)
+    o, guard = O.voxel_grid(p, 0.5, order_mode=1)
+    assert guard == 0 and g.shape == o.shape
+    assert np.array_equal(_bits(g), _bits(o))
+    vg.close()
