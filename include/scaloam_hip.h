@@ -283,6 +283,9 @@ int scal_mapmerge_add_batch_device(scal_mapmerge_t* ctx, const float* d_xyzi, co
                                    int n_frames, double near_thres);
 long long scal_mapmerge_size(scal_mapmerge_t* ctx);                                 /* points merged so far (waits), <0 = error */
 int scal_mapmerge_download(scal_mapmerge_t* ctx, float* out_xyzi, long long cap_points);
+/* pubMap's VoxelGrid over the merged map (laserPosegraphOptimization.cpp:810-834, leaf = mapviz_filter_size): *n_out centroids
+ * in PCL order, the first cap_points of them written to out_xyzi (host).  The merged map itself is kept. */
+int scal_mapmerge_downsample(scal_mapmerge_t* ctx, float leaf, float* out_xyzi, long long cap_points, long long* n_out);
 const float* scal_mapmerge_device_points(scal_mapmerge_t* ctx);                     /* the merged xyzi records in device memory */
 
 /* ------------------------------------------------------------------ loop-closure verification ICP

@@ -12,6 +12,7 @@
 // A workgroup handles 1024 consecutive points of ONE frame; a batch of frames is one launch of each kernel.
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "voxel_dev.hpp"
 #include <vector>
 #include <cstring>
 
@@ -139,6 +140,11 @@ struct scal_mapmerge {
     DevBuf<int> d_error;
     int nb_cap = 0, pose_cap = 0;
     long long n_host = 0;  // upper bound of the running total known to the host (sum of the frame sizes added)
+    // downsampling of the merged map (lazily allocated)
+    VoxelFilter vf;
+    DevBuf<float> sx, sy, sz, sw, ox, oy, oz, ow;
+    DevBuf<int> d_n;
+    bool vf_ready = false;
 };
 
 extern "C" int scal_mapmerge_create(const scal_mapmerge_config* cfg, scal_mapmerge_t** out) {
@@ -286,3 +292,55 @@ extern "C" int scal_mapmerge_download(scal_mapmerge_t* c, float* out_xyzi, long 
 }
 
 extern "C" const float* scal_mapmerge_device_points(scal_mapmerge_t* c) { return c ? reinterpret_cast<const float*>(c->out.p) : nullptr; }
+
+// pubMap's VoxelGrid over the merged map (laserPosegraphOptimization.cpp:810-834, leaf = mapviz_filter_size): PCL order, ordered
+// f32 centroids, PCL's overflow guard (output = input when the voxel count overflows int32).  Result to host memory.
+extern "C" int scal_mapmerge_downsample(scal_mapmerge_t* c, float leaf, float* out_xyzi, long long cap_points, long long* n_out) {
+    if (!c || !(leaf > 0) || !n_out || cap_points < 0 || (cap_points > 0 && !out_xyzi)) {
+        set_error("scal_mapmerge_downsample: bad argument");
+        return SCAL_E_ARG;
+    }
+    const long long n = scal_mapmerge_size(c);
+    if (n < 0) return static_cast<int>(n);
+    if (n > 2000000000ll) {
+        set_error("scal_mapmerge_downsample: %lld points exceed the 32-bit indices of the voxel filter", n);
+        return SCAL_E_TOO_MANY;
+    }
+    *n_out = 0;
+    if (n == 0) return SCAL_OK;
+    hipStream_t s = c->stream;
+    if (!c->vf_ready) {
+        const int cap = static_cast<int>(std::min<long long>(c->cap, 2000000000ll));
+        SCAL_TRY(c->vf.init(cap));
+        SCAL_TRY(c->sx.alloc(cap)); SCAL_TRY(c->sy.alloc(cap)); SCAL_TRY(c->sz.alloc(cap)); SCAL_TRY(c->sw.alloc(cap));
+        SCAL_TRY(c->ox.alloc(cap)); SCAL_TRY(c->oy.alloc(cap)); SCAL_TRY(c->oz.alloc(cap)); SCAL_TRY(c->ow.alloc(cap));
+        SCAL_TRY(c->d_n.alloc(2));
+        c->vf_ready = true;
+    }
+    const int ni = static_cast<int>(n);
+    launch_deinterleave(s, reinterpret_cast<const float*>(c->out.p), ni, SoA4{c->sx.p, c->sy.p, c->sz.p, c->sw.p});
+    SCAL_HIP(hipMemcpyAsync(c->d_n.p, &ni, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_TRY(c->vf.run(s, CSoA4{c->sx.p, c->sy.p, c->sz.p, c->sw.p}, c->d_n.p, ni, leaf, 45, SoA4{c->ox.p, c->oy.p, c->oz.p, c->ow.p}, c->d_n.p + 1));
+    int m = 0;
+    VoxMeta hm;
+    SCAL_HIP(hipMemcpyAsync(&m, c->d_n.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(&hm, c->vf.meta.p, sizeof hm, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    if (hm.error) {
+        set_error("scal_mapmerge_downsample: the map's bounding box needs more voxel-key bits than the sort is given (leaf %g)", leaf);
+        return hm.error;
+    }
+    *n_out = m;
+    const long long w = std::min<long long>(m, cap_points);
+    if (w > 0) {  // the four centroid components come back separately and are interleaved on the host (offline path)
+        std::vector<float> comp(static_cast<size_t>(w));
+        const float* src[4] = {c->ox.p, c->oy.p, c->oz.p, c->ow.p};
+        for (int k = 0; k < 4; ++k) {
+            SCAL_HIP(hipMemcpyAsync(comp.data(), src[k], sizeof(float) * static_cast<size_t>(w), hipMemcpyDeviceToHost, s));
+            SCAL_HIP(hipStreamSynchronize(s));
+            for (long long i = 0; i < w; ++i) out_xyzi[4 * i + k] = comp[static_cast<size_t>(i)];
+        }
+    }
+    return SCAL_OK;
+}

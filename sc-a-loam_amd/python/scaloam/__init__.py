@@ -99,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
-    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_icp_create", "scal_icp_destroy", "scal_icp_align",
+    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
@@ -183,6 +183,7 @@ def lib():
     L.scal_mapmerge_size.argtypes = [vp]
     L.scal_mapmerge_size.restype = C.c_longlong
     L.scal_mapmerge_download.argtypes = [vp, _f32p, C.c_longlong]
+    L.scal_mapmerge_downsample.argtypes = [vp, C.c_float, _f32p, C.c_longlong, C.POINTER(C.c_longlong)]
     L.scal_mapmerge_device_points.argtypes = [vp]
     L.scal_mapmerge_device_points.restype = vp
     L.scal_odom_create.argtypes = [C.POINTER(OdomConfig), C.POINTER(vp)]
@@ -614,6 +615,13 @@ class MapMerge:
         out = np.zeros((max(n, 1), 4), np.float32)
         _check(lib().scal_mapmerge_download(self.h, _p(out, _f32p), n))
         return out[:n]
+
+    def downsample(self, leaf):
+        n = self.size()
+        out = np.zeros((max(n, 1), 4), np.float32)
+        m = C.c_longlong(0)
+        _check(lib().scal_mapmerge_downsample(self.h, C.c_float(leaf), _p(out, _f32p), n, C.byref(m)))
+        return out[:m.value].copy()
 
     def device_points(self):
         return lib().scal_mapmerge_device_points(self.h)

@@ -259,6 +259,11 @@ def test_mapmerge_matches_oracle(O, S, golden):
     mm.add_batch_device(d, offs, poses, 2.0)
     got2 = mm.download()
     assert np.array_equal(_bits(got2), _bits(want))
+    # pubMap's VoxelGrid over the merged map = the oracle's voxel grid over the oracle's merge
+    ds = mm.downsample(0.4)
+    dso, guard = O.voxel_grid(want, 0.4, order_mode=1)
+    assert guard == 0 and ds.shape == dso.shape and np.array_equal(_bits(ds), _bits(dso))
+    assert mm.size() == want.shape[0]  # the merged map is kept
     # appending continues behind what is there
     mm.add(frames[0], poses[0], 2.0)
     assert mm.size() == want.shape[0] + int((np.sqrt((frames[0][:, :3].astype(np.float64) ** 2).sum(1)) > 2.0).sum())

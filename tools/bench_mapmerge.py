@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=40)
+    ap.add_argument("--voxel", type=float, default=0.0, help="also time the VoxelGrid downsample of the merged map at this leaf size")
     a = ap.parse_args()
     import torch
     import scaloam as S
@@ -67,13 +68,25 @@ def main():
     cpu_dt = time.perf_counter() - t1
     got = mm.download()[: ref.shape[0]]
     ok = bool(np.array_equal(got.view(np.uint32), ref.view(np.uint32)))
+    vox = None
+    if a.voxel > 0:
+        import ctypes as C
+        m = C.c_longlong(0)
+        dummy = np.zeros((1, 4), np.float32)
+        lib = S.lib()
+        for _ in range(2):  # first call allocates
+            t2 = time.perf_counter()
+            S._check(lib.scal_mapmerge_downsample(mm.h, C.c_float(a.voxel), dummy.ctypes.data_as(C.POINTER(C.c_float)), 0, C.byref(m)))
+            vdt = time.perf_counter() - t2
+        vox = {"leaf": a.voxel, "points_in": kept, "points_out": int(m.value), "ms": vdt * 1e3, "points_per_s": kept / vdt,
+               "note": "device time incl. the deinterleave, bounding box, radix sort (hierarchical histogram scan) and ordered centroids; no download"}
     print(json.dumps({
         "metric": "points/sec merged (transform + near-range removal + concatenate), offline map merge", "value": n_total / dt, "unit": "points/s",
         "frames": a.frames, "points_in": n_total, "points_out": kept, "ms_per_merge": dt * 1e3, "dtype": "f32 points / f64 transform",
         "roofline": {"bound": "hbm", "kernel": "k_mm_write", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg, "traffic": None},
         "cpu_baseline": {"value": int(offs[nc]) / cpu_dt, "unit": "points/s", "cores": 1, "kind": "port", "sample": f"first {nc} frames through the oracle"},
-        "matches_oracle_on_sample": ok}))
+        "matches_oracle_on_sample": ok, "voxel_downsample": vox}))
 
 
 if __name__ == "__main__":
