@@ -109,12 +109,15 @@ def main():
     # One stream per stage, consecutive scans overlapping like the reference's four ROS nodes (scanRegistration, laserOdometry,
     # laserMapping, laserPosegraphOptimization run concurrently on different scans); two features contexts used alternately.
     S.set_stream_mode(1 if pipelined else 0)
-    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range(a.ring if pipelined else 1)]
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range((max(a.ring, 6) if world > 1 else a.ring) if pipelined else 1)]  # N > 1: the exchange thread may lag 3 scans
     reg = regs[0]
     od = S.LaserOdometry(max_points=cap, device=local)
     mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
+    # N > 1, pipelined: the database shard gets its own stream (lane 5) so that its small insert/query kernels never queue behind
+    # the next scan's descriptor build, which runs in a separate builder context on the stage-D stream
     sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=a.sc_db // world + total * world + 64, device=local,
-                     n_shards=world, shard=rank)
+                     n_shards=world, shard=rank, side_stream=5 if (pipelined and world > 1) else 0)
+    sc_build = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=8, device=local) if (pipelined and world > 1) else None
     rng = np.random.default_rng(4242)
     for d in synth_descs(rng, a.sc_db):
         sc.saveScancontextAndKeys(d.T)  # every shard sees every insert and keeps the ones it owns
@@ -140,7 +143,7 @@ def main():
     def sc_sharded(k, queued=False):
         """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records)"""
         if queued:
-            sc.sync()  # the descriptor was queued right behind stage A
+            sc_build.wait_descriptor()  # the oldest queued descriptor (scan k); younger builds keep running
         else:
             sc.make_features(reg, d_q[k % 2].data_ptr())
         all_gather(all_q, d_q[k % 2])
@@ -214,14 +217,18 @@ def main():
 
     def xchg_worker():
         torch.cuda.set_device(local)
+        prev = None
         while True:
             job = xchg_q.get()
             if job is None:
                 return
-            k, r_ = job
             try:
-                sc.make_features_enqueue(r_, d_q[k % 2].data_ptr())
-                loop_q.put(sc_sharded(k, True))
+                if job != "flush":
+                    k, r_ = job
+                    sc_build.make_features_enqueue(r_, d_q[k % 2].data_ptr())  # scan k's descriptor starts building ...
+                if prev is not None:
+                    loop_q.put(sc_sharded(prev, True))                         # ... while scan k-1's is exchanged and searched
+                prev = None if job == "flush" else k
             except Exception as e:
                 loop_q.put(e)
 
@@ -297,6 +304,8 @@ def main():
             last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
             pipe["accounts"].append((mst, pipe["loop"]))
             pipe["map_pending"] = False
+        if xchg_thread and any(l_ is PENDING for _, l_ in pipe["accounts"]):
+            xchg_q.put("flush")  # the exchange of the last scan runs one job late
         for m_, l_ in pipe["accounts"]:
             account(m_, loop_result(l_))
         pipe["accounts"] = []

@@ -118,8 +118,9 @@ typedef struct {
     int device;
     /* sharding (multi-GPU): this context stores keyframes i with i % n_shards == shard; 1/0 = everything */
     int n_shards, shard;
-    /* 1: run this context on the device's side stream so that insert/detect overlap with stages B and C of the same scan;
-     * ordering against the features context (scal_sc_insert_features / scal_sc_make_features) is kept with events */
+    /* n > 0: run this context on the device's side stream n (1..5) so that insert/detect overlap with stages B and C of the
+     * same scan; ordering against the features context (scal_sc_insert_features / scal_sc_make_features) is kept with events.
+     * Two contexts on different lanes do not queue behind each other (descriptor builder: 1, sharded database: 5). */
     int side_stream;
 } scal_sc_config;
 
@@ -152,8 +153,10 @@ int scal_sc_insert_features(scal_sc_t* ctx, scal_features_t* feat);
 /* same front end but the 20x60 descriptor is only written to d_desc (device memory, 1200 doubles, column-major)
  * and NOT inserted: the sharded search exchanges descriptors first. */
 int scal_sc_make_features(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
-/* the same without waiting: d_desc is valid after scal_sc_sync */
+/* the same without waiting: d_desc is valid after scal_sc_sync, or after scal_sc_wait_descriptor, which waits for the oldest
+ * queued descriptor only (up to four may be in flight) */
 int scal_sc_make_features_enqueue(scal_sc_t* ctx, scal_features_t* feat, double* d_desc);
+int scal_sc_wait_descriptor(scal_sc_t* ctx);
 int scal_sc_insert_descriptor_device(scal_sc_t* ctx, const double* d_desc_colmajor);
 /* n (<= 64) device-resident descriptors in global order - the ranks' descriptors of one step after the all-gather - in one
  * launch and without a host synchronisation; every shard keeps the ones it owns */

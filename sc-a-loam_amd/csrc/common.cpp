@@ -47,12 +47,12 @@ struct DevStream {
     hipStream_t s = nullptr;
     int refs = 0;
 };
-DevStream g_streams[64][5];  // [device][lane], see common.hpp
+DevStream g_streams[64][6];  // [device][lane], see common.hpp
 int g_stream_mode = 0;
 }  // namespace
 
 int acquire_stream(int device, hipStream_t* out, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 4) {
+    if (device < 0 || device >= 64 || lane < 0 || lane > 5) {
         set_error("device ordinal %d out of range", device);
         return SCAL_E_ARG;
     }
@@ -79,7 +79,7 @@ int stage_lane(int stage) {
 }
 
 void release_stream(int device, int lane) {
-    if (device < 0 || device >= 64 || lane < 0 || lane > 4) return;
+    if (device < 0 || device >= 64 || lane < 0 || lane > 5) return;
     std::lock_guard<std::mutex> lk(g_stream_mu);
     DevStream& d = g_streams[device][lane];
     if (d.refs > 0 && --d.refs == 0 && d.s) {

@@ -36,7 +36,8 @@ int select_device(int device);
 // (1: ScanContext with scal_sc_config::side_stream, 2: scal_map_prefetch_features).  With scal_set_stream_mode(1) (set before
 // the contexts are created) every stage gets its own stream - A: 0, D: 1, C prefetch: 2, B: 3, C: 4 - so that consecutive
 // scans overlap the way the reference's four ROS nodes do; every hand-over between contexts is ordered by events in both
-// directions (features_wait_done / features_note_reader).
+// directions (features_wait_done / features_note_reader).  Lane 5 is free for a context that must not queue behind another one
+// of its kind (scal_sc_config::side_stream = 5: the sharded database next to the descriptor builder, bench.py --gpus N).
 enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4 };
 int stage_lane(int stage);
 int acquire_stream(int device, hipStream_t* out, int lane = 0);

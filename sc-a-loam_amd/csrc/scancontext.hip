@@ -481,6 +481,8 @@ struct scal_sc {
     PinBuf<int> bq_hlimits;
     int bq_cap = 0, bq_nb = 0;
     int detect_pending = 0;  // 1: search launched, 2: database too small (nothing launched)
+    hipEvent_t made_ev[4] = {};  // descriptors queued by scal_sc_make_features_enqueue, oldest first
+    unsigned made_head = 0, made_tail = 0;
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
     SCSlot staging() const { return SCSlot{qdesc.p, qrkey.p, qskey.p, qnorm.p}; }
     SCSlot slot(size_t sl) const { return SCSlot{desc.p + sl * DESC, rkey.p + sl * NR, skey.p + sl * NS, cnorm.p + sl * NS}; }
@@ -515,7 +517,7 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->gcell.alloc(DESC));
     if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
     A(c->h_rec.alloc(4));
-    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane = (c->cfg.side_stream ? 1 : stage_lane(STAGE_SC))) != SCAL_OK) {
+    if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane = (c->cfg.side_stream > 0 ? std::min(c->cfg.side_stream, 5) : stage_lane(STAGE_SC))) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
@@ -693,7 +695,31 @@ static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bo
     SCAL_TRY(ds_features(c, feat, &d_n, &cap));
     SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, false));
     SCAL_HIP(hipMemcpyAsync(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
-    if (wait) SCAL_HIP(hipStreamSynchronize(c->stream));
+    if (wait) {
+        SCAL_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        if (c->made_tail - c->made_head >= 4) {
+            set_error("scal_sc_make_features_enqueue: four descriptors are queued and none has been waited for");
+            return SCAL_E_STATE;
+        }
+        hipEvent_t& ev = c->made_ev[c->made_tail % 4];
+        if (!ev) SCAL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        SCAL_HIP(hipEventRecord(ev, c->stream));
+        c->made_tail++;
+    }
+    return SCAL_OK;
+}
+// waits for the OLDEST descriptor queued by scal_sc_make_features_enqueue (not for younger work on the stream)
+extern "C" int scal_sc_wait_descriptor(scal_sc_t* c) {
+    if (!c) return SCAL_E_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->made_head == c->made_tail) {
+        set_error("scal_sc_wait_descriptor: nothing queued");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_HIP(hipEventSynchronize(c->made_ev[c->made_head % 4]));
+    c->made_head++;
     return SCAL_OK;
 }
 extern "C" int scal_sc_make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc) { return make_features(c, feat, d_desc, true); }

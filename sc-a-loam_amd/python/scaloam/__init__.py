@@ -96,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
-    "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue",
+    "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
     "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align",
@@ -153,6 +153,7 @@ def lib():
     L.scal_sc_insert_descriptors_device.argtypes = [vp, vp, C.c_int]
     L.scal_sc_sync.argtypes = [vp]
     L.scal_sc_make_features_enqueue.argtypes = [vp, vp, vp]
+    L.scal_sc_wait_descriptor.argtypes = [vp]
     L.scal_prof_enable.argtypes = [C.c_int]
     L.scal_prof_filter.argtypes = [C.c_char_p]
     L.scal_prof_read.argtypes = [C.c_char_p, _f64p, C.POINTER(C.c_long)]
@@ -377,6 +378,9 @@ class SCManager:
 
     def make_features_enqueue(self, feat, d_desc_ptr):
         _check(lib().scal_sc_make_features_enqueue(self.h, feat.h, d_desc_ptr))
+
+    def wait_descriptor(self):
+        _check(lib().scal_sc_wait_descriptor(self.h))
 
     def insert_descriptor_device(self, d_desc_ptr):
         _check(lib().scal_sc_insert_descriptor_device(self.h, d_desc_ptr))
