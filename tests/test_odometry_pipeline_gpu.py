@@ -231,3 +231,67 @@ def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
             x.close()
     finally:
         S.set_stream_mode(0)
+
+
+def test_sharded_stage_d_flow_equals_single_context(S, hdl64_stream):
+    """The stage-D flow bench.py uses for N > 1, in one process: a builder context turns the keyframe cloud into a descriptor
+    (queued, waited for by ticket order while the next one is already building), two database shards insert / answer in batches.
+    Must equal ONE context doing insert_features + detectLoopClosureID on the same scans."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    G = 2
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(2)]
+    single = S.SCManager(dist_thres=0.4)
+    builder = S.SCManager(dist_thres=0.4, max_keyframes=4, side_stream=1)
+    shards = [S.SCManager(dist_thres=0.4, n_shards=G, shard=s, side_stream=5) for s in range(G)]
+    rng = np.random.default_rng(23)
+    for i in range(40):
+        d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
+        single.saveScancontextAndKeys(d)
+        for sh in shards:
+            sh.saveScancontextAndKeys(d)
+    d_q = [ctypes.c_void_p(), ctypes.c_void_p()]
+    d_out = ctypes.c_void_p()
+    for p in d_q:
+        assert hip.hipMalloc(ctypes.byref(p), 1200 * 8) == 0
+    assert hip.hipMalloc(ctypes.byref(d_out), 3 * 24) == 0
+    counter, size_at_rebuild, n_global = 0, 0, 40
+    refs, got = [], []
+
+    def exchange(k):
+        nonlocal counter, size_at_rebuild, n_global
+        builder.wait_descriptor()
+        n_global += 1
+        if counter % 30 == 0:
+            size_at_rebuild = n_global
+        counter += 1
+        cands = []
+        for sh in shards:
+            sh.insert_descriptors_device(d_q[k % 2], 1)
+            sh.shard_query_batch_device(d_q[k % 2], [size_at_rebuild], d_out)
+            sh.sync()
+            buf = np.zeros(3 * 24, np.uint8)
+            assert hip.hipMemcpy(buf.ctypes.data, d_out, buf.nbytes, 2) == 0
+            cands += [S.SCCand.from_buffer_copy(buf[24 * j:24 * j + 24].tobytes()) for j in range(3)]
+        got.append(S.merge_candidates(cands, 0.4))
+
+    n = 6
+    for k in range(n):
+        reg = regs[k % 2]
+        reg.laserCloudHandler(hdl64_stream(k))
+        single.insert_features(reg)
+        refs.append(single.detectLoopClosureID())
+        builder.make_features_enqueue(reg, d_q[k % 2])   # scan k builds ...
+        if k > 0:
+            exchange(k - 1)                              # ... while scan k-1 is exchanged
+    exchange(n - 1)
+    for k in range(n):
+        assert got[k]["loop_id"] == refs[k]["loop_id"] and got[k]["nn_idx"] == refs[k]["nn_idx"], k
+        assert abs(got[k]["min_dist"] - refs[k]["min_dist"]) <= 1e-12, k
+    for p in d_q + [d_out]:
+        hip.hipFree(p)
+    for x in regs + [single, builder] + shards:
+        x.close()
