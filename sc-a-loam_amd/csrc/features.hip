@@ -18,6 +18,7 @@
 // Data layout: SoA x[] y[] z[] intensity[] in HBM (coalesced 4 B/lane loads; the whole scan is < 2 MB and lives
 // in L2).  All f32 arithmetic that feeds a comparison is compiled without FMA contraction.
 #include "common.hpp"
+#include <cstring>
 #include <mutex>
 #include "device_utils.hpp"
 #include "features_dev.hpp"
@@ -682,6 +683,7 @@ struct scal_features {
     std::mutex ev_mu;  // consumers may register from different host threads  // seen once: record done_ev right behind every run, before later main-stream work
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
+    PinBuf<float> h_in;  // pinned staging of host scans: the upload is then an ordinary stream-ordered copy (see scal_features_run)
     DevBuf<signed char> d_ring;
     DevBuf<float> d_ori;
     DevBuf<int> d_hist;
@@ -774,6 +776,7 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     int rc = SCAL_OK;
     auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
     A(c->d_in.alloc((size_t)cap * 8));  // up to 32-byte point stride
+    A(c->h_in.alloc((size_t)cap * 8));
     A(c->d_ring.alloc(cap));
     A(c->d_ori.alloc(cap));
     A(c->d_hist.alloc((size_t)64 * c->nb_cap));
@@ -952,7 +955,13 @@ extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int
         return SCAL_E_TOO_MANY;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    if (n > 0) SCAL_HIP(hipMemcpyAsync(c->d_in.p, xyz, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        // The caller's (usually pageable) buffer is staged through pinned memory.  Asynchronous copies straight from pageable
+        // memory are legal, but one run in ~50 of the test-suite saw stage A read stale device memory after a 1.2 KB upload.
+        SCAL_HIP(hipStreamSynchronize(c->stream));  // the staging buffer may still feed the previous upload
+        std::memcpy(c->h_in.p, xyz, (size_t)n * stride_bytes);
+        SCAL_HIP(hipMemcpyAsync(c->d_in.p, c->h_in.p, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+    }
     SCAL_TRY(launch_chain(c, c->d_in.p, n, stride_bytes / 4));
     if (out) return scal_features_fetch(c, out);
     return scal_features_sync(c);

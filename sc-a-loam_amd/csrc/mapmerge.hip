@@ -133,6 +133,9 @@ struct scal_mapmerge {
     hipStream_t stream = nullptr;
     long long cap = 0;
     DevBuf<float4> out, stage;
+    PinBuf<float4> h_stage;     // pinned staging of host frames, block descriptors and poses (stream-ordered uploads)
+    PinBuf<MMBlock> h_blocks;
+    PinBuf<double> h_poses;
     DevBuf<MMBlock> blocks;
     DevBuf<int> blkcnt;
     DevBuf<double> poses;
@@ -161,6 +164,7 @@ extern "C" int scal_mapmerge_create(const scal_mapmerge_config* cfg, scal_mapmer
     auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
     A(c->out.alloc(static_cast<size_t>(c->cap)));
     A(c->stage.alloc(static_cast<size_t>(cfg->max_frame_points)));
+    A(c->h_stage.alloc(static_cast<size_t>(cfg->max_frame_points)));
     A(c->d_total.alloc(1));
     A(c->d_error.alloc(1));
     if (rc == SCAL_OK && acquire_stream(cfg->device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
@@ -205,18 +209,21 @@ static int merge_batch(scal_mapmerge* c, const float4* d_in, const int* offsets,
     if (nb > c->nb_cap) {
         SCAL_HIP(hipStreamSynchronize(s));
         SCAL_TRY(c->blocks.alloc(nb));
+        SCAL_TRY(c->h_blocks.alloc(nb));
         SCAL_TRY(c->blkcnt.alloc(static_cast<size_t>(nb) + 8192));  // k_mm_scan reads whole 16-byte groups per thread
         c->nb_cap = nb;
     }
     if (n_frames > c->pose_cap) {
         SCAL_HIP(hipStreamSynchronize(s));
         SCAL_TRY(c->poses.alloc(static_cast<size_t>(12) * n_frames));
+        SCAL_TRY(c->h_poses.alloc(static_cast<size_t>(12) * n_frames));
         c->pose_cap = n_frames;
     }
-    // pageable host sources: the calls return once the data is staged
-    SCAL_HIP(hipMemcpyAsync(c->blocks.p, hb.data(), sizeof(MMBlock) * nb, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->poses.p, poses12, sizeof(double) * 12 * n_frames, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipStreamSynchronize(s));  // hb goes out of scope
+    SCAL_HIP(hipStreamSynchronize(s));  // the pinned staging buffers may still feed the previous batch
+    std::memcpy(c->h_blocks.p, hb.data(), sizeof(MMBlock) * nb);
+    std::memcpy(c->h_poses.p, poses12, sizeof(double) * 12 * n_frames);
+    SCAL_HIP(hipMemcpyAsync(c->blocks.p, c->h_blocks.p, sizeof(MMBlock) * nb, hipMemcpyHostToDevice, s));
+    SCAL_HIP(hipMemcpyAsync(c->poses.p, c->h_poses.p, sizeof(double) * 12 * n_frames, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_mm_count, dim3(nb), dim3(256), 0, s, d_in, c->blocks.p, near_thres, c->blkcnt.p);
     long long base = 0;
     // the running total is read by the write pass as a kernel argument: fetch it (tiny, and add() is not the measured path)
@@ -240,7 +247,9 @@ extern "C" int scal_mapmerge_add(scal_mapmerge_t* c, const float* xyzi, int n, c
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     if (n == 0) return SCAL_OK;
-    SCAL_HIP(hipMemcpyAsync(c->stage.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    SCAL_HIP(hipStreamSynchronize(c->stream));  // the previous frame's write pass reads the staging buffers
+    std::memcpy(c->h_stage.p, xyzi, sizeof(float) * 4 * n);
+    SCAL_HIP(hipMemcpyAsync(c->stage.p, c->h_stage.p, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
     const int offsets[2] = {0, n};
     return merge_batch(c, c->stage.p, offsets, pose12, 1, near_thres);
 }
