@@ -295,3 +295,48 @@ def test_sharded_stage_d_flow_equals_single_context(S, hdl64_stream):
         hip.hipFree(p)
     for x in regs + [single, builder] + shards:
         x.close()
+
+
+def test_async_entry_points_reject_misuse(S, hdl64_stream):
+    """The split entry points keep one step in flight per context: collecting nothing, or queueing a second step before the first
+    has been collected, is an error (SCAL_E_STATE), and the context stays usable."""
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
+    od = S.LaserOdometry(max_points=200000)
+    mp = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=1000000)
+    sc = S.SCManager()
+    with pytest.raises(S.ScalError) as e:
+        od.collect()
+    assert e.value.code == S.E_STATE
+    with pytest.raises(S.ScalError) as e:
+        mp.collect()
+    assert e.value.code == S.E_STATE
+    with pytest.raises(S.ScalError) as e:
+        sc.detect_collect()
+    assert e.value.code == S.E_STATE
+    with pytest.raises(S.ScalError) as e:
+        sc.wait_descriptor()
+    assert e.value.code == S.E_STATE
+    reg.laserCloudHandler(hdl64_stream(0))
+    od.enqueue_features(reg)
+    with pytest.raises(S.ScalError) as e:
+        od.enqueue_features(reg)
+    assert e.value.code == S.E_STATE
+    qlc, tlc, qw, tw, st = od.collect()
+    mp.enqueue_features(reg, qw, tw)
+    with pytest.raises(S.ScalError) as e:
+        mp.enqueue_features(reg, qw, tw)
+    assert e.value.code == S.E_STATE
+    q, t, ms = mp.collect()
+    assert ms.insert_path == -1          # the insertion is still behind the pose
+    mp.finish()
+    assert mp.export(0).shape[0] > 0
+    # three prefetches without a step in between: the third is refused
+    mp.prefetch_features(reg)
+    mp.prefetch_features(reg)
+    with pytest.raises(S.ScalError) as e:
+        mp.prefetch_features(reg)
+    assert e.value.code == S.E_STATE
+    q2, t2, ms2 = mp.process_features(reg, qw, tw)   # consumes the oldest prefetch
+    assert ms2.insert_path in (0, 1)
+    for x in (reg, od, mp, sc):
+        x.close()
