@@ -61,6 +61,13 @@ def main():
     avg_s = ms / cnt * 1e-3
     alg = 16.0 * n_total + 16.0 * kept  # every record read once, every kept record written once
     ach = alg / avg_s / 1e9
+    traffic = None  # from the committed PMC passes (separate rocprofv3 runs of this tool), scaled to this run's point count
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mapmerge_v1.json")))
+        k = pmc["kernels"]["k_mm_write"]
+        traffic = (k["fetch_bytes_corrected"] + k["write_bytes"]) * (n_total / 47870650.0)
+    except (OSError, KeyError, ValueError):
+        pass
     import oracle_py as O
     nc = min(a.cpu_frames, a.frames)
     t1 = time.perf_counter()
@@ -84,7 +91,7 @@ def main():
         "metric": "points/sec merged (transform + near-range removal + concatenate), offline map merge", "value": n_total / dt, "unit": "points/s",
         "frames": a.frames, "points_in": n_total, "points_out": kept, "ms_per_merge": dt * 1e3, "dtype": "f32 points / f64 transform",
         "roofline": {"bound": "hbm", "kernel": "k_mm_write", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg, "traffic": None},
+                     "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg, "traffic": traffic},
         "cpu_baseline": {"value": int(offs[nc]) / cpu_dt, "unit": "points/s", "cores": 1, "kind": "port", "sample": f"first {nc} frames through the oracle"},
         "matches_oracle_on_sample": ok, "voxel_downsample": vox}))
 
