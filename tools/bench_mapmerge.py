@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Offline dense map merge (BASELINE.json config #5) on one MI355X: F synthetic HDL-64 keyframes resident in
-HBM -> global frame, near-range removal, concatenation (scal_mapmerge_add_batch_device).  Prints one JSON line with the HBM
-roofline of the write pass and the oracle's CPU rate.  Not the headline benchmark (that is bench.py, config #2)."""
+"""Offline dense map merge (BASELINE.json config #5): F synthetic HDL-64 keyframes resident in HBM -> global
+frame, near-range removal, concatenation (scal_mapmerge_add_batch_device).  Prints one JSON line with the HBM roofline of the
+write pass and the oracle's CPU rate.  Not the headline benchmark (that is bench.py, config #2).
+N > 1 (torch.distributed, one process per GPU): the keyframes partition over the ranks (rank r merges its own F frames into its
+own part of the map - no exchange on the data path), weak scaling, time = max over ranks behind a barrier."""
 import argparse
 import json
 import os
@@ -21,16 +23,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-frames", type=int, default=40)
     ap.add_argument("--voxel", type=float, default=0.0, help="also time the VoxelGrid downsample of the merged map at this leaf size")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl")
     a = ap.parse_args()
     import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
     import scaloam as S
     import scansynth
-    world = scansynth.World(scansynth.HDL64, 77)
-    base = [np.hstack([world.scan(k), np.full((world.scan(k).shape[0], 1), float(k), np.float32)]) for k in range(8)]
+    world_gen = scansynth.World(scansynth.HDL64, 77 + rank)
+    world_ = world_gen
+    base = [np.hstack([world_.scan(k), np.full((world_.scan(k).shape[0], 1), float(k), np.float32)]) for k in range(8)]
     frames = [base[f % 8] for f in range(a.frames)]
     poses = []
     for f in range(a.frames):
-        q, t = world.pose(f)
+        q, t = world_.pose(f)
         x, y, z, w = q
         R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
@@ -40,7 +54,7 @@ def main():
     offs = np.concatenate([[0], np.cumsum([f.shape[0] for f in frames])]).astype(np.int64)
     n_total = int(offs[-1])
     d_in = torch.from_numpy(np.ascontiguousarray(np.concatenate(frames), np.float32)).cuda()
-    mm = S.MapMerge(max_points=n_total + 1024, max_frame_points=400000)
+    mm = S.MapMerge(max_points=n_total + 1024, max_frame_points=400000, device=local)
     for _ in range(a.warmup):
         mm.reset()
         mm.add_batch_device(d_in.data_ptr(), offs, poses, 2.0)
@@ -48,6 +62,8 @@ def main():
     S.prof_reset()
     S.prof_enable(True)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         mm.reset()
@@ -55,6 +71,10 @@ def main():
     kept = mm.size()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     S.prof_enable(False)
     prof = S.prof_read_all()
     ms, cnt = prof["k_mm_write"]
@@ -87,8 +107,14 @@ def main():
             vdt = time.perf_counter() - t2
         vox = {"leaf": a.voxel, "points_in": kept, "points_out": int(m.value), "ms": vdt * 1e3, "points_per_s": kept / vdt,
                "note": "device time incl. the deinterleave, bounding box, radix sort (hierarchical histogram scan) and ordered centroids; no download"}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     print(json.dumps({
-        "metric": "points/sec merged (transform + near-range removal + concatenate), offline map merge", "value": n_total / dt, "unit": "points/s",
+        "metric": "points/sec merged (transform + near-range removal + concatenate), offline map merge", "value": world * n_total / dt, "unit": "points/s",
+        "n_gpus": world, "scaling": "weak",
         "frames": a.frames, "points_in": n_total, "points_out": kept, "ms_per_merge": dt * 1e3, "dtype": "f32 points / f64 transform",
         "roofline": {"bound": "hbm", "kernel": "k_mm_write", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                      "avg_launch_us": avg_s * 1e6, "algorithmic_bytes_per_launch": alg, "traffic": traffic},
