@@ -181,8 +181,8 @@ def test_sc_side_stream_overlap_is_ordered(O, S, hdl64_stream):
 
 def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
     """scal_set_stream_mode(1): every stage on its own stream, consecutive scans overlapping like the reference's four nodes
-    (A of scan k+1 while C of scan k still runs; map insertion behind the pose).  Software-pipelined exactly as bench.py does
-    it, with two features contexts used alternately.  Every pose and every loop-closure answer must equal the oracle chain."""
+    (A and B of scan k+1, and its stage-C prefetch, while C of scan k still runs; map insertion behind the pose).  Software-
+    pipelined exactly as bench.py does it, with a ring of features contexts and two prefetches in flight.  Every pose and every loop-closure answer must equal the oracle chain."""
     n = 8
     S.set_stream_mode(1)
     try:
@@ -197,20 +197,25 @@ def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
             sc.saveScancontextAndKeys(d)
             osc.saveScancontextAndKeys(d)
         poses, loops = [], []
-        pending = None
-        for k in range(n):
-            reg = regs[k % 2]
+        regs += [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(2)]  # ring of four, as bench.py uses
+
+        def front(k):  # everything of scan k that needs no pose: stage A, stage B, C's prefetch, stage D
+            reg = regs[k % 4]
             reg.laserCloudHandler(hdl64_stream(k))
             od.enqueue_features(reg)
             mp.prefetch_features(reg)
             sc.insert_features(reg)
             sc.detect_enqueue()
+
+        front(0)
+        for k in range(n):
             qlc, tlc, qw, tw, ost = od.collect()
-            if pending is not None:
-                poses.append(mp.collect()[:2])
-            mp.enqueue_features(reg, qw, tw)
-            pending = k
             loops.append(sc.detect_collect())
+            if k + 1 < n:
+                front(k + 1)                 # scan k+1's prefetch is queued while scan k's stage C has not even started
+            if k > 0:
+                poses.append(mp.collect()[:2])
+            mp.enqueue_features(regs[k % 4], qw, tw)
         poses.append(mp.collect()[:2])
         mp.finish()
         oo, om = O.Odometry(), O.Mapper(0.4, 0.8)
