@@ -3,10 +3,15 @@
 ScanContext loop search on KITTI-like HDL-64 scans (~120k points), one MI355X per process.
 
 A "step" is one scan through the whole hot path on one GPU, inputs already resident in HBM:
-  stage A  scal_features_run_device        (scanRegistration.cpp:134-421)
-  stage B  scal_odom_step_features         (laserOdometry.cpp:267-568)      - provides the prior for stage C
-  stage C  scal_map_step_features          (laserMapping.cpp:310-802,:845-849)   2 outer x <=4 LM iterations
-  stage D  scal_sc_insert_features + scal_sc_detect (Scancontext.cpp:151-260, :336-427) over a pre-filled keyframe DB
+  stage A  scal_features_run_device                      (scanRegistration.cpp:134-421)
+  stage B  scal_odom_enqueue_features / scal_odom_collect  (laserOdometry.cpp:267-568)   - provides the prior for stage C
+  stage C  scal_map_prefetch_features / _enqueue_features / _collect (laserMapping.cpp:310-802,:845-849)   2 outer x <=4 LM iterations
+  stage D  scal_sc_insert_features + scal_sc_detect_*    (Scancontext.cpp:151-260, :336-427) over a pre-filled keyframe DB
+Default schedule: stage-pipelined - every stage on its own stream and consecutive scans overlapping, the way the reference's four
+ROS nodes (scanRegistration, laserOdometry, laserMapping, laserPosegraphOptimization) process different scans at the same time;
+every scan still goes through A -> B -> C and A -> D with the reference's data dependencies (C(k) registers against the map that
+contains scan k-1), and the K timed steps end only when the last scan's map insertion is done.  --no-overlap runs one scan
+at a time on one stream; both schedules give bit-identical poses (tools/gpu_sched_check.sh).
 N > 1 (one process per GPU, torch.distributed/RCCL): stages A-C do not shard (pose k+1 depends on pose k and on the
 map), so every rank replays its own seeded sequence ("replicas only", weak scaling); the ScanContext keyframe database
 IS sharded (keyframe i on rank i % N) and every step exchanges descriptors and per-shard top-3 records with two RCCL
