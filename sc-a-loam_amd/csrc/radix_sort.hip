@@ -1,5 +1,5 @@
 // Stable LSD radix sort (9-bit digits) for gfx950.  Two kernels per pass:
-//   k_rs_hist     per-block digit histogram (LDS atomics) -> hist[digit][block]
+//   k_rs_hist     per-block digit histogram (LDS atomics) -> histogram matrix
 //   k_rs_scatter  every block first derives its own scatter bases from the histogram matrix (sum of the earlier blocks'
 //                 counts per digit + exclusive prefix of the digit totals, 512 x nb L2-resident words - cheaper than a
 //                 separate scan launch while nb is small), then scatters stably: per wave, items are ranked with
@@ -19,8 +19,11 @@ constexpr int RS_BINS = RadixSort::BINS;
 
 __device__ __forceinline__ bool pass_active(const int* d_used_bits, int shift) { return d_used_bits == nullptr || shift < *d_used_bits; }
 
+// Histogram matrix layout: [block][digit] for ordinary sorts (a wave of the scatter kernel then reads 64 consecutive digits of
+// one block = one or two cache lines per load), [digit][block] for sorts that go through the hierarchical scan (its flattened
+// order must be digit-major).
 __global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int shift,
-                                                 const int* __restrict__ d_used_bits, int* __restrict__ hist) {
+                                                 const int* __restrict__ d_used_bits, int* __restrict__ hist, int digit_major) {
     if (!pass_active(d_used_bits, shift)) return;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
@@ -35,7 +38,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __res
         if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RS_BINS; i += 256) hist[i * nb + blockIdx.x] = h[i];
+    for (int i = threadIdx.x; i < RS_BINS; i += 256) hist[digit_major ? i * nb + blockIdx.x : blockIdx.x * RS_BINS + i] = h[i];
 }
 
 __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int* __restrict__ d_n, int tile, int bins, int* __restrict__ d_total) {
@@ -74,18 +77,16 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
         sbase[2 * threadIdx.x + 1] = hist[(2 * threadIdx.x + 1) * nb + blockIdx.x];
     } else {
         int before[2] = {0, 0}, totals[2] = {0, 0};
-        // both rows are read in batches of 8 independent loads: one dependent load per block column would serialise
-        // ~2 x nb L2 round trips in front of the scatter
-        const int* row0 = hist + (2 * threadIdx.x) * nb;
-        const int* row1 = row0 + nb;
+        // [block][digit] layout: thread t owns digits t and t + 256, so a wave reads 64 consecutive words of one block's row;
+        // the columns are walked in batches of 8 independent loads
         const int me = static_cast<int>(blockIdx.x);
         for (int b0 = 0; b0 < nb; b0 += 8) {
             int v0[8], v1[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const bool in = b0 + q < nb;
-                v0[q] = in ? row0[b0 + q] : 0;
-                v1[q] = in ? row1[b0 + q] : 0;
+                v0[q] = in ? hist[(b0 + q) * RS_BINS + threadIdx.x] : 0;
+                v1[q] = in ? hist[(b0 + q) * RS_BINS + 256 + threadIdx.x] : 0;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -93,10 +94,13 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
                 if (b0 + q < me) before[0] += v0[q], before[1] += v1[q];
             }
         }
-        int dummy;
-        const int pre = block_exclusive_scan(totals[0] + totals[1], smem, &dummy);
-        sbase[2 * threadIdx.x] = pre + before[0];
-        sbase[2 * threadIdx.x + 1] = pre + totals[0] + before[1];
+        // exclusive prefix of the digit totals in digit order: digits 0..255 (one per thread), then 256..511
+        int sum_lo;
+        const int pre_lo = block_exclusive_scan(totals[0], smem, &sum_lo);
+        int sum_hi;
+        const int pre_hi = block_exclusive_scan(totals[1], smem, &sum_hi);
+        sbase[threadIdx.x] = pre_lo + before[0];
+        sbase[256 + threadIdx.x] = sum_lo + pre_hi + before[1];
     }
     for (int i = threadIdx.x; i < 4 * RS_BINS; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
@@ -216,7 +220,7 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     int pass = 0;
     for (int shift = 0; shift < max_bits; shift += DIGIT, ++pass) {
         const int in = pass & 1, o = in ^ 1;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p);
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p, big ? 1 : 0);
         if (big) {
             hipLaunchKernelGGL(k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, shift, d_used_bits, tile_sum.p);
             hipLaunchKernelGGL(k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, shift, d_used_bits);
