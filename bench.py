@@ -417,7 +417,7 @@ def roofline_of(prof, K, c, pipelined=True):
     # Dominant kernel = largest event-timed total among the kernels of the pose chains (streams A, B, C).  The kernels of the two
     # side streams (radix passes and the one-workgroup voxel filter of stage C's prefetch and of stage D) are left out of the
     # choice when the stages are pipelined: their queues are deep, and a dispatch's start..stop events then include its wait
-    # for the command processor, which rocprofv3's kernel durations do not (16.7 us vs ~35 us for k_rs_scatter in the same
+    # for the command processor, which rocprofv3's kernel durations do not (about 2x for k_rs_scatter in the same
     # traced run, profiles/README.md) - by rocprofv3's own totals k_lm_solve leads either way.
     side = {"k_rs_scatter", "k_vox_small"} if pipelined else set()
     cands = {k: v for k, v in prof.items() if k not in side and k in per_launch_bytes} or prof
