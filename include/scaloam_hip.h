@@ -174,9 +174,14 @@ int scal_sc_detect_enqueue(scal_sc_t* ctx);
 int scal_sc_detect_collect(scal_sc_t* ctx, scal_sc_result* res);
 /* distanceBtnScanContext for descriptor pairs already in the database */
 int scal_sc_distance_pairs(scal_sc_t* ctx, const int* idx_a, const int* idx_b, int n_pairs, double* dist, int* shift);
-/* dense mode: all 60 shifts for queries [q0,q1) x database [d0,d1): min over shifts; mode 0 = the
- * reference's 7-shift search around the sector-key alignment, 1 = exhaustive 60 shifts. */
+/* dense block of the pair grid (SURVEY.md 8d "D dense"; distDirectSC Scancontext.cpp:83-110 over every pair): queries [q0,q1) x
+ * database [d0,d1), row-major [q][d].  mode 0 = the reference's 7-shift search around the sector-key alignment
+ * (distanceBtnScanContext :113-148); 1 = exhaustive 60 shifts, column sums in the reference's order on the vector ALUs;
+ * 2 = exhaustive 60 shifts on the matrix cores (v_mfma_f64_16x16x4_f64 over unit columns: same minimum and shift, distances
+ * equal to mode 1 within a few ulp - the summation order differs).  Unsharded contexts only. */
 int scal_sc_distance_matrix(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift);
+/* the same with DEVICE outputs (nq*nd doubles / ints), enqueued on the context's stream: scal_sc_sync() before reading them */
+int scal_sc_distance_matrix_device(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift);
 /* sharded search pieces (one context per GPU): local top-3 for the newest GLOBAL key, then a merge of the
  * gathered per-shard records (the all-gather itself is the caller's: RCCL via torch.distributed). */
 typedef struct {

@@ -438,6 +438,138 @@ __global__ void __launch_bounds__(256) k_sc_matrix(SCDb db, int q0, int nq, int 
     if (lane == 0) dist[p] = bd, shift[p] = bs;
 }
 
+
+// ---- dense matrix on the matrix cores (mode 2) --------------------------------------------------------------------------------
+// distDirectSC (Scancontext.cpp:83-110) summed over a column shift s is  sum_col <A[:,col], B[:,col-s]> / (|A col| |B col-s|):
+// with unit columns Ahat, Bhat this is a product  C[q][s] = sum_k Ahat_q[k] * X_b[k][s],  k = (ring, col), K = 1200, where
+// X_b[(r,col)][s] = Bhat_b[r][(col - s) mod 60] is the circulant expansion of one database descriptor.  16 queries x 64 shifts
+// (60 used) x K = 1200 per database entry is 300 k-steps of v_mfma_f64_16x16x4_f64 per 16-shift tile; the expansion is never
+// materialised - each lane reads its B operand from an LDS copy of Bhat_b whose rows are extended to 124 entries so that
+// (col - s) needs no modulo.  The effective-column count of the reference (columns where either norm is zero are skipped and
+// not counted) is popcount(maskA & rotl60(maskB, s)).
+constexpr int GQ = 64;      // queries per workgroup, 16 per wave
+constexpr int GE = 4;       // database entries per workgroup, shared by its 4 waves
+constexpr int GROW = 124;   // extended row: x = c + 64 for c in [-64, 59]
+constexpr int GKS = DESC / 4;
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// operand A in fragment order: frag[tile][ks][lane] = Ahat_q[r][col], q = 16 tile + (lane & 15), k = 4 ks + (lane >> 4) = 60 r + col
+__global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, double* __restrict__ frag,
+                                                      unsigned long long* __restrict__ qmask) {
+    const int tile = blockIdx.x;
+    double* out = frag + static_cast<size_t>(tile) * GKS * 64;
+    for (int i = threadIdx.x; i < GKS * 64; i += blockDim.x) {
+        const int ks = i >> 6, lane = i & 63;
+        const int q = tile * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
+        const int r = k / NS, col = k - r * NS;
+        double v = 0;
+        if (q < nq) {
+            const double n = db.cnorm[static_cast<size_t>(q0 + q) * NS + col];
+            if (n != 0) v = db.desc[static_cast<size_t>(q0 + q) * DESC + col * NR + r] / n;
+        }
+        out[i] = v;
+    }
+    // column masks of this tile's 16 queries: wave w takes queries w, w+4, ...
+    for (int j = wave_id(); j < 16; j += 4) {
+        const int q = tile * 16 + j;
+        const int lane = lane_id();
+        const bool nz = q < nq && lane < NS && db.cnorm[static_cast<size_t>(q0 + q) * NS + lane] != 0;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) qmask[q] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_sc_gram(SCDb db, const double* __restrict__ frag, const unsigned long long* __restrict__ qmask,
+                                                    int nq, int d0, int nd, double* __restrict__ dist, int* __restrict__ shift) {
+    extern __shared__ double ext[];  // [GE][NR][GROW]
+    __shared__ unsigned long long bmask[GE];
+    const int chunk = blockIdx.x, lane = lane_id(), w = wave_id();
+    for (int i = threadIdx.x; i < GE * NR * GROW; i += blockDim.x) {
+        const int e = i / (NR * GROW), rem = i - e * (NR * GROW);
+        const int x = rem / NR, r = rem - x * NR;
+        const int b = chunk * GE + e;
+        const int c = (x + 56) % NS;  // (x - 64) mod 60
+        double v = 0;
+        if (b < nd) {
+            const double n = db.cnorm[static_cast<size_t>(d0 + b) * NS + c];
+            if (n != 0) v = db.desc[static_cast<size_t>(d0 + b) * DESC + c * NR + r] / n;
+        }
+        ext[e * (NR * GROW) + r * GROW + x] = v;
+    }
+    {
+        const int b = chunk * GE + w;
+        const bool nz = b < nd && lane < NS && db.cnorm[static_cast<size_t>(d0 + b) * NS + lane] != 0;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) bmask[w] = m;
+    }
+    __syncthreads();
+    const int tile = blockIdx.y * 4 + w;
+    const double* fa = frag + static_cast<size_t>(tile) * GKS * 64 + lane;
+    const double* bp = ext + ((lane >> 4) - (lane & 15) + 16);
+    d4_t acc[GE][4];
+#pragma unroll
+    for (int e = 0; e < GE; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[e][t] = d4_t{0, 0, 0, 0};
+    // one ring (15 k-steps) of the query operand lives in registers; each value is reloaded for the next ring right after its
+    // 16 MFMAs have been issued, so the load has the other 14 k-steps (about 14 x 16 x 64 cycles) to land
+    double a[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) a[j] = fa[j * 64];
+    for (int r = 0; r < NR; ++r) {
+        const double* br = bp + r * GROW;
+        const double* fn = fa + (r + 1 < NR ? r + 1 : r) * 15 * 64;
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+#pragma unroll
+            for (int e = 0; e < GE; ++e) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double bv = br[e * (NR * GROW) + 4 * j + 16 * (3 - t)];
+                    acc[e][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bv, acc[e][t], 0, 0, 0);
+                }
+            }
+            a[j] = fn[j * 64];
+        }
+    }
+    // acc[e][t][reg]: query = 16 tile + (lane >> 4) + 4 reg, shift = 16 t + (lane & 15)
+    const unsigned long long m60 = (1ull << NS) - 1;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int q = tile * 16 + (lane >> 4) + 4 * reg;
+        const unsigned long long ma = qmask[q];
+#pragma unroll
+        for (int e = 0; e < GE; ++e) {
+            const unsigned long long mb = bmask[e];
+            double bd = 1e300;
+            int bs = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int s = 16 * t + (lane & 15);
+                if (s < NS) {
+                    const unsigned long long rot = ((mb << s) | (mb >> (NS - s))) & m60;
+                    const int eff = __popcll(ma & rot);
+                    double dd = 1.0 - acc[e][t][reg] / eff;
+                    if (eff == 0 || !(dd == dd)) dd = 1e300;
+                    if (dd < bd) bd = dd, bs = s;
+                }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(bd, o, 64);
+                const int os = __shfl_xor(bs, o, 64);
+                if (ob < bd || (ob == bd && os < bs)) bd = ob, bs = os;
+            }
+            if (!(bd < 10000000)) bd = 10000000, bs = 0;
+            const int b = chunk * GE + e;
+            if ((lane & 15) == 0 && q < nq && b < nd) {
+                dist[static_cast<size_t>(q) * nd + b] = bd;
+                shift[static_cast<size_t>(q) * nd + b] = bs;
+            }
+        }
+    }
+}
+
 }  // namespace scal
 
 using namespace scal;
@@ -465,6 +597,8 @@ struct scal_sc {
     DevBuf<int> d_pairs;
     DevBuf<double> d_dist;
     DevBuf<int> d_shift;
+    DevBuf<double> g_frag;  // dense matrix, mode 2: query operand in MFMA fragment order
+    DevBuf<unsigned long long> g_qmask;
     size_t pair_cap = 0;
     // keyframe downsampling for scal_sc_insert_features (lazy)
     VoxelFilter vf;
@@ -1030,11 +1164,43 @@ extern "C" int scal_sc_distance_pairs(scal_sc_t* c, const int* idx_a, const int*
     return SCAL_OK;
 }
 
-extern "C" int scal_sc_distance_matrix(scal_sc_t* c, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift) {
-    if (!c || !dist || !shift || q0 < 0 || d0 < 0 || q1 < q0 || d1 < d0 || (mode != 0 && mode != 1)) {
+// mode 0 / 1: one wave per pair on the vector ALUs (summation order of the reference); mode 2: matrix cores (k_sc_gram)
+static int enqueue_matrix(scal_sc* c, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift, hipStream_t s) {
+    const int nq = q1 - q0, nd = d1 - d0;
+    const size_t np = static_cast<size_t>(nq) * nd;
+    if (mode != 2) {
+        SCAL_LAUNCH_PROF("k_sc_matrix", k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, nq, d0, nd, mode,
+                         d_dist, d_shift);
+        SCAL_HIP(hipGetLastError());
+        return SCAL_OK;
+    }
+    const int qblocks = div_up(nq, GQ), n_tiles = qblocks * 4, chunks = div_up(nd, GE);
+    if (qblocks > 65535) {
+        set_error("scal_sc_distance_matrix: more than 65535 x 64 queries in one call");
+        return SCAL_E_ARG;
+    }
+    const size_t frag_n = static_cast<size_t>(n_tiles) * GKS * 64;
+    if (c->g_frag.n < frag_n) SCAL_TRY(c->g_frag.alloc(frag_n));
+    if (c->g_qmask.n < static_cast<size_t>(n_tiles) * 16) SCAL_TRY(c->g_qmask.alloc(static_cast<size_t>(n_tiles) * 16));
+    const size_t lds = sizeof(double) * GE * NR * GROW;  // 79,360 B: above the 64 KiB default, two workgroups per CU
+    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_gram), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    SCAL_LAUNCH_PROF("k_sc_gram_prep", k_sc_gram_prep, dim3(n_tiles), dim3(256), 0, s, c->db(), q0, nq, c->g_frag.p, c->g_qmask.p);
+    SCAL_LAUNCH_PROF("k_sc_gram", k_sc_gram, dim3(chunks, qblocks), dim3(256), lds, s, c->db(), c->g_frag.p, c->g_qmask.p, nq, d0, nd, d_dist,
+                     d_shift);
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
+static int check_matrix_args(scal_sc* c, const void* dist, const void* shift, int q0, int q1, int d0, int d1, int mode) {
+    if (!c || !dist || !shift || q0 < 0 || d0 < 0 || q1 < q0 || d1 < d0 || mode < 0 || mode > 2) {
         set_error("scal_sc_distance_matrix: bad argument");
         return SCAL_E_ARG;
     }
+    return SCAL_OK;
+}
+
+extern "C" int scal_sc_distance_matrix(scal_sc_t* c, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift) {
+    SCAL_TRY(check_matrix_args(c, dist, shift, q0, q1, d0, d1, mode));
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->cfg.n_shards > 1 || q1 > c->n_global || d1 > c->n_global) {
         set_error("scal_sc_distance_matrix: range outside the database (or sharded context)");
@@ -1045,11 +1211,21 @@ extern "C" int scal_sc_distance_matrix(scal_sc_t* c, int q0, int q1, int d0, int
     SCAL_HIP(hipSetDevice(c->cfg.device));
     SCAL_TRY(ensure_pairs(c, np));
     hipStream_t s = c->stream;
-    hipLaunchKernelGGL(k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, q1 - q0, d0, d1 - d0, mode, c->d_dist.p,
-                       c->d_shift.p);
-    SCAL_HIP(hipGetLastError());
+    SCAL_TRY(enqueue_matrix(c, q0, q1, d0, d1, mode, c->d_dist.p, c->d_shift.p, s));
     SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * np, hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipMemcpyAsync(shift, c->d_shift.p, sizeof(int) * np, hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
+}
+
+extern "C" int scal_sc_distance_matrix_device(scal_sc_t* c, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift) {
+    SCAL_TRY(check_matrix_args(c, d_dist, d_shift, q0, q1, d0, d1, mode));
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->cfg.n_shards > 1 || q1 > c->n_global || d1 > c->n_global) {
+        set_error("scal_sc_distance_matrix_device: range outside the database (or sharded context)");
+        return SCAL_E_ARG;
+    }
+    if (q1 == q0 || d1 == d0) return SCAL_OK;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    return enqueue_matrix(c, q0, q1, d0, d1, mode, d_dist, d_shift, c->stream);
 }

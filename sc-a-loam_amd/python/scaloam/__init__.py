@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
-    "scal_sc_distance_matrix", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
+    "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
@@ -143,6 +143,7 @@ def lib():
     L.scal_sc_detect_collect.argtypes = [vp, C.POINTER(SCResult)]
     L.scal_sc_distance_pairs.argtypes = [vp, _i32p, _i32p, C.c_int, _f64p, _i32p]
     L.scal_sc_distance_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _i32p]
+    L.scal_sc_distance_matrix_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     L.scal_sc_shard_query.argtypes = [vp, _f64p, C.c_int, C.POINTER(SCCand)]
     L.scal_sc_merge_candidates.argtypes = [C.POINTER(SCCand), C.c_int, C.c_double, C.POINTER(SCResult)]
     L.scal_sc_insert_features.argtypes = [vp, vp]
@@ -430,6 +431,10 @@ class SCManager:
         s = np.zeros((q1 - q0, d1 - d0), np.int32)
         _check(lib().scal_sc_distance_matrix(self.h, q0, q1, d0, d1, mode, _p(d, _f64p), _p(s, _i32p)))
         return d, s
+
+    def distance_matrix_device(self, q0, q1, d0, d1, mode, d_dist_ptr, d_shift_ptr):
+        """Device outputs ((q1-q0)*(d1-d0) doubles / int32), enqueued on the context's stream; sync() before reading."""
+        _check(lib().scal_sc_distance_matrix_device(self.h, q0, q1, d0, d1, mode, d_dist_ptr, d_shift_ptr))
 
     def shard_query(self, query_desc_ring_sector, global_size_at_rebuild):
         d = _f64(np.asarray(query_desc_ring_sector).T.reshape(-1))
