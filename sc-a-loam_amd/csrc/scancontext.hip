@@ -479,28 +479,42 @@ __global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, d
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_sc_gram(SCDb db, const double* __restrict__ frag, const unsigned long long* __restrict__ qmask,
-                                                    int nq, int d0, int nd, double* __restrict__ dist, int* __restrict__ shift) {
-    extern __shared__ double ext[];  // [GE][NR][GROW]
+// database operand: unit columns, ring-major (bhat[b][60 r + c]), and the 60-bit column masks; k_sc_gram's workgroups then fill
+// their LDS rows with plain 16-byte copies instead of each re-deriving the quotients
+__global__ void __launch_bounds__(256) k_sc_gram_prep_db(SCDb db, int d0, int nd, double* __restrict__ bhat, unsigned long long* __restrict__ dmask) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
+        const int c = i / NR, r = i - c * NR;
+        const double n = db.cnorm[static_cast<size_t>(d0 + b) * NS + c];
+        bhat[static_cast<size_t>(b) * DESC + r * NS + c] = n != 0 ? db.desc[static_cast<size_t>(d0 + b) * DESC + i] / n : 0.0;
+    }
+    if (wave_id() == 0) {
+        const int lane = lane_id();
+        const bool nz = lane < NS && db.cnorm[static_cast<size_t>(d0 + b) * NS + lane] != 0;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) dmask[b] = m;
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ bhat, const unsigned long long* __restrict__ dmask,
+                                                    const double* __restrict__ frag, const unsigned long long* __restrict__ qmask, int nq, int nd,
+                                                    double* __restrict__ dist, int* __restrict__ shift) {
+    extern __shared__ __attribute__((aligned(16))) double ext[];  // [GE][NR][GROW]
     __shared__ unsigned long long bmask[GE];
     const int chunk = blockIdx.x, lane = lane_id(), w = wave_id();
-    for (int i = threadIdx.x; i < GE * NR * GROW; i += blockDim.x) {
-        const int e = i / (NR * GROW), rem = i - e * (NR * GROW);
-        const int x = rem / NR, r = rem - x * NR;
+    // extended rows, two values per copy: x even -> c = (x - 64) mod 60 is even, so a pair never straddles the wrap
+    for (int i = threadIdx.x; i < GE * NR * GROW / 2; i += blockDim.x) {
+        const int e = i / (NR * GROW / 2), rem = i - e * (NR * GROW / 2);
+        const int r = rem / (GROW / 2), x = 2 * (rem - r * (GROW / 2));
         const int b = chunk * GE + e;
-        const int c = (x + 56) % NS;  // (x - 64) mod 60
-        double v = 0;
-        if (b < nd) {
-            const double n = db.cnorm[static_cast<size_t>(d0 + b) * NS + c];
-            if (n != 0) v = db.desc[static_cast<size_t>(d0 + b) * DESC + c * NR + r] / n;
-        }
-        ext[e * (NR * GROW) + r * GROW + x] = v;
+        const int c = (x + 56) % NS;
+        double2 v = make_double2(0.0, 0.0);
+        if (b < nd) v = *reinterpret_cast<const double2*>(bhat + static_cast<size_t>(b) * DESC + r * NS + c);
+        *reinterpret_cast<double2*>(ext + e * (NR * GROW) + r * GROW + x) = v;
     }
-    {
-        const int b = chunk * GE + w;
-        const bool nz = b < nd && lane < NS && db.cnorm[static_cast<size_t>(d0 + b) * NS + lane] != 0;
-        const unsigned long long m = __ballot(nz);
-        if (lane == 0) bmask[w] = m;
+    if (threadIdx.x < GE) {
+        const int b = chunk * GE + threadIdx.x;
+        bmask[threadIdx.x] = b < nd ? dmask[b] : 0ull;
     }
     __syncthreads();
     const int tile = blockIdx.y * 4 + w;
@@ -516,20 +530,36 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(SCDb db, const double* __res
     double a[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) a[j] = fa[j * 64];
+    // the 16 circulant operands of a k-step are read from LDS one k-step ahead (bn) and the issue order is pinned to one
+    // ds_read per MFMA, so no MFMA waits on the read issued just in front of it
+    double bc[GE * 4], bn[GE * 4];
+#pragma unroll
+    for (int e = 0; e < GE; ++e)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bc[e * 4 + t] = bp[e * (NR * GROW) + 16 * (3 - t)];
     for (int r = 0; r < NR; ++r) {
         const double* br = bp + r * GROW;
         const double* fn = fa + (r + 1 < NR ? r + 1 : r) * 15 * 64;
 #pragma unroll
         for (int j = 0; j < 15; ++j) {
+            // next k-step: j + 1 of this ring, or the first of the next ring (the last ring re-reads its own: unused)
+            const double* bx = j + 1 < 15 ? br + 4 * (j + 1) : (r + 1 < NR ? br + GROW : br);
 #pragma unroll
-            for (int e = 0; e < GE; ++e) {
+            for (int e = 0; e < GE; ++e)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double bv = br[e * (NR * GROW) + 4 * j + 16 * (3 - t)];
-                    acc[e][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bv, acc[e][t], 0, 0, 0);
-                }
-            }
+                for (int t = 0; t < 4; ++t) bn[e * 4 + t] = bx[e * (NR * GROW) + 16 * (3 - t)];
+#pragma unroll
+            for (int e = 0; e < GE; ++e)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[e][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bc[e * 4 + t], acc[e][t], 0, 0, 0);
             a[j] = fn[j * 64];
+#pragma unroll
+            for (int i = 0; i < GE * 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
+            }
+#pragma unroll
+            for (int i = 0; i < GE * 4; ++i) bc[i] = bn[i];
         }
     }
     // acc[e][t][reg]: query = 16 tile + (lane >> 4) + 4 reg, shift = 16 t + (lane & 15)
@@ -599,6 +629,8 @@ struct scal_sc {
     DevBuf<int> d_shift;
     DevBuf<double> g_frag;  // dense matrix, mode 2: query operand in MFMA fragment order
     DevBuf<unsigned long long> g_qmask;
+    DevBuf<double> g_bhat;  // database operand: unit columns, ring-major
+    DevBuf<unsigned long long> g_dmask;
     size_t pair_cap = 0;
     // keyframe downsampling for scal_sc_insert_features (lazy)
     VoxelFilter vf;
@@ -1184,9 +1216,12 @@ static int enqueue_matrix(scal_sc* c, int q0, int q1, int d0, int d1, int mode, 
     if (c->g_qmask.n < static_cast<size_t>(n_tiles) * 16) SCAL_TRY(c->g_qmask.alloc(static_cast<size_t>(n_tiles) * 16));
     const size_t lds = sizeof(double) * GE * NR * GROW;  // 79,360 B: above the 64 KiB default, two workgroups per CU
     SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_gram), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    if (c->g_bhat.n < static_cast<size_t>(nd) * DESC) SCAL_TRY(c->g_bhat.alloc(static_cast<size_t>(nd) * DESC));
+    if (c->g_dmask.n < static_cast<size_t>(nd)) SCAL_TRY(c->g_dmask.alloc(nd));
     SCAL_LAUNCH_PROF("k_sc_gram_prep", k_sc_gram_prep, dim3(n_tiles), dim3(256), 0, s, c->db(), q0, nq, c->g_frag.p, c->g_qmask.p);
-    SCAL_LAUNCH_PROF("k_sc_gram", k_sc_gram, dim3(chunks, qblocks), dim3(256), lds, s, c->db(), c->g_frag.p, c->g_qmask.p, nq, d0, nd, d_dist,
-                     d_shift);
+    SCAL_LAUNCH_PROF("k_sc_gram_prep_db", k_sc_gram_prep_db, dim3(nd), dim3(256), 0, s, c->db(), d0, nd, c->g_bhat.p, c->g_dmask.p);
+    SCAL_LAUNCH_PROF("k_sc_gram", k_sc_gram, dim3(chunks, qblocks), dim3(256), lds, s, c->g_bhat.p, c->g_dmask.p, c->g_frag.p, c->g_qmask.p, nq, nd,
+                     d_dist, d_shift);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

@@ -9,9 +9,11 @@ __global__ void __launch_bounds__(256) k_probe(double* out, int iters, double a0
     d4_t acc[NACC];
     for (int i = 0; i < NACC; ++i) acc[i] = d4_t{0, 0, 0, 0};
     double a = a0 + threadIdx.x, b = b0 + blockIdx.x;
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; it += 16) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
     }
     double s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -22,7 +24,7 @@ template <int NACC>
 static double run(double* d, int blocks, int iters) {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL(k_probe<NACC>, dim3(blocks), dim3(256), 0, 0, d, 100, 1e-3, 1e-3);
+    hipLaunchKernelGGL(k_probe<NACC>, dim3(blocks), dim3(256), 0, 0, d, 160, 1e-3, 1e-3);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_probe<NACC>, dim3(blocks), dim3(256), 0, 0, d, iters, 1e-3, 1e-3);
