@@ -178,7 +178,9 @@ int scal_sc_distance_pairs(scal_sc_t* ctx, const int* idx_a, const int* idx_b, i
  * database [d0,d1), row-major [q][d].  mode 0 = the reference's 7-shift search around the sector-key alignment
  * (distanceBtnScanContext :113-148); 1 = exhaustive 60 shifts, column sums in the reference's order on the vector ALUs;
  * 2 = exhaustive 60 shifts on the matrix cores (v_mfma_f64_16x16x4_f64 over unit columns: same minimum and shift, distances
- * equal to mode 1 within a few ulp - the summation order differs).  Unsharded contexts only. */
+ * equal to mode 1 within a few ulp - the summation order differs); 3 = the same product on v_mfma_f32_16x16x4_f32 with the
+ * unit columns rounded to f32 (twice the rate; distances within 2e-6 of mode 2 - inside the 1e-5 the path is held to - and the
+ * shift can differ where two shifts are closer than that).  Unsharded contexts only. */
 int scal_sc_distance_matrix(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift);
 /* the same with DEVICE outputs (nq*nd doubles / ints), enqueued on the context's stream: scal_sc_sync() before reading them */
 int scal_sc_distance_matrix_device(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift);

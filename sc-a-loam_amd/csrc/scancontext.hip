@@ -448,16 +448,38 @@ __global__ void __launch_bounds__(256) k_sc_matrix(SCDb db, int q0, int nq, int 
 // (col - s) needs no modulo.  The effective-column count of the reference (columns where either norm is zero are skipped and
 // not counted) is popcount(maskA & rotl60(maskB, s)).
 constexpr int GQ = 64;      // queries per workgroup, 16 per wave
-constexpr int GE = 4;       // database entries per workgroup, shared by its 4 waves
 constexpr int GROW = 124;   // extended row: x = c + 64 for c in [-64, 59]
 constexpr int GKS = DESC / 4;
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+// f64: v_mfma_f64_16x16x4_f64, 64 cycles, C row = (lane >> 4) + 4 reg; 4 database entries per workgroup.
+// f32 (mode 3): v_mfma_f32_16x16x4_f32, 32 cycles, C row = 4 (lane >> 4) + reg; 8 entries per workgroup (same LDS bytes,
+// same 128 accumulator registers, twice the pairs per query-operand load).
+template <typename T>
+struct GramT;
+template <>
+struct GramT<double> {
+    typedef d4_t acc_t;
+    typedef double2 vec_t;
+    static constexpr int GE = 4, VEC = 2;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <>
+struct GramT<float> {
+    typedef f4_t acc_t;
+    typedef float4 vec_t;
+    static constexpr int GE = 8, VEC = 4;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
 
 // operand A in fragment order: frag[tile][ks][lane] = Ahat_q[r][col], q = 16 tile + (lane & 15), k = 4 ks + (lane >> 4) = 60 r + col
-__global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, double* __restrict__ frag,
-                                                      unsigned long long* __restrict__ qmask) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, T* __restrict__ frag, unsigned long long* __restrict__ qmask) {
     const int tile = blockIdx.x;
-    double* out = frag + static_cast<size_t>(tile) * GKS * 64;
+    T* out = frag + static_cast<size_t>(tile) * GKS * 64;
     for (int i = threadIdx.x; i < GKS * 64; i += blockDim.x) {
         const int ks = i >> 6, lane = i & 63;
         const int q = tile * 16 + (lane & 15), k = 4 * ks + (lane >> 4);
@@ -467,7 +489,7 @@ __global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, d
             const double n = db.cnorm[static_cast<size_t>(q0 + q) * NS + col];
             if (n != 0) v = db.desc[static_cast<size_t>(q0 + q) * DESC + col * NR + r] / n;
         }
-        out[i] = v;
+        out[i] = static_cast<T>(v);
     }
     // column masks of this tile's 16 queries: wave w takes queries w, w+4, ...
     for (int j = wave_id(); j < 16; j += 4) {
@@ -481,12 +503,13 @@ __global__ void __launch_bounds__(256) k_sc_gram_prep(SCDb db, int q0, int nq, d
 
 // database operand: unit columns, ring-major (bhat[b][60 r + c]), and the 60-bit column masks; k_sc_gram's workgroups then fill
 // their LDS rows with plain 16-byte copies instead of each re-deriving the quotients
-__global__ void __launch_bounds__(256) k_sc_gram_prep_db(SCDb db, int d0, int nd, double* __restrict__ bhat, unsigned long long* __restrict__ dmask) {
+template <typename T>
+__global__ void __launch_bounds__(256) k_sc_gram_prep_db(SCDb db, int d0, int nd, T* __restrict__ bhat, unsigned long long* __restrict__ dmask) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
         const int c = i / NR, r = i - c * NR;
         const double n = db.cnorm[static_cast<size_t>(d0 + b) * NS + c];
-        bhat[static_cast<size_t>(b) * DESC + r * NS + c] = n != 0 ? db.desc[static_cast<size_t>(d0 + b) * DESC + i] / n : 0.0;
+        bhat[static_cast<size_t>(b) * DESC + r * NS + c] = static_cast<T>(n != 0 ? db.desc[static_cast<size_t>(d0 + b) * DESC + i] / n : 0.0);
     }
     if (wave_id() == 0) {
         const int lane = lane_id();
@@ -496,21 +519,27 @@ __global__ void __launch_bounds__(256) k_sc_gram_prep_db(SCDb db, int d0, int nd
     }
 }
 
-__global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ bhat, const unsigned long long* __restrict__ dmask,
-                                                    const double* __restrict__ frag, const unsigned long long* __restrict__ qmask, int nq, int nd,
+template <typename T>
+__global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, const unsigned long long* __restrict__ dmask,
+                                                    const T* __restrict__ frag, const unsigned long long* __restrict__ qmask, int nq, int nd,
                                                     double* __restrict__ dist, int* __restrict__ shift) {
-    extern __shared__ __attribute__((aligned(16))) double ext[];  // [GE][NR][GROW]
+    typedef GramT<T> G;
+    typedef typename G::acc_t acc_t;
+    typedef typename G::vec_t vec_t;
+    constexpr int GE = G::GE, VEC = G::VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ext_raw[];
+    T* ext = reinterpret_cast<T*>(ext_raw);  // [GE][NR][GROW]
     __shared__ unsigned long long bmask[GE];
     const int chunk = blockIdx.x, lane = lane_id(), w = wave_id();
-    // extended rows, two values per copy: x even -> c = (x - 64) mod 60 is even, so a pair never straddles the wrap
-    for (int i = threadIdx.x; i < GE * NR * GROW / 2; i += blockDim.x) {
-        const int e = i / (NR * GROW / 2), rem = i - e * (NR * GROW / 2);
-        const int r = rem / (GROW / 2), x = 2 * (rem - r * (GROW / 2));
+    // extended rows, 16 bytes per copy: x a multiple of VEC -> c = (x - 64) mod 60 is one too, so a copy never straddles the wrap
+    for (int i = threadIdx.x; i < GE * NR * GROW / VEC; i += blockDim.x) {
+        const int e = i / (NR * GROW / VEC), rem = i - e * (NR * GROW / VEC);
+        const int r = rem / (GROW / VEC), x = VEC * (rem - r * (GROW / VEC));
         const int b = chunk * GE + e;
         const int c = (x + 56) % NS;
-        double2 v = make_double2(0.0, 0.0);
-        if (b < nd) v = *reinterpret_cast<const double2*>(bhat + static_cast<size_t>(b) * DESC + r * NS + c);
-        *reinterpret_cast<double2*>(ext + e * (NR * GROW) + r * GROW + x) = v;
+        vec_t v = {};
+        if (b < nd) v = *reinterpret_cast<const vec_t*>(bhat + static_cast<size_t>(b) * DESC + r * NS + c);
+        *reinterpret_cast<vec_t*>(ext + e * (NR * GROW) + r * GROW + x) = v;
     }
     if (threadIdx.x < GE) {
         const int b = chunk * GE + threadIdx.x;
@@ -518,32 +547,32 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ b
     }
     __syncthreads();
     const int tile = blockIdx.y * 4 + w;
-    const double* fa = frag + static_cast<size_t>(tile) * GKS * 64 + lane;
-    const double* bp = ext + ((lane >> 4) - (lane & 15) + 16);
-    d4_t acc[GE][4];
+    const T* fa = frag + static_cast<size_t>(tile) * GKS * 64 + lane;
+    const T* bp = ext + ((lane >> 4) - (lane & 15) + 16);
+    acc_t acc[GE][4];
 #pragma unroll
     for (int e = 0; e < GE; ++e)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[e][t] = d4_t{0, 0, 0, 0};
+        for (int t = 0; t < 4; ++t) acc[e][t] = acc_t{0, 0, 0, 0};
     // one ring (15 k-steps) of the query operand lives in registers; each value is reloaded for the next ring right after its
-    // 16 MFMAs have been issued, so the load has the other 14 k-steps (about 14 x 16 x 64 cycles) to land
-    double a[15];
+    // MFMAs have been issued, so the load has the other 14 k-steps to land
+    T a[15];
 #pragma unroll
     for (int j = 0; j < 15; ++j) a[j] = fa[j * 64];
-    // the 16 circulant operands of a k-step are read from LDS one k-step ahead (bn) and the issue order is pinned to one
+    // the circulant operands of a k-step are read from LDS one k-step ahead (bn) and the issue order is pinned to one
     // ds_read per MFMA, so no MFMA waits on the read issued just in front of it
-    double bc[GE * 4], bn[GE * 4];
+    T bc[GE * 4], bn[GE * 4];
 #pragma unroll
     for (int e = 0; e < GE; ++e)
 #pragma unroll
         for (int t = 0; t < 4; ++t) bc[e * 4 + t] = bp[e * (NR * GROW) + 16 * (3 - t)];
     for (int r = 0; r < NR; ++r) {
-        const double* br = bp + r * GROW;
-        const double* fn = fa + (r + 1 < NR ? r + 1 : r) * 15 * 64;
+        const T* br = bp + r * GROW;
+        const T* fn = fa + (r + 1 < NR ? r + 1 : r) * 15 * 64;
 #pragma unroll
         for (int j = 0; j < 15; ++j) {
             // next k-step: j + 1 of this ring, or the first of the next ring (the last ring re-reads its own: unused)
-            const double* bx = j + 1 < 15 ? br + 4 * (j + 1) : (r + 1 < NR ? br + GROW : br);
+            const T* bx = j + 1 < 15 ? br + 4 * (j + 1) : (r + 1 < NR ? br + GROW : br);
 #pragma unroll
             for (int e = 0; e < GE; ++e)
 #pragma unroll
@@ -551,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ b
 #pragma unroll
             for (int e = 0; e < GE; ++e)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[e][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], bc[e * 4 + t], acc[e][t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[e][t] = G::mma(a[j], bc[e * 4 + t], acc[e][t]);
             a[j] = fn[j * 64];
 #pragma unroll
             for (int i = 0; i < GE * 4; ++i) {
@@ -562,11 +591,11 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ b
             for (int i = 0; i < GE * 4; ++i) bc[i] = bn[i];
         }
     }
-    // acc[e][t][reg]: query = 16 tile + (lane >> 4) + 4 reg, shift = 16 t + (lane & 15)
+    // acc[e][t][reg]: query = 16 tile + row(lane, reg), shift = 16 t + (lane & 15)
     const unsigned long long m60 = (1ull << NS) - 1;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-        const int q = tile * 16 + (lane >> 4) + 4 * reg;
+        const int q = tile * 16 + G::row(lane, reg);
         const unsigned long long ma = qmask[q];
 #pragma unroll
         for (int e = 0; e < GE; ++e) {
@@ -579,7 +608,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const double* __restrict__ b
                 if (s < NS) {
                     const unsigned long long rot = ((mb << s) | (mb >> (NS - s))) & m60;
                     const int eff = __popcll(ma & rot);
-                    double dd = 1.0 - acc[e][t][reg] / eff;
+                    double dd = 1.0 - static_cast<double>(acc[e][t][reg]) / eff;
                     if (eff == 0 || !(dd == dd)) dd = 1e300;
                     if (dd < bd) bd = dd, bs = s;
                 }
@@ -630,6 +659,7 @@ struct scal_sc {
     DevBuf<double> g_frag;  // dense matrix, mode 2: query operand in MFMA fragment order
     DevBuf<unsigned long long> g_qmask;
     DevBuf<double> g_bhat;  // database operand: unit columns, ring-major
+    DevBuf<float> g_frag32, g_bhat32;  // mode 3 (f32 MFMA)
     DevBuf<unsigned long long> g_dmask;
     size_t pair_cap = 0;
     // keyframe downsampling for scal_sc_insert_features (lazy)
@@ -1196,38 +1226,48 @@ extern "C" int scal_sc_distance_pairs(scal_sc_t* c, const int* idx_a, const int*
     return SCAL_OK;
 }
 
-// mode 0 / 1: one wave per pair on the vector ALUs (summation order of the reference); mode 2: matrix cores (k_sc_gram)
-static int enqueue_matrix(scal_sc* c, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift, hipStream_t s) {
-    const int nq = q1 - q0, nd = d1 - d0;
-    const size_t np = static_cast<size_t>(nq) * nd;
-    if (mode != 2) {
-        SCAL_LAUNCH_PROF("k_sc_matrix", k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, nq, d0, nd, mode,
-                         d_dist, d_shift);
-        SCAL_HIP(hipGetLastError());
-        return SCAL_OK;
-    }
+template <typename T>
+static int enqueue_gram(scal_sc* c, int q0, int nq, int d0, int nd, DevBuf<T>& frag, DevBuf<T>& bhat, double* d_dist, int* d_shift, hipStream_t s) {
+    constexpr int GE = GramT<T>::GE;
     const int qblocks = div_up(nq, GQ), n_tiles = qblocks * 4, chunks = div_up(nd, GE);
     if (qblocks > 65535) {
         set_error("scal_sc_distance_matrix: more than 65535 x 64 queries in one call");
         return SCAL_E_ARG;
     }
     const size_t frag_n = static_cast<size_t>(n_tiles) * GKS * 64;
-    if (c->g_frag.n < frag_n) SCAL_TRY(c->g_frag.alloc(frag_n));
+    if (frag.n < frag_n) SCAL_TRY(frag.alloc(frag_n));
     if (c->g_qmask.n < static_cast<size_t>(n_tiles) * 16) SCAL_TRY(c->g_qmask.alloc(static_cast<size_t>(n_tiles) * 16));
-    const size_t lds = sizeof(double) * GE * NR * GROW;  // 79,360 B: above the 64 KiB default, two workgroups per CU
-    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_gram), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-    if (c->g_bhat.n < static_cast<size_t>(nd) * DESC) SCAL_TRY(c->g_bhat.alloc(static_cast<size_t>(nd) * DESC));
+    if (bhat.n < static_cast<size_t>(nd) * DESC) SCAL_TRY(bhat.alloc(static_cast<size_t>(nd) * DESC));
     if (c->g_dmask.n < static_cast<size_t>(nd)) SCAL_TRY(c->g_dmask.alloc(nd));
-    SCAL_LAUNCH_PROF("k_sc_gram_prep", k_sc_gram_prep, dim3(n_tiles), dim3(256), 0, s, c->db(), q0, nq, c->g_frag.p, c->g_qmask.p);
-    SCAL_LAUNCH_PROF("k_sc_gram_prep_db", k_sc_gram_prep_db, dim3(nd), dim3(256), 0, s, c->db(), d0, nd, c->g_bhat.p, c->g_dmask.p);
-    SCAL_LAUNCH_PROF("k_sc_gram", k_sc_gram, dim3(chunks, qblocks), dim3(256), lds, s, c->g_bhat.p, c->g_dmask.p, c->g_frag.p, c->g_qmask.p, nq, nd,
-                     d_dist, d_shift);
+    const size_t lds = sizeof(T) * GE * NR * GROW;  // 79,360 B: above the 64 KiB default, two workgroups per CU
+    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sc_gram<T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+    const bool f64 = sizeof(T) == 8;
+    SCAL_LAUNCH_PROF(f64 ? "k_sc_gram_prep" : "k_sc_gram_prep_f32", k_sc_gram_prep<T>, dim3(n_tiles), dim3(256), 0, s, c->db(), q0, nq, frag.p,
+                     c->g_qmask.p);
+    SCAL_LAUNCH_PROF(f64 ? "k_sc_gram_prep_db" : "k_sc_gram_prep_db_f32", k_sc_gram_prep_db<T>, dim3(nd), dim3(256), 0, s, c->db(), d0, nd, bhat.p,
+                     c->g_dmask.p);
+    SCAL_LAUNCH_PROF(f64 ? "k_sc_gram" : "k_sc_gram_f32", k_sc_gram<T>, dim3(chunks, qblocks), dim3(256), lds, s, bhat.p, c->g_dmask.p, frag.p,
+                     c->g_qmask.p, nq, nd, d_dist, d_shift);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
+// mode 0 / 1: one wave per pair on the vector ALUs (summation order of the reference); mode 2: matrix cores (k_sc_gram)
+static int enqueue_matrix(scal_sc* c, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift, hipStream_t s) {
+    const int nq = q1 - q0, nd = d1 - d0;
+    const size_t np = static_cast<size_t>(nq) * nd;
+    if (mode < 2) {
+        SCAL_LAUNCH_PROF("k_sc_matrix", k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, nq, d0, nd, mode,
+                         d_dist, d_shift);
+        SCAL_HIP(hipGetLastError());
+        return SCAL_OK;
+    }
+    return mode == 2 ? enqueue_gram<double>(c, q0, nq, d0, nd, c->g_frag, c->g_bhat, d_dist, d_shift, s)
+                     : enqueue_gram<float>(c, q0, nq, d0, nd, c->g_frag32, c->g_bhat32, d_dist, d_shift, s);
+}
+
 static int check_matrix_args(scal_sc* c, const void* dist, const void* shift, int q0, int q1, int d0, int d1, int mode) {
-    if (!c || !dist || !shift || q0 < 0 || d0 < 0 || q1 < q0 || d1 < d0 || mode < 0 || mode > 2) {
+    if (!c || !dist || !shift || q0 < 0 || d0 < 0 || q1 < q0 || d1 < d0 || mode < 0 || mode > 3) {
         set_error("scal_sc_distance_matrix: bad argument");
         return SCAL_E_ARG;
     }

@@ -176,6 +176,17 @@ def test_sc_matrix_mfma(O, S):
     assert np.array_equal(Db, D2[5:78, 9:138]) and np.array_equal(Sb, S2[5:78, 9:138])
     Dc, Sc = gm.distance_matrix(100, 101, 0, 3, mode=2)
     assert np.array_equal(Dc, D2[100:101, 0:3]) and np.array_equal(Sc, S2[100:101, 0:3])
+    # mode 3: f32 matrix cores, held to the path's 1e-5 (BASELINE.json north_star); the shift may differ only between
+    # shifts whose f64 distances are closer than the f32 error
+    D3, S3 = gm.distance_matrix(0, 140, 0, 140, mode=3)
+    assert np.abs(D3 - D2).max() <= 1e-5
+    for q, j in zip(*np.nonzero(S3 != S2)):
+        full = O.sc_distance_full(descs[q], descs[j])
+        assert abs(full[S3[q, j]] - full[S2[q, j]]) <= 1e-5
+    assert (S3 != S2).mean() < 0.01
+    assert np.all(D3[17, :] == 10000000) and np.all(S3[17, :] == 0)
+    Db3, Sb3 = gm.distance_matrix(5, 78, 9, 138, mode=3)
+    assert np.array_equal(Db3, D3[5:78, 9:138]) and np.array_equal(Sb3, S3[5:78, 9:138])
     gm.close()
 
 

@@ -4,7 +4,9 @@ query against every database descriptor over all 60 column shifts, on the matrix
 k_sc_gram).  Prints one JSON line with the MFMA roofline of k_sc_gram (algorithmic flops = 2*20*60*60 per pair), the vector-ALU
 mode 1 (reference summation order) on a slice, the oracle's CPU rate on a sample, and two checks that hold at any size:
 mode 2 == mode 1 on the slice, and the shift symmetry D[a][b] == D[b][a], shift[a][b] == (60 - shift[b][a]) % 60.
-Not the headline benchmark (that is bench.py, config #2)."""
+Not the headline benchmark (that is bench.py, config #2).
+N > 1 (torch.distributed, one process per GPU): every rank holds the whole database (48 MB at 5,000) and computes its own row
+block of the pair grid - no exchange on the data path (dense mode), strong scaling, time = max over ranks."""
 import argparse
 import json
 import os
@@ -39,33 +41,77 @@ def descriptors(n, seed):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=5000, help="descriptors in the database (= queries)")
+    ap.add_argument("--db-size", "--n", dest="n", type=int, default=5000, help="descriptors in the database (= queries)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slice", type=int, default=256, help="queries of the mode-1 comparison slice")
     ap.add_argument("--cpu-pairs", type=int, default=20000)
     ap.add_argument("--probe", default="", help="path of the built tools/mfma_f64_peak.hip probe (optional)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--backend", default="nccl")
     a = ap.parse_args()
     import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(a.backend, rank=rank, world_size=world)
     import scaloam as S
     n = a.n
     descs = descriptors(n, 401)
-    sc = S.SCManager(max_keyframes=max(8192, n + 8))
+    sc = S.SCManager(max_keyframes=max(8192, n + 8), device=local)
     for d in descs:
         sc.saveScancontextAndKeys(d)
-    d_dist = torch.empty(n * n, dtype=torch.float64, device="cuda")
-    d_shift = torch.empty(n * n, dtype=torch.int32, device="cuda")
+    r0, r1 = rank * n // world, (rank + 1) * n // world  # this rank's row block of the pair grid
+    d_dist = torch.empty((r1 - r0) * n, dtype=torch.float64, device="cuda")
+    d_shift = torch.empty((r1 - r0) * n, dtype=torch.int32, device="cuda")
     for _ in range(a.warmup):
-        sc.distance_matrix_device(0, n, 0, n, 2, d_dist.data_ptr(), d_shift.data_ptr())
+        sc.distance_matrix_device(r0, r1, 0, n, 2, d_dist.data_ptr(), d_shift.data_ptr())
         sc.sync()
     S.prof_reset()
     S.prof_enable(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        sc.distance_matrix_device(0, n, 0, n, 2, d_dist.data_ptr(), d_shift.data_ptr())
+        sc.distance_matrix_device(r0, r1, 0, n, 2, d_dist.data_ptr(), d_shift.data_ptr())
     sc.sync()
     dt = (time.perf_counter() - t0) / a.steps
     S.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # every rank checks its own block against the oracle on a few pairs; rank 0 reports
+        import oracle_py as O
+        Dr = d_dist.cpu().numpy().reshape(r1 - r0, n)
+        Sr = d_shift.cpu().numpy().reshape(r1 - r0, n)
+        rng = np.random.default_rng(5 + rank)
+        bad = 0
+        for x, y in zip(rng.integers(r0, r1, 200), rng.integers(0, n, 200)):
+            full = O.sc_distance_full(descs[x], descs[y])
+            full = np.where(np.isnan(full), 1e300, full)
+            k = int(np.argmin(full))
+            bad += int(abs(float(full[k]) - Dr[x - r0, y]) > 1e-12 or k != Sr[x - r0, y])
+        tb = torch.tensor([bad], dtype=torch.int64, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(tb)
+        ms, cnt = S.prof_read_all()["k_sc_gram"]
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            ach = FLOP_PER_PAIR * (r1 - r0) * n / (ms / cnt * 1e-3) / 1e12
+            print(json.dumps({
+                "metric": "pairs/sec, dense ScanContext distance matrix over all 60 shifts", "value": n * n / dt, "unit": "pairs/s",
+                "n_gpus": world, "scaling": "strong", "descriptors": n, "ms_per_matrix": dt * 1e3, "dtype": "f64",
+                "roofline": {"bound": "mfma", "kernel": "k_sc_gram", "achieved": ach, "peak": PEAK_F64_MFMA, "unit": "TFLOP/s",
+                             "frac": ach / PEAK_F64_MFMA, "note": "rank 0's row block"},
+                "checks": {"oracle_mismatches_over_all_ranks": int(tb.item()), "pairs_checked": 200 * world}}))
+        return
     prof = S.prof_read_all()
     ms, cnt = prof["k_sc_gram"]
     gram_s = ms / cnt * 1e-3
@@ -91,6 +137,25 @@ def main():
     m1_ms, m1_cnt = S.prof_read_all()["k_sc_matrix"]
     D1 = d1.cpu().numpy().reshape(ns, n)
     S1 = s1.cpu().numpy().reshape(ns, n)
+    # mode 3: the same product on the f32 matrix cores
+    d3 = torch.empty(n * n, dtype=torch.float64, device="cuda")
+    s3 = torch.empty(n * n, dtype=torch.int32, device="cuda")
+    sc.distance_matrix_device(0, n, 0, n, 3, d3.data_ptr(), s3.data_ptr())
+    sc.sync()
+    S.prof_reset()
+    S.prof_enable(True)
+    for _ in range(a.steps):
+        sc.distance_matrix_device(0, n, 0, n, 3, d3.data_ptr(), s3.data_ptr())
+    sc.sync()
+    S.prof_enable(False)
+    f32_ms, f32_cnt = S.prof_read_all()["k_sc_gram_f32"]
+    D3 = d3.cpu().numpy().reshape(n, n)
+    S3 = s3.cpu().numpy().reshape(n, n)
+    f32_diff = float(np.abs(D3 - D2).max())
+    f32_shift = int((S3 != S2).sum())
+    # where the shift differs, the two shifts' f64 distances are closer than the f32 error (checked through the oracle below)
+    f32_shift_pairs = [(int(x), int(y)) for x, y in zip(*np.nonzero(S3 != S2))][:50]
+    del d3, s3
     max_diff = float(np.abs(D1 - D2[:ns]).max())
     shift_mismatch = int((S1 != S2[:ns]).sum())
     # oracle (CPU restatement of distDirectSC over the 60 shifts) on a sample of pairs
@@ -107,6 +172,10 @@ def main():
         worst = max(worst, abs(float(full[k]) - D2[x, y]))
         bad_shift += int(k != S2[x, y])
     cpu_dt = time.perf_counter() - t1
+    f32_gap = 0.0
+    for x, y in f32_shift_pairs:
+        full = O.sc_distance_full(descs[x], descs[y])
+        f32_gap = max(f32_gap, abs(float(full[S3[x, y]]) - float(full[S2[x, y]])))
     probe = None
     if a.probe and os.path.exists(a.probe):
         try:
@@ -121,6 +190,10 @@ def main():
                      "avg_launch_ms": gram_s * 1e3, "algorithmic_flop_per_launch": FLOP_PER_PAIR * n * n, "issued_flop_per_launch":
                      2048.0 * 16 * 300 * 4 * ((n + 63) // 64) * ((n + 3) // 4), "measured_issue_peak": probe, "traffic": None},
         "prep_ms": prep_ms,
+        "mode3_f32_mfma": {"kernel": "k_sc_gram_f32", "avg_launch_ms": f32_ms / f32_cnt, "pairs_per_s": n * n / (f32_ms / f32_cnt * 1e-3),
+                           "achieved": FLOP_PER_PAIR * n * n / (f32_ms / f32_cnt * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                           "frac": FLOP_PER_PAIR * n * n / (f32_ms / f32_cnt * 1e-3) / 1e12 / 157.3, "max_abs_vs_mode2": f32_diff,
+                           "shift_differs_from_mode2": f32_shift, "max_f64_gap_between_differing_shifts": f32_gap},
         "mode1_vector_alu": {"queries": ns, "ms": m1_ms / m1_cnt, "pairs_per_s": ns * n / (m1_ms / m1_cnt * 1e-3)},
         "cpu_baseline": {"value": a.cpu_pairs / cpu_dt, "unit": "pairs/s", "cores": 1, "kind": "port",
                          "sample": f"{a.cpu_pairs} random pairs through the oracle's 60-shift distDirectSC (incl. the ctypes call)"},
