@@ -530,7 +530,9 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, 
     extern __shared__ __attribute__((aligned(16))) unsigned char ext_raw[];
     T* ext = reinterpret_cast<T*>(ext_raw);  // [GE][NR][GROW]
     __shared__ unsigned long long bmask[GE];
+    __shared__ double inv_eff[NS + 1];  // f32 mode only: 1 / eff, so its 128 quotients per lane are products
     const int chunk = blockIdx.x, lane = lane_id(), w = wave_id();
+    if (sizeof(T) == 4 && threadIdx.x <= NS) inv_eff[threadIdx.x] = threadIdx.x ? 1.0 / threadIdx.x : 0.0;
     // extended rows, 16 bytes per copy: x a multiple of VEC -> c = (x - 64) mod 60 is one too, so a copy never straddles the wrap
     for (int i = threadIdx.x; i < GE * NR * GROW / VEC; i += blockDim.x) {
         const int e = i / (NR * GROW / VEC), rem = i - e * (NR * GROW / VEC);
@@ -608,7 +610,11 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, 
                 if (s < NS) {
                     const unsigned long long rot = ((mb << s) | (mb >> (NS - s))) & m60;
                     const int eff = __popcll(ma & rot);
-                    double dd = 1.0 - static_cast<double>(acc[e][t][reg]) / eff;
+                    double dd;
+                    if (sizeof(T) == 4)
+                        dd = 1.0 - static_cast<double>(acc[e][t][reg]) * inv_eff[eff];
+                    else
+                        dd = 1.0 - acc[e][t][reg] / eff;
                     if (eff == 0 || !(dd == dd)) dd = 1e300;
                     if (dd < bd) bd = dd, bs = s;
                 }
