@@ -13,8 +13,9 @@
 //   host          Horn's closed form of the rigid least-squares fit (what TransformationEstimationSVD / Eigen::umeyama solve),
 //                 PCL's DefaultConvergenceCriteria
 //   k_icp_apply   the increment applied to the source cloud in place, f32 as PCL does
-// The reference pays a kd-tree query per point and iteration on the CPU; here one iteration is a dense 20k x 200k distance
-// sweep (~2 ms) - brute force, but exact and branch-free.  A cell grid is the obvious next step.
+// The reference pays a kd-tree query per point and iteration on the CPU.  Here the target is bucketed into a cell grid once per
+// alignment and a wave per query searches it ring by ring (k_icp_grid_nn, exact); queries the grid cannot settle within three
+// rings fall back to the dense sweep of k_icp_nn, which is also the whole search when scal_icp_set_search(ctx, 0) asks for it.
 #include "common.hpp"
 #include "device_utils.hpp"
 #include <cmath>
@@ -28,20 +29,28 @@ constexpr int ICP_QT = 256 * ICP_QPT;  // queries per workgroup
 constexpr int ICP_TC = 2048;   // targets per workgroup
 constexpr int ICP_NSUM = 17;   // n, sum p[3], sum q[3], sum q p^T[9], sum d^2
 
+// qlist == nullptr: queries are cur[0 .. n_src); else the *d_nq queries qlist[] (the cell grid's unresolved ones; surplus
+// workgroups leave at once)
 __global__ void __launch_bounds__(256) k_icp_nn(const float4* __restrict__ cur, int n_src, const float4* __restrict__ tgt, int n_tgt,
-                                                unsigned long long* __restrict__ best) {
+                                                unsigned long long* __restrict__ best, const int* __restrict__ qlist,
+                                                const int* __restrict__ d_nq) {
     __shared__ float4 st[ICP_TC];
+    if (qlist) {
+        n_src = *d_nq;
+        if (static_cast<int>(blockIdx.x) * ICP_QT >= n_src) return;
+    }
     const int t0 = blockIdx.y * ICP_TC;
     const int tn = min(ICP_TC, n_tgt - t0);
     for (int i = threadIdx.x; i < tn; i += 256) st[i] = tgt[t0 + i];
     __syncthreads();
     // every thread owns ICP_QPT queries and walks the whole chunk: one LDS broadcast read feeds ICP_QPT distance evaluations
     float qx[ICP_QPT], qy[ICP_QPT], qz[ICP_QPT], bd[ICP_QPT];
-    int bi[ICP_QPT];
+    int bi[ICP_QPT], qid[ICP_QPT];
 #pragma unroll
     for (int u = 0; u < ICP_QPT; ++u) {
         const int qi = blockIdx.x * ICP_QT + u * 256 + threadIdx.x;
-        const float4 q = qi < n_src ? cur[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qid[u] = qi < n_src ? (qlist ? qlist[qi] : qi) : -1;
+        const float4 q = qid[u] >= 0 ? cur[qid[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
         qx[u] = q.x, qy[u] = q.y, qz[u] = q.z, bd[u] = 3.4e38f, bi[u] = -1;
     }
 #pragma unroll 2
@@ -58,17 +67,188 @@ __global__ void __launch_bounds__(256) k_icp_nn(const float4* __restrict__ cur, 
     }
 #pragma unroll
     for (int u = 0; u < ICP_QPT; ++u) {
-        const int qi = blockIdx.x * ICP_QT + u * 256 + threadIdx.x;
-        if (qi < n_src && bi[u] >= 0)
-            atomicMin(&best[qi], (static_cast<unsigned long long>(__float_as_uint(bd[u])) << 32) | static_cast<unsigned>(t0 + bi[u]));
+        if (qid[u] >= 0 && bi[u] >= 0)
+            atomicMin(&best[qid[u]], (static_cast<unsigned long long>(__float_as_uint(bd[u])) << 32) | static_cast<unsigned>(t0 + bi[u]));
+    }
+}
+
+// ---- cell grid over the target (built once per alignment) ---------------------------------------------------------------------
+// Exact nearest neighbour without the dense sweep: target points bucketed into <= 2^18 cubic cells (counting sort, original
+// index kept beside each point); a wave per query examines the cube of cells around the query ring by ring.  After ring k every
+// unexamined point lies more than k cell widths away, so the search stops as soon as the best squared distance is below
+// ((k - 0.05) c)^2 (the margin covers the f32 cell assignment); keys are (f32 squared distance, original index) exactly as in the dense
+// sweep, so equal distances still resolve to the lowest index.  Queries with nothing that close within ICP_RINGS rings (far
+// outliers, a poor initial guess) go to the dense sweep as a list - the result is the same either way.
+constexpr int ICP_NCELL = 1 << 18;
+constexpr int ICP_RINGS = 3;
+struct IcpGrid {
+    float ox, oy, oz, cell, inv;
+    int dx, dy, dz;
+};
+
+__global__ void __launch_bounds__(256) k_icp_bbox(const float4* __restrict__ tgt, int n, unsigned* __restrict__ mm) {
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 p = tgt[i];
+        if (!(fabsf(p.x) < 3.4e38f && fabsf(p.y) < 3.4e38f && fabsf(p.z) < 3.4e38f)) continue;  // never a neighbour either
+        lo[0] = fminf(lo[0], p.x), lo[1] = fminf(lo[1], p.y), lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x), hi[1] = fmaxf(hi[1], p.y), hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = wave_min_i(static_cast<int>(float_to_ordered(lo[k]) ^ 0x80000000u));
+        const int b = wave_max_i(static_cast<int>(float_to_ordered(hi[k]) ^ 0x80000000u));
+        if (lane_id() == 0) {
+            atomicMin(&mm[k], static_cast<unsigned>(a) ^ 0x80000000u);
+            atomicMax(&mm[3 + k], static_cast<unsigned>(b) ^ 0x80000000u);
+        }
+    }
+}
+
+// one thread: origin, cell width (>= min_cell, grown until the grid fits ICP_NCELL cells), dimensions; resets the box for the next call
+__global__ void k_icp_grid_setup(unsigned* __restrict__ mm, IcpGrid* __restrict__ g, float min_cell) {
+    float lo[3], ext[3];
+    bool ok = true;
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = ordered_to_float(mm[k]);
+        const float hi = ordered_to_float(mm[3 + k]);
+        ext[k] = hi - lo[k];
+        ok = ok && hi >= lo[k];
+        mm[k] = 0xffffffffu, mm[3 + k] = 0u;
+    }
+    IcpGrid r;
+    r.ox = lo[0], r.oy = lo[1], r.oz = lo[2], r.cell = min_cell, r.inv = 1.f / min_cell, r.dx = r.dy = r.dz = 0;
+    if (ok) {
+        float c = min_cell;
+        for (int it = 0; it < 200; ++it) {
+            const long long dx = static_cast<long long>(ext[0] / c) + 2, dy = static_cast<long long>(ext[1] / c) + 2,
+                            dz = static_cast<long long>(ext[2] / c) + 2;
+            if (dx * dy * dz <= ICP_NCELL) {
+                r.cell = c, r.inv = 1.f / c, r.dx = static_cast<int>(dx), r.dy = static_cast<int>(dy), r.dz = static_cast<int>(dz);
+                break;
+            }
+            c *= 1.1f;
+        }
+    }
+    *g = r;
+}
+
+__device__ __forceinline__ int icp_cell_coord(float v, float o, float inv) {
+    const float f = floorf((v - o) * inv);
+    return static_cast<int>(fminf(fmaxf(f, -1048576.f), 1048576.f));  // NaN -> -2^20: outside every grid
+}
+
+__global__ void __launch_bounds__(256) k_icp_cell_count(const float4* __restrict__ tgt, int n, const IcpGrid* __restrict__ gp,
+                                                        int* __restrict__ count, int* __restrict__ cell_of) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const IcpGrid g = *gp;
+    const float4 p = tgt[i];
+    const int x = icp_cell_coord(p.x, g.ox, g.inv), y = icp_cell_coord(p.y, g.oy, g.inv), z = icp_cell_coord(p.z, g.oz, g.inv);
+    int cell = -1;  // non-finite points are in no cell: they can never be a nearest neighbour (d < bd fails for NaN)
+    if (static_cast<unsigned>(x) < static_cast<unsigned>(g.dx) && static_cast<unsigned>(y) < static_cast<unsigned>(g.dy) &&
+        static_cast<unsigned>(z) < static_cast<unsigned>(g.dz)) {
+        cell = (z * g.dy + y) * g.dx + x;
+        atomicAdd(&count[cell], 1);
+    }
+    cell_of[i] = cell;
+}
+
+// exclusive scan of count[ICP_NCELL] in two launches: workgroup sums, then every workgroup adds the sums in front of it
+__global__ void __launch_bounds__(256) k_icp_scan_sums(const int* __restrict__ count, int* __restrict__ bsum) {
+    const int4 v = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
+    __shared__ int red[4];
+    const int s = wave_sum((v.x + v.y) + (v.z + v.w));
+    if (lane_id() == 0) red[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) k_icp_scan_apply(int* __restrict__ count, const int* __restrict__ bsum, int* __restrict__ start,
+                                                        int* __restrict__ total) {
+    __shared__ int smem[17];
+    __shared__ int red[4];
+    // sum of the workgroup sums in front of this one (gridDim.x = ICP_NCELL / 1024 = 256 = blockDim.x)
+    const int mine = static_cast<int>(threadIdx.x) < static_cast<int>(blockIdx.x) ? bsum[threadIdx.x] : 0;
+    const int ws = wave_sum(mine);
+    if (lane_id() == 0) red[wave_id()] = ws;
+    __syncthreads();
+    const int base = (red[0] + red[1]) + (red[2] + red[3]);
+    int4 v = reinterpret_cast<const int4*>(count)[blockIdx.x * 256 + threadIdx.x];
+    int tot;
+    const int ex = block_exclusive_scan((v.x + v.y) + (v.z + v.w), smem, &tot) + base;
+    int4 o;
+    o.x = ex, o.y = ex + v.x, o.z = o.y + v.y, o.w = o.z + v.z;
+    reinterpret_cast<int4*>(start)[blockIdx.x * 256 + threadIdx.x] = o;
+    reinterpret_cast<int4*>(count)[blockIdx.x * 256 + threadIdx.x] = make_int4(0, 0, 0, 0);  // becomes the fill cursor, zero again after
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) start[ICP_NCELL] = base + tot, *total = base + tot;
+}
+
+__global__ void __launch_bounds__(256) k_icp_cell_fill(const float4* __restrict__ tgt, int n, const int* __restrict__ cell_of,
+                                                       const int* __restrict__ start, int* __restrict__ cursor, float4* __restrict__ sorted) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int cell = cell_of[i];
+    if (cell < 0) return;
+    float4 p = tgt[i];
+    p.w = __int_as_float(i);
+    sorted[start[cell] + atomicAdd(&cursor[cell], 1)] = p;
+}
+
+// one wave per query
+__global__ void __launch_bounds__(256) k_icp_grid_nn(const float4* __restrict__ cur, int n_src, const IcpGrid* __restrict__ gp,
+                                                     const int* __restrict__ start, const float4* __restrict__ sorted,
+                                                     unsigned long long* __restrict__ best, int* __restrict__ un_list, int* __restrict__ d_nun) {
+    const int qi = blockIdx.x * 4 + wave_id();
+    if (qi >= n_src) return;
+    const IcpGrid g = *gp;
+    const int lane = lane_id();
+    const float4 q = cur[qi];
+    const int cx = icp_cell_coord(q.x, g.ox, g.inv), cy = icp_cell_coord(q.y, g.oy, g.inv), cz = icp_cell_coord(q.z, g.oz, g.inv);
+    unsigned long long bk = ~0ull;
+    bool done = false;
+    for (int k = 1; k <= ICP_RINGS && !done; ++k) {
+        const int w = 2 * k + 1, ncube = w * w * w;
+        for (int j = lane; j < ncube; j += 64) {
+            const int jz = j / (w * w), rem = j - jz * w * w, jy = rem / w, jx = rem - jy * w;
+            const int ax = jx - k, ay = jy - k, az = jz - k;
+            if (k > 1 && max(max(abs(ax), abs(ay)), abs(az)) < k) continue;  // examined in an earlier ring
+            const int x = cx + ax, y = cy + ay, z = cz + az;
+            if (static_cast<unsigned>(x) >= static_cast<unsigned>(g.dx) || static_cast<unsigned>(y) >= static_cast<unsigned>(g.dy) ||
+                static_cast<unsigned>(z) >= static_cast<unsigned>(g.dz))
+                continue;
+            const int cell = (z * g.dy + y) * g.dx + x;
+            const int s0 = start[cell], s1 = start[cell + 1];
+            for (int t = s0; t < s1; ++t) {
+                const float4 p = sorted[t];
+                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                float d = dx * dx;  // the dense sweep's arithmetic
+                d += dy * dy;
+                d += dz * dz;
+                if (d < 3.4e38f) {
+                    const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(__float_as_int(p.w));
+                    bk = key < bk ? key : bk;
+                }
+            }
+        }
+        bk = wave_min_u64(bk);
+        const float bound = (static_cast<float>(k) - 0.05f) * g.cell;  // 0.05 cells: the f32 cell assignment of either point
+        done = bk != ~0ull && __uint_as_float(static_cast<unsigned>(bk >> 32)) < bound * bound;
+    }
+    if (lane == 0) {
+        if (done)
+            best[qi] = bk;
+        else
+            un_list[atomicAdd(d_nun, 1)] = qi;
     }
 }
 
 // partial sums of one workgroup of 256 source points; resets the keys for the next sweep
 __global__ void __launch_bounds__(256) k_icp_reduce(const float4* __restrict__ cur, int n_src, const float4* __restrict__ tgt,
-                                                    unsigned long long* __restrict__ best, float max2, double* __restrict__ partials) {
+                                                    unsigned long long* __restrict__ best, float max2, double* __restrict__ partials,
+                                                    int* __restrict__ d_nun) {
     __shared__ double red[4][ICP_NSUM];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *d_nun = 0;  // the cell grid's unresolved-query list is consumed by now
     double v[ICP_NSUM];
 #pragma unroll
     for (int k = 0; k < ICP_NSUM; ++k) v[k] = 0.0;
@@ -206,6 +386,13 @@ struct scal_icp {
     DevBuf<unsigned long long> best;
     DevBuf<double> partials;
     PinBuf<double> h_sums;
+    // cell grid over the target
+    int search = 1;  // 0: dense sweep, 1: cell grid with the dense sweep for unresolved queries
+    bool grid_built = false;
+    DevBuf<IcpGrid> grid;
+    DevBuf<unsigned> mm;
+    DevBuf<int> count, start, bsum, cell_of, un_list, d_nun;
+    DevBuf<float4> sorted;
 };
 
 extern "C" int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** out) {
@@ -223,12 +410,28 @@ extern "C" int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** out) {
     A(c->best.alloc(cfg->max_source));
     A(c->partials.alloc(static_cast<size_t>(ICP_NSUM) * (div_up(cfg->max_source, 256) + 1)));
     A(c->h_sums.alloc(ICP_NSUM));
+    A(c->grid.alloc(1)); A(c->mm.alloc(6)); A(c->count.alloc(ICP_NCELL)); A(c->start.alloc(ICP_NCELL + 4)); A(c->bsum.alloc(256));
+    A(c->cell_of.alloc(cfg->max_target)); A(c->sorted.alloc(cfg->max_target)); A(c->un_list.alloc(cfg->max_source)); A(c->d_nun.alloc(2));
+    if (rc == SCAL_OK) {
+        const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+        if (hipMemcpy(c->mm.p, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->d_nun.p, 0, 2 * sizeof(int)) != hipSuccess)
+            rc = SCAL_E_HIP;
+    }
     if (rc == SCAL_OK && acquire_stream(cfg->device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc != SCAL_OK) {
         delete c;
         return rc;
     }
     *out = c;
+    return SCAL_OK;
+}
+
+extern "C" int scal_icp_set_search(scal_icp_t* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) {
+        set_error("scal_icp_set_search: bad argument");
+        return SCAL_E_ARG;
+    }
+    c->search = mode;
     return SCAL_OK;
 }
 
@@ -246,8 +449,17 @@ extern "C" void scal_icp_destroy(scal_icp_t* c) {
 static int icp_sweep(scal_icp* c, const float4* pts, int n_src, int n_tgt, float max2) {
     hipStream_t s = c->stream;
     const int nb = div_up(n_src, 256);
-    SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt, c->best.p);
-    hipLaunchKernelGGL(k_icp_reduce, dim3(nb), dim3(256), 0, s, pts, n_src, c->tgt.p, c->best.p, max2, c->partials.p);
+    const int* no_list = nullptr;
+    if (c->grid_built) {
+        SCAL_LAUNCH_PROF("k_icp_grid_nn", k_icp_grid_nn, dim3(div_up(n_src, 4)), dim3(256), 0, s, pts, n_src, c->grid.p, c->start.p, c->sorted.p,
+                         c->best.p, c->un_list.p, c->d_nun.p);
+        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt,
+                         c->best.p, c->un_list.p, c->d_nun.p);
+    } else {
+        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt,
+                         c->best.p, no_list, no_list);
+    }
+    hipLaunchKernelGGL(k_icp_reduce, dim3(nb), dim3(256), 0, s, pts, n_src, c->tgt.p, c->best.p, max2, c->partials.p, c->d_nun.p);
     hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(64), 0, s, c->partials.p, nb, c->h_sums.p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipStreamSynchronize(s));
@@ -277,6 +489,19 @@ extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, c
     SCAL_HIP(hipMemcpyAsync(c->cur.p, src_xyzi, sizeof(float) * 4 * n_src, hipMemcpyHostToDevice, s));
     SCAL_HIP(hipMemcpyAsync(c->tgt.p, tgt_xyzi, sizeof(float) * 4 * n_tgt, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_icp_fill, dim3(div_up(n_src, 256)), dim3(256), 0, s, c->best.p, n_src);
+    c->grid_built = false;
+    if (c->search == 1 && n_tgt >= 4 * ICP_TC) {  // small targets: the dense sweep is a handful of workgroups anyway
+        SCAL_HIP(hipMemsetAsync(c->count.p, 0, sizeof(int) * ICP_NCELL, s));
+        hipLaunchKernelGGL(k_icp_bbox, dim3(std::min(div_up(n_tgt, 256), 1024)), dim3(256), 0, s, c->tgt.p, n_tgt, c->mm.p);
+        hipLaunchKernelGGL(k_icp_grid_setup, dim3(1), dim3(1), 0, s, c->mm.p, c->grid.p, 1.0f);
+        hipLaunchKernelGGL(k_icp_cell_count, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, c->tgt.p, n_tgt, c->grid.p, c->count.p, c->cell_of.p);
+        hipLaunchKernelGGL(k_icp_scan_sums, dim3(ICP_NCELL / 1024), dim3(256), 0, s, c->count.p, c->bsum.p);
+        hipLaunchKernelGGL(k_icp_scan_apply, dim3(ICP_NCELL / 1024), dim3(256), 0, s, c->count.p, c->bsum.p, c->start.p, c->d_nun.p + 1);
+        SCAL_LAUNCH_PROF("k_icp_cell_fill", k_icp_cell_fill, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, c->tgt.p, n_tgt, c->cell_of.p, c->start.p,
+                         c->count.p, c->sorted.p);
+        SCAL_HIP(hipGetLastError());
+        c->grid_built = true;
+    }
     const float max2 = static_cast<float>(c->cfg.max_corr_dist * c->cfg.max_corr_dist);
     const double te = c->cfg.transformation_epsilon, fe = c->cfg.fitness_epsilon;
     int it = 0, st = 0;

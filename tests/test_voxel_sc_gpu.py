@@ -359,6 +359,32 @@ def test_loop_icp_matches_oracle(O, S, golden):
         x.close()
 
 
+def test_loop_icp_cell_grid_equals_dense_sweep(S, golden):
+    """The cell grid (default) and the dense sweep find the same nearest neighbours - same squared distances, lowest index on
+    ties - so every iterate, the final transform and the fitness are bit-identical.  Cases: partial overlap; a 30 m initial offset
+    (most queries unresolved by the grid in the first iterations: the dense-sweep list path); a target with a far outlier, a
+    non-finite point and duplicated points (equal distances); queries far outside the grid."""
+    vg = S.VoxelGrid()
+    a = vg.filter(golden("KAIST03_000000.npy"), 0.4)
+    b = vg.filter(golden("KAIST03_000007.npy"), 0.4)
+    tgt = np.concatenate([a, vg.filter(golden("KAIST03_000020.npy"), 0.4)])
+    assert tgt.shape[0] >= 8192  # large enough for the grid to be built
+    far = b.copy()
+    far[:, 0] += 30.0
+    odd = np.concatenate([tgt, tgt[:500], np.array([[5000.0, -3000.0, 40.0, 0.0], [np.nan, 1.0, 2.0, 0.0]], np.float32)]).astype(np.float32)
+    out = b.copy()
+    out[:50, :3] += np.array([800.0, 650.0, -30.0], np.float32)
+    grid = S.LoopICP(max_source=100000, max_target=400000, max_iterations=30)
+    dense = S.LoopICP(max_source=100000, max_target=400000, max_iterations=30)
+    dense.set_search(0)
+    for src, t in ((b, tgt), (far, tgt), (b, odd), (out, tgt)):
+        rg, rd = grid.align(src, t), dense.align(src, t)
+        assert rg["iterations"] == rd["iterations"] and rg["state"] == rd["state"] and rg["n_correspondences"] == rd["n_correspondences"]
+        assert np.array_equal(rg["T"], rd["T"]) and rg["fitness"] == rd["fitness"]
+    for x in (vg, grid, dense):
+        x.close()
+
+
 def test_sc_5k_database_8_shards(S):
     """BASELINE config #4 shape: a 5000-keyframe database sharded 8 ways (keyframe i on shard i % 8), batched insert + query per
     step exactly as bench.py --gpus 8 issues them, against ONE context holding the whole database (the path validated against
