@@ -323,6 +323,9 @@ int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** ctx);
 void scal_icp_destroy(scal_icp_t* ctx);
 /* icp.setInputSource(src); icp.setInputTarget(tgt); icp.align(): xyzi host records */
 int scal_icp_align(scal_icp_t* ctx, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, scal_icp_result* res);
+/* the same with both clouds already in HBM (16-byte xyzi records, e.g. scal_mapmerge_device_points / a device voxel output): the
+ * source is copied into the context, the target is read in place and must stay valid until the call returns */
+int scal_icp_align_device(scal_icp_t* ctx, const float* d_src_xyzi, int n_src, const float* d_tgt_xyzi, int n_tgt, scal_icp_result* res);
 /* nearest-neighbour search: 1 (default) = cell grid over the target, exact, with the dense sweep for queries it cannot settle;
  * 0 = dense sweep only.  Both stand in for pcl::KdTreeFLANN::nearestKSearch(k=1) (pcl/registration/impl/icp.hpp) and give the
  * same correspondences, lowest target index on equal distances. */

@@ -383,6 +383,7 @@ struct scal_icp {
     scal_icp_config cfg;
     hipStream_t stream = nullptr;
     DevBuf<float4> src, cur, tgt;
+    const float4* tgt_cur = nullptr;  // the target of the alignment in flight: tgt, or the caller's device cloud
     DevBuf<unsigned long long> best;
     DevBuf<double> partials;
     PinBuf<double> h_sums;
@@ -453,20 +454,21 @@ static int icp_sweep(scal_icp* c, const float4* pts, int n_src, int n_tgt, float
     if (c->grid_built) {
         SCAL_LAUNCH_PROF("k_icp_grid_nn", k_icp_grid_nn, dim3(div_up(n_src, 4)), dim3(256), 0, s, pts, n_src, c->grid.p, c->start.p, c->sorted.p,
                          c->best.p, c->un_list.p, c->d_nun.p);
-        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt,
+        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt_cur, n_tgt,
                          c->best.p, c->un_list.p, c->d_nun.p);
     } else {
-        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt.p, n_tgt,
+        SCAL_LAUNCH_PROF("k_icp_nn", k_icp_nn, dim3(div_up(n_src, ICP_QT), div_up(n_tgt, ICP_TC)), dim3(256), 0, s, pts, n_src, c->tgt_cur, n_tgt,
                          c->best.p, no_list, no_list);
     }
-    hipLaunchKernelGGL(k_icp_reduce, dim3(nb), dim3(256), 0, s, pts, n_src, c->tgt.p, c->best.p, max2, c->partials.p, c->d_nun.p);
+    hipLaunchKernelGGL(k_icp_reduce, dim3(nb), dim3(256), 0, s, pts, n_src, c->tgt_cur, c->best.p, max2, c->partials.p, c->d_nun.p);
     hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(64), 0, s, c->partials.p, nb, c->h_sums.p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
 }
 
-extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, scal_icp_result* res) {
+// clouds in host memory (on_device = false: staged into the context) or already in HBM (the target is then used in place)
+static int icp_align(scal_icp* c, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, bool on_device, scal_icp_result* res) {
     if (!c || !res || n_src < 0 || n_tgt < 0 || (n_src && !src_xyzi) || (n_tgt && !tgt_xyzi)) {
         set_error("scal_icp_align: bad argument");
         return SCAL_E_ARG;
@@ -485,19 +487,25 @@ extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, c
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->src.p, src_xyzi, sizeof(float) * 4 * n_src, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->cur.p, src_xyzi, sizeof(float) * 4 * n_src, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->tgt.p, tgt_xyzi, sizeof(float) * 4 * n_tgt, hipMemcpyHostToDevice, s));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    SCAL_HIP(hipMemcpyAsync(c->src.p, src_xyzi, sizeof(float) * 4 * n_src, kind, s));
+    SCAL_HIP(hipMemcpyAsync(c->cur.p, src_xyzi, sizeof(float) * 4 * n_src, kind, s));
+    const float4* tgt = c->tgt.p;
+    if (on_device)
+        tgt = reinterpret_cast<const float4*>(tgt_xyzi);
+    else
+        SCAL_HIP(hipMemcpyAsync(c->tgt.p, tgt_xyzi, sizeof(float) * 4 * n_tgt, hipMemcpyHostToDevice, s));
+    c->tgt_cur = tgt;
     hipLaunchKernelGGL(k_icp_fill, dim3(div_up(n_src, 256)), dim3(256), 0, s, c->best.p, n_src);
     c->grid_built = false;
     if (c->search == 1 && n_tgt >= 4 * ICP_TC) {  // small targets: the dense sweep is a handful of workgroups anyway
         SCAL_HIP(hipMemsetAsync(c->count.p, 0, sizeof(int) * ICP_NCELL, s));
-        hipLaunchKernelGGL(k_icp_bbox, dim3(std::min(div_up(n_tgt, 256), 1024)), dim3(256), 0, s, c->tgt.p, n_tgt, c->mm.p);
+        hipLaunchKernelGGL(k_icp_bbox, dim3(std::min(div_up(n_tgt, 256), 1024)), dim3(256), 0, s, tgt, n_tgt, c->mm.p);
         hipLaunchKernelGGL(k_icp_grid_setup, dim3(1), dim3(1), 0, s, c->mm.p, c->grid.p, 1.0f);
-        hipLaunchKernelGGL(k_icp_cell_count, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, c->tgt.p, n_tgt, c->grid.p, c->count.p, c->cell_of.p);
+        hipLaunchKernelGGL(k_icp_cell_count, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, tgt, n_tgt, c->grid.p, c->count.p, c->cell_of.p);
         hipLaunchKernelGGL(k_icp_scan_sums, dim3(ICP_NCELL / 1024), dim3(256), 0, s, c->count.p, c->bsum.p);
         hipLaunchKernelGGL(k_icp_scan_apply, dim3(ICP_NCELL / 1024), dim3(256), 0, s, c->count.p, c->bsum.p, c->start.p, c->d_nun.p + 1);
-        SCAL_LAUNCH_PROF("k_icp_cell_fill", k_icp_cell_fill, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, c->tgt.p, n_tgt, c->cell_of.p, c->start.p,
+        SCAL_LAUNCH_PROF("k_icp_cell_fill", k_icp_cell_fill, dim3(div_up(n_tgt, 256)), dim3(256), 0, s, tgt, n_tgt, c->cell_of.p, c->start.p,
                          c->count.p, c->sorted.p);
         SCAL_HIP(hipGetLastError());
         c->grid_built = true;
@@ -558,4 +566,12 @@ extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, c
     res->fitness = c->h_sums.p[0] > 0 ? c->h_sums.p[16] / c->h_sums.p[0] : std::numeric_limits<double>::max();
     for (int k = 0; k < 16; ++k) res->T[k] = F[k];
     return SCAL_OK;
+}
+
+extern "C" int scal_icp_align(scal_icp_t* c, const float* src_xyzi, int n_src, const float* tgt_xyzi, int n_tgt, scal_icp_result* res) {
+    return icp_align(c, src_xyzi, n_src, tgt_xyzi, n_tgt, false, res);
+}
+
+extern "C" int scal_icp_align_device(scal_icp_t* c, const float* d_src_xyzi, int n_src, const float* d_tgt_xyzi, int n_tgt, scal_icp_result* res) {
+    return icp_align(c, d_src_xyzi, n_src, d_tgt_xyzi, n_tgt, true, res);
 }

@@ -99,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
-    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_set_search",
+    "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_align_device", "scal_icp_set_search",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
 ]
@@ -177,6 +177,7 @@ def lib():
     L.scal_icp_destroy.restype = None
     L.scal_icp_align.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, C.POINTER(ICPResult)]
     L.scal_icp_set_search.argtypes = [vp, C.c_int]
+    L.scal_icp_align_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, C.POINTER(ICPResult)]
     L.scal_mapmerge_create.argtypes = [C.POINTER(MapMergeConfig), C.POINTER(vp)]
     L.scal_mapmerge_destroy.argtypes = [vp]
     L.scal_mapmerge_destroy.restype = None
@@ -577,6 +578,12 @@ class LoopICP:
         self.h = None
 
     __del__ = close
+
+    def align_device(self, d_src_ptr, n_src, d_tgt_ptr, n_tgt):
+        r = ICPResult()
+        _check(lib().scal_icp_align_device(self.h, d_src_ptr, n_src, d_tgt_ptr, n_tgt, C.byref(r)))
+        return dict(converged=bool(r.converged), iterations=r.iterations, state=r.state, n_correspondences=r.n_correspondences,
+                    fitness=r.fitness, T=np.array(r.T[:]).reshape(4, 4))
 
     def set_search(self, mode):
         """1 (default): cell grid + dense sweep for unresolved queries; 0: dense sweep only.  Same result."""

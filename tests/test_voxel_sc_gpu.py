@@ -381,6 +381,19 @@ def test_loop_icp_cell_grid_equals_dense_sweep(S, golden):
         rg, rd = grid.align(src, t), dense.align(src, t)
         assert rg["iterations"] == rd["iterations"] and rg["state"] == rd["state"] and rg["n_correspondences"] == rd["n_correspondences"]
         assert np.array_equal(rg["T"], rd["T"]) and rg["fitness"] == rd["fitness"]
+    # clouds already in HBM: same result as from host memory
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    bs, ts = np.ascontiguousarray(b, np.float32), np.ascontiguousarray(tgt, np.float32)
+    d_s, d_t = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_s), bs.nbytes) == 0 and hip.hipMemcpy(d_s, bs.ctypes.data, bs.nbytes, 1) == 0
+    assert hip.hipMalloc(ctypes.byref(d_t), ts.nbytes) == 0 and hip.hipMemcpy(d_t, ts.ctypes.data, ts.nbytes, 1) == 0
+    rh, rdv = grid.align(b, tgt), grid.align_device(d_s, bs.shape[0], d_t, ts.shape[0])
+    assert np.array_equal(rh["T"], rdv["T"]) and rh["fitness"] == rdv["fitness"] and rh["iterations"] == rdv["iterations"]
+    hip.hipFree(d_s), hip.hipFree(d_t)
     for x in (vg, grid, dense):
         x.close()
 
