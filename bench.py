@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
+    ap.add_argument("--sync-dir", default="", help="start the timed region together with --sync-n other bench.py processes (ready files in this directory)")
+    ap.add_argument("--sync-n", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
     return ap.parse_args()
 
@@ -336,6 +338,11 @@ def main():
     gc.collect()
     gc.disable()  # a generation-2 collection inside a ~40 ms timed region would be a visible fraction of it
     fence()
+    if a.sync_dir and a.sync_n > 1:  # several independent sequences on one GPU (tools/gpu_multi_seq.sh): common start
+        open(os.path.join(a.sync_dir, f"ready_{os.getpid()}"), "w").close()
+        while len([f for f in os.listdir(a.sync_dir) if f.startswith("ready_")]) < a.sync_n:
+            time.sleep(0.0005)
+    t_wall0 = time.time()
     t0 = time.perf_counter()
     n_prof_steps = 0
     for k in range(W, W + K):
@@ -385,6 +392,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / max(1, n_prof_steps) for k, v in sorted(prof.items())}, "profiled_steps": n_prof_steps,
             "loops_detected": int(stats["loops"]), "input_gen_s": gen_s, "final_map_pose": last_pose,
             "host_us_per_step": {k: v / K * 1e6 for k, v in host_t.items()} if a.host_timing else None,
+            "timed_window_unix": [t_wall0, t_wall0 + dt],
         }
         print(json.dumps(out))
     if world > 1:
