@@ -208,25 +208,46 @@ __global__ void __launch_bounds__(256) k_icp_grid_nn(const float4* __restrict__ 
     bool done = false;
     for (int k = 1; k <= ICP_RINGS && !done; ++k) {
         const int w = 2 * k + 1, ncube = w * w * w;
-        for (int j = lane; j < ncube; j += 64) {
-            const int jz = j / (w * w), rem = j - jz * w * w, jy = rem / w, jx = rem - jy * w;
-            const int ax = jx - k, ay = jy - k, az = jz - k;
-            if (k > 1 && max(max(abs(ax), abs(ay)), abs(az)) < k) continue;  // examined in an earlier ring
-            const int x = cx + ax, y = cy + ay, z = cz + az;
-            if (static_cast<unsigned>(x) >= static_cast<unsigned>(g.dx) || static_cast<unsigned>(y) >= static_cast<unsigned>(g.dy) ||
-                static_cast<unsigned>(z) >= static_cast<unsigned>(g.dz))
-                continue;
-            const int cell = (z * g.dy + y) * g.dx + x;
-            const int s0 = start[cell], s1 = start[cell + 1];
-            for (int t = s0; t < s1; ++t) {
-                const float4 p = sorted[t];
-                const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
-                float d = dx * dx;  // the dense sweep's arithmetic
-                d += dy * dy;
-                d += dz * dz;
-                if (d < 3.4e38f) {
-                    const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(__float_as_int(p.w));
-                    bk = key < bk ? key : bk;
+        for (int j0 = 0; j0 < ncube; j0 += 64) {  // 64 cells at a time, one per lane
+            const int j = j0 + lane;
+            int s0 = 0, cnt = 0;
+            if (j < ncube) {
+                const int jz = j / (w * w), rem = j - jz * w * w, jy = rem / w, jx = rem - jy * w;
+                const int ax = jx - k, ay = jy - k, az = jz - k;
+                const int x = cx + ax, y = cy + ay, z = cz + az;
+                const bool fresh = k == 1 || max(max(abs(ax), abs(ay)), abs(az)) == k;  // inner cells were examined in an earlier ring
+                if (fresh && static_cast<unsigned>(x) < static_cast<unsigned>(g.dx) && static_cast<unsigned>(y) < static_cast<unsigned>(g.dy) &&
+                    static_cast<unsigned>(z) < static_cast<unsigned>(g.dz)) {
+                    const int cell = (z * g.dy + y) * g.dx + x;
+                    s0 = start[cell];
+                    cnt = start[cell + 1] - s0;
+                }
+            }
+            // the points of these cells as one list spread over the lanes: candidate t belongs to the lane whose running count
+            // first exceeds t (six-step search over the inclusive scan), so a crowded cell costs no lane more than an empty one
+            const int incl = wave_inclusive_scan(cnt);
+            const int total = __shfl(incl, 63, 64);
+            const int excl = incl - cnt;
+            for (int base = 0; base < total; base += 64) {
+                const int t = base + lane;
+                int owner = 0;
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int v = __shfl(incl, owner + step - 1, 64);
+                    if (v <= t) owner += step;
+                }
+                owner = min(owner, 63);
+                const int idx = __shfl(s0, owner, 64) + (t - __shfl(excl, owner, 64));
+                if (t < total) {
+                    const float4 p = sorted[idx];
+                    const float dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+                    float d = dx * dx;  // the dense sweep's arithmetic
+                    d += dy * dy;
+                    d += dz * dz;
+                    if (d < 3.4e38f) {
+                        const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(d)) << 32) | static_cast<unsigned>(__float_as_int(p.w));
+                        bk = key < bk ? key : bk;
+                    }
                 }
             }
         }

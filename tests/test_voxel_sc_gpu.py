@@ -190,6 +190,36 @@ def test_sc_matrix_mfma(O, S):
     gm.close()
 
 
+def test_sc_matrix_mfma_real_scans(O, S, golden):
+    """Modes 1-3 of the dense matrix on descriptors of the reference's real sample scans (two sessions, keyframes downsampled at
+    0.4 m as the detector sees them, PGO :629-631), each also inserted rolled by a few sectors (a revisit with another heading):
+    every pair against the oracle's distDirectSC over the 60 shifts."""
+    vg = S.VoxelGrid()
+    gm = S.SCManager()
+    descs = []
+    for name in ["KAIST03_000000.npy", "KAIST03_000007.npy", "KAIST03_000020.npy", "Seosan01_000000.npy", "Seosan01_000011.npy"]:
+        d = gm.makeScancontext(vg.filter(golden(name), 0.4))
+        descs += [d, np.roll(d, 7 + len(descs), axis=1)]
+    for d in descs:
+        gm.saveScancontextAndKeys(d)
+    n = len(descs)
+    want_d, want_s = np.zeros((n, n)), np.zeros((n, n), np.int32)
+    for q in range(n):
+        for j in range(n):
+            full = O.sc_distance_full(descs[q], descs[j])
+            full = np.where(np.isnan(full), 1e300, full)
+            want_d[q, j], want_s[q, j] = full.min(), int(np.argmin(full))
+    for mode, tol in ((1, 1e-12), (2, 1e-12), (3, 1e-5)):
+        D, Sh = gm.distance_matrix(0, n, 0, n, mode=mode)
+        assert np.abs(D - want_d).max() <= tol, mode
+        assert np.array_equal(Sh, want_s), mode
+    # the rolled copies are found at their shift with zero distance
+    for k in range(0, n, 2):
+        assert want_d[k + 1, k] <= 1e-12 and want_s[k, k + 1] == (60 - (7 + k)) % 60
+    gm.close()
+    vg.close()
+
+
 def test_sc_sharded_equals_single(O, S):
     """Keyframe i lives on shard i % G; per-shard top-3 + merge must equal the single-context answer."""
     rng = np.random.default_rng(11)
