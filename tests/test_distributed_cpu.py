@@ -93,3 +93,66 @@ def test_sharded_sc_search_gloo_world2():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _voxel_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "sc-a-loam_amd", "python"))
+    import torch
+    import torch.distributed as dist
+    import oracle_py as O
+    from scaloam import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    for case, (n, zspan) in enumerate([(60000, 12.0), (5000, 0.3), (0, 1.0)]):
+        rng = np.random.default_rng(900 + case)  # the same whole map on every rank; rank r owns the r-th contiguous part
+        pts = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.uniform(-zspan, zspan, (n, 1)), rng.uniform(0, 1, (n, 1))], axis=1).astype(np.float32)
+        pts[: n // 3, :3] = np.round(pts[: n // 3, :3] * 2) / 2  # many points on voxel borders and in shared voxels
+        cut = [0, n // 3 + 7 if n else 0, n] if world == 2 else [0, n // 4, n // 2, n]
+        mine = pts[cut[rank]:cut[rank + 1]]
+
+        def oracle_filter(t, leaf):  # the checker stands in for the HIP filter (no GPU in this container)
+            a = t.numpy()
+            return O.voxel_grid(a, leaf)[0] if a.shape[0] else np.zeros((0, 4), np.float32)
+
+        part = sharded.sharded_downsample(torch.from_numpy(mine.copy()), 0.4, local_filter=oracle_filter)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([part.shape[0]], dtype=torch.int64))
+        mx = max(1, max(int(s.item()) for s in sizes))
+        pad = np.zeros((mx, 4), np.float32)
+        pad[: part.shape[0]] = part
+        parts = [torch.zeros((mx, 4)) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(pad))
+        got = np.concatenate([p.numpy()[: int(s.item())] for p, s in zip(parts, sizes)])
+        want = O.voxel_grid(pts, 0.4)[0] if n else np.zeros((0, 4), np.float32)
+        ok &= got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        # the exchange keeps the global order: a rank's received points are a subsequence of the whole map
+        recv, (lo, hi) = sharded.exchange_by_layer(torch.from_numpy(mine.copy()), 0.4)
+        r = recv.numpy()
+        if n:
+            k_all = np.floor(pts[:, 2] * (np.float32(1.0) / np.float32(0.4))).astype(np.int64)
+            sel = pts[(k_all >= lo) & (k_all < hi)]
+            ok &= sel.shape == r.shape and np.array_equal(sel.view(np.uint32), r.view(np.uint32))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_voxel_downsample_gloo(world):
+    """SURVEY 8e, offline map merge: the slab exchange of scaloam.sharded (all-to-all over gloo here, RCCL on a GPU node) with
+    the oracle's VoxelGrid as the local filter equals the oracle's VoxelGrid over the whole map bit for bit - balanced slabs,
+    a map thinner than one voxel layer per rank (empty slabs), an empty map."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_voxel_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, True) for r in range(world)], res
