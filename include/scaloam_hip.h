@@ -106,6 +106,9 @@ typedef struct scal_voxel scal_voxel_t;
 int scal_voxel_create(int max_points, int device, scal_voxel_t** ctx);
 void scal_voxel_destroy(scal_voxel_t* ctx);
 int scal_voxel_downsample(scal_voxel_t* ctx, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out);
+/* the same with the cloud and the output (room for n records; may not overlap the input) in device memory, e.g. between
+ * scal_mapmerge_device_points and scal_icp_align_device: loopFindNearKeyframesCloud's VoxelGrid, :491-492; waits, *n_out on the host */
+int scal_voxel_downsample_device(scal_voxel_t* ctx, const float* d_xyzi, int n, float leaf, float* d_out_xyzi, int* n_out);
 
 /* ------------------------------------------------------------------ stage D: ScanContext
  * Replaces SCManager (include/scancontext/Scancontext.h:57-123, Scancontext.cpp), call sites

@@ -393,7 +393,8 @@ extern "C" void scal_voxel_destroy(scal_voxel_t* c) {
     delete c;
 }
 
-extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out) {
+// host clouds (on_device = false) or 16-byte xyzi records already in HBM; the output goes where the input came from
+static int voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out, bool on_device) {
     if (!c || !n_out || n < 0 || (n > 0 && (!xyzi || !out_xyzi)) || !(leaf > 0.f)) {
         set_error("scal_voxel_downsample: bad argument");
         return SCAL_E_ARG;
@@ -407,12 +408,16 @@ extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, 
     std::lock_guard<std::mutex> lk(c->mu);
     SCAL_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->aos.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+    const float* d_in = xyzi;
+    if (!on_device) {
+        SCAL_HIP(hipMemcpyAsync(c->aos.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+        d_in = c->aos.p;
+    }
     SCAL_HIP(hipMemcpyAsync(c->d_n.p, &n, sizeof(int), hipMemcpyHostToDevice, s));
     SoA4 in{c->ix.p, c->iy.p, c->iz.p, c->iw.p}, o{c->ox.p, c->oy.p, c->oz.p, c->ow.p};
-    launch_deinterleave(s, c->aos.p, n, in);
+    launch_deinterleave(s, d_in, n, in);
     SCAL_TRY(c->vf.run(s, CSoA4{in.x, in.y, in.z, in.w}, c->d_n.p, n, leaf, 45, o, c->d_n.p + 1));
-    launch_interleave(s, c->d_n.p + 1, n, CSoA4{o.x, o.y, o.z, o.w}, c->aos.p);
+    launch_interleave(s, c->d_n.p + 1, n, CSoA4{o.x, o.y, o.z, o.w}, on_device ? out_xyzi : c->aos.p);
     VoxMeta hm;
     SCAL_HIP(hipMemcpyAsync(&hm, c->vf.meta.p, sizeof hm, hipMemcpyDeviceToHost, s));
     int m = 0;
@@ -422,8 +427,18 @@ extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, 
         set_error("voxel grid bounding box needs more than 45 key bits (or 16383 cells per axis on the small-cloud path)");
         return SCAL_E_CAPACITY;
     }
-    SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    if (!on_device) {
+        SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+    }
     *n_out = m;
     return SCAL_OK;
+}
+
+extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out) {
+    return voxel_downsample(c, xyzi, n, leaf, out_xyzi, n_out, false);
+}
+
+extern "C" int scal_voxel_downsample_device(scal_voxel_t* c, const float* d_xyzi, int n, float leaf, float* d_out_xyzi, int* n_out) {
+    return voxel_downsample(c, d_xyzi, n, leaf, d_out_xyzi, n_out, true);
 }

@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names",
     "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_fetch",
     "scal_features_sync",
-    "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample",
+    "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample", "scal_voxel_downsample_device",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
@@ -129,6 +129,7 @@ def lib():
     L.scal_voxel_destroy.argtypes = [vp]
     L.scal_voxel_destroy.restype = None
     L.scal_voxel_downsample.argtypes = [vp, _f32p, C.c_int, C.c_float, _f32p, _i32p]
+    L.scal_voxel_downsample_device.argtypes = [vp, vp, C.c_int, C.c_float, vp, _i32p]
     L.scal_sc_create.argtypes = [C.POINTER(SCConfig), C.POINTER(vp)]
     L.scal_sc_destroy.argtypes = [vp]
     L.scal_sc_destroy.restype = None
@@ -330,6 +331,12 @@ class VoxelGrid:
         n = C.c_int(0)
         _check(lib().scal_voxel_downsample(self.h, _p(xyzi, _f32p), xyzi.shape[0], C.c_float(leaf), _p(out, _f32p), C.byref(n)))
         return out[:n.value].copy()
+
+    def filter_device(self, d_in_ptr, n, leaf, d_out_ptr):
+        """16-byte xyzi records in device memory in, centroids to d_out_ptr (room for n records); returns their number."""
+        m = C.c_int(0)
+        _check(lib().scal_voxel_downsample_device(self.h, d_in_ptr, n, C.c_float(leaf), d_out_ptr, C.byref(m)))
+        return m.value
 
 
 # ---------------------------------------------------------------------------------------------- stage D

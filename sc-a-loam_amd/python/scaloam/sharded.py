@@ -75,9 +75,9 @@ def exchange_by_layer(points, leaf, group=None):
 
 
 def gpu_voxel_filter(device):
-    """The product's local filter: scal_mapmerge_add_batch_device (identity pose, no range gate: an exact copy) +
-    scal_mapmerge_downsample on the received device tensor."""
-    from . import MapMerge
+    """The product's local filter: scal_voxel_downsample_device on the received device tensor."""
+    import torch
+    from . import VoxelGrid
     state = {}
 
     def run(recv, leaf):
@@ -86,15 +86,15 @@ def gpu_voxel_filter(device):
         n = int(recv.shape[0])
         if n == 0:
             return np.zeros((0, 4), np.float32)
-        mm = state.get("mm")
-        if mm is None or state["cap"] < n:
-            if mm is not None:
-                mm.close()
-            mm = state["mm"] = MapMerge(max_points=n + 1024, max_frame_points=16, device=device)
-            state["cap"] = n
-        mm.reset()
-        mm.add_batch_device(recv.data_ptr(), [0, n], np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float64), -1.0)
-        return mm.downsample(leaf)
+        vg = state.get("vg")
+        if vg is None or state["cap"] < n:
+            if vg is not None:
+                vg.close()
+            vg = state["vg"] = VoxelGrid(max_points=n + 1024, device=device)
+            state["cap"] = n + 1024
+        out = torch.empty_like(recv)
+        m = vg.filter_device(recv.data_ptr(), n, leaf, out.data_ptr())
+        return out[:m].cpu().numpy()
 
     return run
 

@@ -350,6 +350,38 @@ def test_mapmerge_matches_oracle(O, S, golden):
     mm.close()
 
 
+def test_voxel_device_in_out_equals_host(S, golden):
+    """scal_voxel_downsample_device (records already in HBM, centroids left in HBM) = scal_voxel_downsample, and the chain
+    device voxel -> scal_icp_align_device = the host chain: loopFindNearKeyframesCloud's VoxelGrid + doICPVirtualRelative
+    (laserPosegraphOptimization.cpp:491-492, :518-535) without the clouds leaving the GPU."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    vg = S.VoxelGrid()
+    clouds = {}
+    for name in ("KAIST03_000000.npy", "KAIST03_000007.npy"):
+        a = np.ascontiguousarray(golden(name), np.float32)
+        want = vg.filter(a, 0.4)
+        d_in, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d_in), a.nbytes) == 0 and hip.hipMalloc(ctypes.byref(d_out), a.nbytes) == 0
+        assert hip.hipMemcpy(d_in, a.ctypes.data, a.nbytes, 1) == 0
+        m = vg.filter_device(d_in, a.shape[0], 0.4, d_out)
+        got = np.zeros((m, 4), np.float32)
+        assert hip.hipMemcpy(got.ctypes.data, d_out, got.nbytes, 2) == 0
+        assert m == want.shape[0] and np.array_equal(_bits(got), _bits(want))
+        clouds[name] = (want, d_out, m, d_in)
+    (src_h, d_src, ns, _), (tgt_h, d_tgt, nt, _) = clouds["KAIST03_000007.npy"], clouds["KAIST03_000000.npy"]
+    icp = S.LoopICP(max_source=100000, max_target=400000)
+    rh, rd = icp.align(src_h, tgt_h), icp.align_device(d_src, ns, d_tgt, nt)
+    assert np.array_equal(rh["T"], rd["T"]) and rh["fitness"] == rd["fitness"] and rh["iterations"] == rd["iterations"]
+    for _, d_out, _, d_in in clouds.values():
+        hip.hipFree(d_out), hip.hipFree(d_in)
+    icp.close()
+    vg.close()
+
+
 def test_loop_icp_matches_oracle(O, S, golden):
     """Loop-closure verification ICP (SURVEY 8f-2): the HIP path against the oracle's restatement of pcl::IterativeClosestPoint
     on real keyframes downsampled at 0.4 m as doICPVirtualRelative prepares them.  Nearest neighbours are exact on both sides;
