@@ -156,3 +156,20 @@ def test_sharded_voxel_downsample_gloo(world):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(r, True) for r in range(world)], res
+
+
+def test_balanced_cuts_properties():
+    """Slab boundaries of the sharded VoxelGrid: non-decreasing, inside [0, layers], every layer owned by exactly one rank, and
+    no rank's share above the ideal by more than the heaviest single layer (a layer is never split)."""
+    sys.path.insert(0, os.path.join(ROOT, "sc-a-loam_amd", "python"))
+    from scaloam.sharded import balanced_cuts
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        for hist in (rng.integers(0, 1000, 75), np.array([0, 0, 5, 0, 0]), np.array([7]), np.zeros(4, np.int64), rng.integers(0, 3, 200)):
+            cuts = balanced_cuts(hist, world)
+            assert len(cuts) == world - 1 and all(0 <= c <= len(hist) for c in cuts) and cuts == sorted(cuts)
+            edges = [0] + cuts + [len(hist)]
+            shares = [int(hist[edges[r]:edges[r + 1]].sum()) for r in range(world)]
+            assert sum(shares) == int(hist.sum())
+            if hist.sum():
+                assert max(shares) <= hist.sum() / world + hist.max()
