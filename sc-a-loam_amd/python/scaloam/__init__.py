@@ -436,8 +436,8 @@ class SCManager:
         return d, s
 
     def distance_matrix(self, q0, q1, d0, d1, mode=0):
-        d = np.zeros((q1 - q0, d1 - d0))
-        s = np.zeros((q1 - q0, d1 - d0), np.int32)
+        d = np.zeros((max(0, q1 - q0), max(0, d1 - d0)))  # inverted ranges are the library's to refuse
+        s = np.zeros((max(0, q1 - q0), max(0, d1 - d0)), np.int32)
         _check(lib().scal_sc_distance_matrix(self.h, q0, q1, d0, d1, mode, _p(d, _f64p), _p(s, _i32p)))
         return d, s
 

@@ -382,6 +382,40 @@ def test_voxel_device_in_out_equals_host(S, golden):
     vg.close()
 
 
+def test_new_entry_points_reject_bad_arguments(S):
+    """Error behaviour of the round's added entry points: status codes, nothing thrown across the ABI, contexts stay usable."""
+    gm = S.SCManager()
+    rng = np.random.default_rng(1)
+    for d in _random_descs(rng, 6):
+        gm.saveScancontextAndKeys(d)
+    for args in ((0, 6, 0, 6, 4), (0, 6, 0, 6, -1), (0, 7, 0, 6, 2), (3, 2, 0, 6, 2), (0, 6, -1, 6, 2)):
+        with pytest.raises(S.ScalError) as e:
+            gm.distance_matrix(*args[:4], mode=args[4])
+        assert e.value.code == S.E_ARG
+    D, _ = gm.distance_matrix(0, 6, 0, 6, mode=2)  # still works
+    assert D.shape == (6, 6) and np.abs(np.diag(D)).max() <= 1e-12
+    sharded = S.SCManager(n_shards=2, shard=0)
+    with pytest.raises(S.ScalError) as e:
+        sharded.distance_matrix(0, 0, 0, 0, mode=2)
+    assert e.value.code == S.E_ARG
+    icp = S.LoopICP(max_source=1000, max_target=1000)
+    with pytest.raises(S.ScalError) as e:
+        icp.set_search(2)
+    assert e.value.code == S.E_ARG
+    with pytest.raises(S.ScalError) as e:
+        icp.align(np.zeros((1001, 4), np.float32), np.zeros((10, 4), np.float32))
+    assert e.value.code == S.E_TOO_MANY
+    vg = S.VoxelGrid(max_points=1000)
+    with pytest.raises(S.ScalError) as e:
+        vg.filter_device(1, 1001, 0.4, 1)  # over capacity: refused before any pointer is touched
+    assert e.value.code == S.E_TOO_MANY
+    with pytest.raises(S.ScalError) as e:
+        vg.filter_device(None, 10, 0.4, None)
+    assert e.value.code == S.E_ARG
+    for x in (gm, sharded, icp, vg):
+        x.close()
+
+
 def test_loop_icp_matches_oracle(O, S, golden):
     """Loop-closure verification ICP (SURVEY 8f-2): the HIP path against the oracle's restatement of pcl::IterativeClosestPoint
     on real keyframes downsampled at 0.4 m as doICPVirtualRelative prepares them.  Nearest neighbours are exact on both sides;
