@@ -236,13 +236,19 @@ int scal_map_step(scal_map_t* ctx, const float* corner_last, int n_corner, const
 int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom,
                            double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
 /* Optional: start the pose-independent part of the next scal_map_step_features(ctx, feat, ...) - input gather and the stack
- * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately.  Up to two
- * prefetches may be queued ahead of their steps (three rotating input sets); steps consume them in order. */
+ * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately.  Up to three
+ * prefetches may be queued ahead of their steps (rotating input sets); steps consume them in order. */
 int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
-/* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns as soon as the optimised pose is on
- * the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it - the next enqueue,
- * scal_map_export and scal_map_finish wait for them (and report a capacity error of the insertion).  The map sizes in the
- * statistics of collect are those before this scan's insertion, insert_path is -1. */
+/* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns the oldest uncollected pose as soon as it
+ * is on the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it.  Up to four steps may
+ * be queued before the first is collected: transformAssociateToMap / transformUpdate (:143-153), the rolling-window decision
+ * (:313-508) and the map sizes live on the device, so a step is queued right behind the previous one with nothing read back.
+ * Such a step is speculative: it assumes the cube window of the previous step and the merge insert; when that does not hold the
+ * device stops the chain, and collect / finish redo the step on the general path (window shift, full-sort insertion) and replay
+ * the steps queued behind it - results are identical either way.  A features context handed to enqueue must not be run again
+ * before its step has been collected.  scal_map_export and scal_map_finish wait for all queued insertions (and report a
+ * capacity error of an insertion).  The map sizes in the statistics of collect are those before this scan's insertion,
+ * insert_path is -1. */
 int scal_map_enqueue_features(scal_map_t* ctx, scal_features_t* feat, const double* q_wodom, const double* t_wodom);
 int scal_map_collect(scal_map_t* ctx, double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
 int scal_map_finish(scal_map_t* ctx);
@@ -251,6 +257,12 @@ int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_
 int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);
 /* enable (default) / disable the merge insert; both give identical maps, the switch exists for tests and measurements */
 int scal_map_set_merge_insert(scal_map_t* ctx, int enable);
+/* how the steps ran so far: out4 = {queued speculatively, run on the general path, redone from the start after a stopped chain
+ * (window moved), insertion redone with the full sort after a stopped chain}; for tests and measurements */
+int scal_map_get_path_counters(scal_map_t* ctx, int* out4);
+/* 1 (default): every enqueue first looks (without waiting) whether queued steps have finished or stopped; 0: a stopped chain is
+ * only noticed by collect / finish, so that steps really get queued behind it (test switch for the replay path) */
+int scal_map_set_poll(scal_map_t* ctx, int enable);
 
 /* ------------------------------------------------------------------ stage B: scan-to-scan odometry
  * Replaces the main loop body of src/laserOdometry.cpp:267-291, :299-506, :554-568. */

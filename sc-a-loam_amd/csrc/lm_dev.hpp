@@ -399,7 +399,9 @@ struct LMSync {
 };
 
 static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
-                                                         const int* __restrict__ d_enable, double* partials, LMSync* sync) {
+                                                         const int* __restrict__ d_enable, double* partials, LMSync* sync,
+                                                         const int* __restrict__ d_abort) {
+    if (d_abort && *d_abort) return;  // uniform over the grid (written by an earlier kernel): a stopped chain leaves the state alone
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
@@ -541,10 +543,10 @@ inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* 
 
 // host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
-                            int outer) {
+                            int outer, const int* d_abort = nullptr) {
     int g = (f.cap + 255) / 256;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
-    SCAL_LAUNCH_PROF("k_lm_solve", k_lm_solve, dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync);
+    SCAL_LAUNCH_PROF("k_lm_solve", k_lm_solve, dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort);
 }
 
 }  // namespace scal

@@ -59,6 +59,20 @@ struct MapCounters {
     int merge_neff[2];                   // new points inside the cube window (merge insert)
 };
 
+// Persistent device-side state of the mapper.  The pose algebra of :143-153, the rolling-window decision of :313-508 and the
+// map sizes live here, so that a step can be queued behind the previous one without the host reading anything back.
+enum { MAP_ABORT_NONE = 0, MAP_ABORT_WINDOW = 1, MAP_ABORT_MERGE = 2 };
+struct MapState {
+    double q_wmap_wodom[4], t_wmap_wodom[3];  // :113-114
+    double q_wodom[4], t_wodom[3];            // this step's /laser_odom_to_init pose (kept for transformUpdate)
+    MapParams mp;                             // window of the current step
+    int have_mp;
+    int window_same;                          // this step's window equals the previous step's (merge insert possible)
+    int n_map[2];                             // points per class in the current map buffers
+    int abort;                                // sticky: while set, every kernel of a speculatively queued step returns at once
+    int seq;                                  // steps begun
+};
+
 __device__ __forceinline__ int pack_cube(int ai, int aj, int ak) { return (ai + 512) | ((aj + 512) << 10) | ((ak + 512) << 20); }
 __device__ __forceinline__ void unpack_cube(int p, int& ai, int& aj, int& ak) {
     ai = (p & 1023) - 512, aj = ((p >> 10) & 1023) - 512, ak = ((p >> 20) & 1023) - 512;
@@ -96,79 +110,103 @@ struct GridPts {
 };
 struct GridArgs {
     MapCloud m[2];
-    int n[2], nb0;
     int* cnt[2];
     int* rank[2];
     int* start[2];
     GridPts g[2];
 };
-__device__ __forceinline__ bool grid_part(const GridArgs& a, int& cls, int& i) {
-    int b = blockIdx.x;
-    cls = b < a.nb0 ? 0 : 1;
-    if (cls) b -= a.nb0;
-    i = b * blockDim.x + threadIdx.x;
-    return i < a.n[cls];
+// Fixed launch shape (the map sizes are device words): a quarter of the blocks walks the corner map, the rest the surf map,
+// each with a block-stride loop.  `i0` is the first point of this block's current tile, uniform over the block.
+constexpr int GRID_BLOCKS = 512;
+__device__ __forceinline__ void grid_part(int& cls, int& first, int& stride) {
+    const int nb0 = gridDim.x / 4;
+    const int b = blockIdx.x;
+    cls = b < nb0 ? 0 : 1;
+    first = (cls ? b - nb0 : b) * 256;
+    stride = (cls ? static_cast<int>(gridDim.x) - nb0 : nb0) * 256;
 }
 
-__global__ void __launch_bounds__(256) k_grid_count(GridArgs a, MapParams mp, MapCounters* C) {
+__global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* __restrict__ S, MapCounters* C) {
+    if (S->abort) return;
     __shared__ int s_valid;
     if (threadIdx.x == 0) s_valid = 0;
     __syncthreads();
-    int cls, i;
-    const bool in = grid_part(a, cls, i);
+    int cls, first, stride;
+    grid_part(cls, first, stride);
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
     const MapCloud& m = a.m[cls];
-    bool v = false;
-    if (in && cube_valid(mp, m.cube[i])) {
-        v = true;
-        a.rank[cls][i] = atomicAdd(&a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
-    } else if (in) {
-        a.rank[cls][i] = -1;
+    for (int i0 = first; i0 < n; i0 += stride) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < n;
+        bool v = false;
+        if (in && cube_valid(mp, m.cube[i])) {
+            v = true;
+            a.rank[cls][i] = atomicAdd(&a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
+        } else if (in) {
+            a.rank[cls][i] = -1;
+        }
+        // one global atomic per workgroup: a per-wave atomic on the same word was most of this kernel's time
+        const uint64_t b = __ballot(v);
+        if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
     }
-    // one global atomic per workgroup: a per-wave atomic on the same word was most of this kernel's time
-    const uint64_t b = __ballot(v);
-    if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
     __syncthreads();
     if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
 }
 
 // every non-empty cell gets a slice of the point pool: the cells' sizes are summed per workgroup (the point with rank 0
-// speaks for its cell), one cursor atomic per workgroup
-__global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, MapParams mp, MapCounters* C) {
+// speaks for its cell), one cursor atomic per workgroup and tile
+__global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, const MapState* __restrict__ S, MapCounters* C) {
+    if (S->abort) return;
     __shared__ int s_scan[17];
     __shared__ int s_base;
-    int cls, i;
-    const bool in = grid_part(a, cls, i);
+    int cls, first, stride;
+    grid_part(cls, first, stride);
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
     const MapCloud& m = a.m[cls];
-    int c = -1, mine = 0;
-    if (in && a.rank[cls][i] == 0) {
-        c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-        mine = a.cnt[cls][c];
+    for (int i0 = first; i0 < n; i0 += stride) {
+        const int i = i0 + threadIdx.x;
+        int c = -1, mine = 0;
+        if (i < n && a.rank[cls][i] == 0) {
+            c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
+            mine = a.cnt[cls][c];
+        }
+        int total = 0;
+        const int off = block_exclusive_scan(mine, s_scan, &total);
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(&C->cursor[cls], total) : 0;
+        __syncthreads();
+        if (c >= 0) a.start[cls][c] = s_base + off;
+        __syncthreads();
     }
-    int total = 0;
-    const int off = block_exclusive_scan(mine, s_scan, &total);
-    if (threadIdx.x == 0) s_base = total ? atomicAdd(&C->cursor[cls], total) : 0;
-    __syncthreads();
-    if (c >= 0) a.start[cls][c] = s_base + off;
     if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555
 }
 
-__global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, MapParams mp) {
-    int cls, i;
-    const bool in = grid_part(a, cls, i);
+__global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, const MapState* __restrict__ S) {
+    if (S->abort) return;
+    int cls, first, stride;
+    grid_part(cls, first, stride);
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
     const MapCloud& m = a.m[cls];
-    if (in && a.rank[cls][i] >= 0) {
-        const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-        const int p = a.start[cls][c] + a.rank[cls][i];
-        const GridPts& g = a.g[cls];
-        g.p[p] = make_float4(m.x[i], m.y[i], m.z[i], __int_as_float(i));
+    const GridPts& g = a.g[cls];
+    for (int i = first + threadIdx.x; i < n; i += stride) {
+        if (a.rank[cls][i] >= 0) {
+            const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
+            const int p = a.start[cls][c] + a.rank[cls][i];
+            g.p[p] = make_float4(m.x[i], m.y[i], m.z[i], __int_as_float(i));
+        }
     }
 }
 
-__global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, MapParams mp) {
-    int cls, i;
-    const bool in = grid_part(a, cls, i);
+__global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* __restrict__ S) {
+    int cls, first, stride;
+    grid_part(cls, first, stride);
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
     const MapCloud& m = a.m[cls];
-    if (in && a.rank[cls][i] >= 0) a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
+    for (int i = first + threadIdx.x; i < n; i += stride)
+        if (a.rank[cls][i] >= 0) a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------- association
@@ -393,10 +431,12 @@ struct NNBuf {
 // k_assoc_knn: one WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
 // many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
 // so it wants every lane busy with a different point).
-__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams mp, const int* __restrict__ ccnt, const int* __restrict__ cstart,
-                                                   GridPts cg, const int* __restrict__ scnt, const int* __restrict__ sstart, GridPts sg,
-                                                   const LMState* __restrict__ st, const MapCounters* __restrict__ C, NNBuf nb) {
-    if (!C->solve_on) return;
+__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const MapState* __restrict__ S, const int* __restrict__ ccnt,
+                                                   const int* __restrict__ cstart, GridPts cg, const int* __restrict__ scnt,
+                                                   const int* __restrict__ sstart, GridPts sg, const LMState* __restrict__ st,
+                                                   const MapCounters* __restrict__ C, NNBuf nb) {
+    if (S->abort || !C->solve_on) return;
+    const MapParams mp = S->mp;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
     const int n = min(nc + ns, nb.cap);
     double x7[7];
@@ -433,8 +473,9 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, MapParams
     }
 }
 
-__global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, MapCounters* C, int outer, FactorSoA f) {
-    if (!C->solve_on) return;
+__global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, const MapState* __restrict__ S, MapCounters* C, int outer,
+                                                 FactorSoA f) {
+    if (S->abort || !C->solve_on) return;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int valid = 0;
@@ -529,9 +570,11 @@ __device__ __forceinline__ unsigned long long map_key(const MapParams& mp, float
 
 // appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
 //   key layout (36 sorted bits = 4 passes): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
-__global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, int n_old, CSoA4 stack, const int* __restrict__ d_nstack, const LMState* __restrict__ st,
-                                                     MapParams mp, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
+__global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, const MapState* __restrict__ S, CSoA4 stack, const int* __restrict__ d_nstack,
+                                                     const LMState* __restrict__ st, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
                                                      int* __restrict__ vals, MapCounters* C, int cls) {
+    const MapParams mp = S->mp;
+    const int n_old = S->n_map[cls];
     const int ns = *d_nstack;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -621,7 +664,7 @@ __global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* _
 // the new points in arrival order - exactly the order the stable full sort would give), the other runs are inserted.
 // Anything unusual - old keys not strictly increasing inside a valid cube (a centroid rounded across a voxel face, a cube
 // that collected unfiltered points while it was outside the 5x5x3 window), an old point outside the window, too many new
-// points - raises MapCounters::merge_fail and the host redoes the insertion with the full sort.
+// points - raises MapCounters::merge_fail: k_merge_write then stops the chain and the host redoes the insertion with the full sort.
 constexpr int MERGE_MAX = 8192;
 constexpr int MERGE_IDX_BITS = 13;
 constexpr int MERGE_SAMPLES = 4096;  // old keys staged in LDS for the two-level lookup
@@ -629,219 +672,249 @@ constexpr int MERGE_SAMPLES = 4096;  // old keys staged in LDS for the two-level
 struct MergeNew {            // per class, MERGE_MAX entries
     float *x, *y, *z, *w;    // new points in the map frame, arrival order
     int* cube;
-    unsigned long long* key;     // their map keys
-    unsigned long long* sorted;  // (key << 13 | arrival index), ascending; entries >= n_eff are ~0
-    int* pre;                    // [MERGE_MAX + 1] inserted (unmatched) runs that start before sorted position t
+    unsigned long long* sorted;  // (key << 13 | arrival index), ascending; n_eff entries
+    int* pre;                    // inserted (unmatched) runs that start before sorted position t, counted inside t's 512-block
     int* lb;                     // run heads: number of old points in front of the run
     unsigned char* hm;           // bit 0: run head, bit 1: run joins an old point
+    int* blocktot;               // [MERGE_LOOKUP_BLOCKS] inserted runs per 512-block of sorted positions
 };
 struct MergeArgs {
     MapCloud in[2], out[2];
-    int n_old[2];
     CSoA4 stack[2];
     const int* d_ns[2];
     float inv_leaf[2];
     unsigned long long* okeys[2];  // keys of the old points
     MergeNew nw[2];
-    int nbo[2];                    // blocks over the old points
     int cap;
     int* grid_cnt[2];              // cell counters of the neighbour grid: restored to zero here (saves a launch)
     const int* grid_rank[2];
 };
+// Launch shapes (the map sizes are device words, so the old points are walked with block-stride loops):
+//   k_merge_keys   1024 threads: blocks [0, KB0) old corner points, [KB0, KB0 + KB1) old surf points, then MERGE_CHUNKS blocks
+//                  per class that sort the new keys
+//   k_merge_lookup 512 threads, MERGE_CHUNKS blocks per class
+//   k_merge_write  256 threads: blocks [0, WB0) / [WB0, WB0 + WB1) old points, then MERGE_MAX / 256 blocks per class for the new runs
+constexpr int MERGE_CHUNKS = MERGE_MAX / 512;
+constexpr int MERGE_KB0 = 24, MERGE_KB1 = 88;
+constexpr int MERGE_KEYS_GRID = MERGE_KB0 + MERGE_KB1 + 2 * MERGE_CHUNKS;
 constexpr int MERGE_NEW_BLOCKS = MERGE_MAX / 256;
+constexpr int MERGE_WB0 = 96, MERGE_WB1 = 352;
+constexpr int MERGE_WRITE_GRID = MERGE_WB0 + MERGE_WB1 + 2 * MERGE_NEW_BLOCKS;
 
 __device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >> 27) == MAP_NOMERGE; }
 
-__global__ void __launch_bounds__(256) k_merge_keys(MergeArgs a, const LMState* __restrict__ st, MapParams mp, MapCounters* C) {
+// Old points: their keys, the sortedness check, the zero invariant of the cell grid.  New points: every sorting block stages ALL
+// new keys of its class in LDS (map-frame point + key are cheap to recompute), sorts the 512-chunks in registers (one wave
+// each), then ranks the keys of ITS chunk against the other chunks with binary searches - rank = sorted position, the keys are
+// distinct because they carry the arrival index - and scatters them.  No merge network across workgroups, no second launch.
+__global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
+    if (S->abort) return;
+    extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX packed keys
+    __shared__ int s_scan[17];
+    const MapParams mp = S->mp;
     int b = blockIdx.x;
-    int cls, part;  // part 0: old points, 1: new points
-    if (b < a.nbo[0]) cls = 0, part = 0;
-    else if ((b -= a.nbo[0]) < a.nbo[1]) cls = 1, part = 0;
-    else if ((b -= a.nbo[1]) < MERGE_NEW_BLOCKS) cls = 0, part = 1;
-    else b -= MERGE_NEW_BLOCKS, cls = 1, part = 1;
-    const int i = b * 256 + threadIdx.x;
-    const MapCloud m = a.in[cls];
-    if (part == 0) {
-        if (i >= a.n_old[cls]) return;
-        const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
-        a.okeys[cls][i] = k;
-        if (a.grid_rank[cls][i] >= 0) a.grid_cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;  // zero invariant of the cell grid
-        bool bad = k == ~0ull;
-        if (i > 0) {
-            const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
-            bad |= kp > k || (kp == k && !key_nomerge(k));
+    if (b < MERGE_KB0 + MERGE_KB1) {
+        const int cls = b < MERGE_KB0 ? 0 : 1;
+        const int nblk = cls ? MERGE_KB1 : MERGE_KB0;
+        if (cls) b -= MERGE_KB0;
+        const MapCloud m = a.in[cls];
+        const int n_old = S->n_map[cls];
+        for (int i = b * 1024 + threadIdx.x; i < n_old; i += nblk * 1024) {
+            const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
+            a.okeys[cls][i] = k;
+            if (a.grid_rank[cls][i] >= 0) a.grid_cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;  // zero invariant of the cell grid
+            bool bad = k == ~0ull;
+            if (i > 0) {
+                const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
+                bad |= kp > k || (kp == k && !key_nomerge(k));
+            }
+            if (bad) C->merge_fail = 1;
         }
-        if (bad) C->merge_fail = 1;
         return;
     }
+    b -= MERGE_KB0 + MERGE_KB1;
+    const int cls = b / MERGE_CHUNKS, tile = b % MERGE_CHUNKS;
     const int ns = *a.d_ns[cls];
-    if (i == 0 && (ns > MERGE_MAX || a.n_old[cls] + ns > a.cap)) C->merge_fail = 1;
-    if (i >= min(ns, MERGE_MAX)) return;
+    const int n_new = min(ns, MERGE_MAX);
+    const int nc = (n_new + 511) >> 9;
+    if (tile == 0 && threadIdx.x == 0 && (ns > MERGE_MAX || S->n_map[cls] + ns > a.cap || !S->window_same)) C->merge_fail = 1;
+    if (tile > 0 && tile >= nc) return;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-    float sel[3];
     const CSoA4 stack = a.stack[cls];
-    associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);  // :740 / :764
-    const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
     const MergeNew nw = a.nw[cls];
-    nw.x[i] = sel[0], nw.y[i] = sel[1], nw.z[i] = sel[2], nw.w[i] = stack.w[i], nw.cube[i] = pc;
-    nw.key[i] = map_key(mp, a.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
-}
-
-// one workgroup per class: sort the new keys, find the run heads, look each head up among the old keys, count the inserts
-__global__ void __launch_bounds__(1024) k_merge_prepare(MergeArgs a, MapCounters* C) {
-    extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX keys
-    __shared__ unsigned char s_hm[MERGE_MAX];
-    __shared__ unsigned long long s_samp[MERGE_SAMPLES];
-    __shared__ int s_scan[17];
-    const int cls = blockIdx.x;
-    const MergeNew nw = a.nw[cls];
-    const int tid = threadIdx.x;
-    const int n_new = min(*a.d_ns[cls], MERGE_MAX);
-    const int n_old = a.n_old[cls];
-    const unsigned long long* okeys = a.okeys[cls];
-    const int np2 = max(512, next_pow2(n_new));
-    if (cls == 1 && tid == 0) SCAL_STAMP(26);
     int mine = 0;
-    for (int t = tid; t < np2; t += 1024) {
-        unsigned long long k = ~0ull;
-        if (t < n_new) {
-            const unsigned long long kk = nw.key[t];
-            if (kk != ~0ull) k = (kk << MERGE_IDX_BITS) | static_cast<unsigned long long>(t), ++mine;
+    for (int i = threadIdx.x; i < nc * 512; i += 1024) {
+        unsigned long long pk = ~0ull;
+        if (i < n_new) {
+            float sel[3];
+            associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);  // :740 / :764
+            const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
+            const unsigned long long k = map_key(mp, a.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
+            if (k != ~0ull) pk = (k << MERGE_IDX_BITS) | static_cast<unsigned long long>(i), ++mine;
+            if ((i >> 9) == tile) nw.x[i] = sel[0], nw.y[i] = sel[1], nw.z[i] = sel[2], nw.w[i] = stack.w[i], nw.cube[i] = pc;
         }
-        sk[t] = k;
+        sk[i] = pk;
     }
     int n_eff = 0;
     block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
-    if (cls == 1 && tid == 0) SCAL_STAMP(27);
-    block_sort_u64(sk, np2, n_new);
-    if (cls == 1 && tid == 0) SCAL_STAMP(28);
-    // heads + lookups; element t = e * 1024 + tid, so the eight binary searches of a thread advance in lock step
-    constexpr int PER = MERGE_MAX / 1024;
-    unsigned long long key[PER];
-    int lo[PER], hi[PER];
-    bool head[PER], nom[PER];
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int t = e * 1024 + tid;
-        head[e] = false, nom[e] = false, key[e] = 0, lo[e] = 0, hi[e] = 0;
-        if (t < n_eff) {
-            key[e] = sk[t] >> MERGE_IDX_BITS;
-            nom[e] = key_nomerge(key[e]);
-            head[e] = nom[e] || t == 0 || (sk[t - 1] >> MERGE_IDX_BITS) != key[e];
-            if (head[e] && !nom[e]) hi[e] = n_old;       // lower bound among the old keys
-            if (nom[e]) lo[e] = hi[e] = n_old;           // behind every old point (NOMERGE is the largest old key)
-        }
+    if (tile == 0 && threadIdx.x == 0) C->merge_neff[cls] = n_eff;
+    if (nc == 0) return;
+    const int w = wave_id();
+    if (w < nc) {
+        unsigned long long v[8];
+        chunk_load(sk, w, v);
+        wave_sort512(v);
+        chunk_store(sk, w, v);
     }
-    if (cls == 1 && tid == 0) SCAL_STAMP(29);
-    // Two-level lower bound: every `stride`-th old key is staged in LDS (one coalesced pass), the search over the samples
-    // runs at LDS latency and leaves a window of <= stride old keys for the last few global steps.
+    __syncthreads();
+    // two threads per key of this block's chunk: each searches half of the other chunks
+    const int j = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const unsigned long long key = sk[tile * 512 + j];
+    int rank = half == 0 ? j : 0;  // position inside the own chunk
+    for (int c = half; c < nc; c += 2) {
+        if (c == tile) continue;
+        const unsigned long long* ch = sk + c * 512;
+        int lo = 0, hi = 512;
+#pragma unroll
+        for (int step = 0; step < 9; ++step) {  // 512 = 2^9: lo ends as the number of entries < key
+            const int mid = (lo + hi) >> 1;
+            if (ch[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+        rank += lo;
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    if (half == 0 && key != ~0ull) nw.sorted[rank] = key;
+}
+
+// Run heads of the sorted new keys, each head looked up among the old keys, inserted runs counted per 512-block.
+// Two-level lower bound: every `stride`-th old key is staged in LDS (one pass), the search over the samples runs at LDS
+// latency and leaves a window of <= stride old keys for the last few global steps.
+__global__ void __launch_bounds__(512) k_merge_lookup(MergeArgs a, const MapState* __restrict__ S, const MapCounters* __restrict__ C) {
+    if (S->abort) return;
+    __shared__ unsigned long long s_samp[MERGE_SAMPLES];
+    __shared__ int s_scan[17];
+    const int cls = blockIdx.x / MERGE_CHUNKS, blk = blockIdx.x % MERGE_CHUNKS;
+    const MergeNew nw = a.nw[cls];
+    const int n_eff = C->merge_neff[cls];
+    if (blk * 512 >= n_eff) {
+        if (threadIdx.x == 0) nw.blocktot[blk] = 0;
+        return;
+    }
+    const int n_old = S->n_map[cls];
+    const unsigned long long* okeys = a.okeys[cls];
     int stride = 32;
     while ((n_old + stride - 1) / stride > MERGE_SAMPLES) stride <<= 1;
     const int n_samp = (n_old + stride - 1) / stride;
-    for (int j = tid; j < n_samp; j += 1024) s_samp[j] = okeys[static_cast<size_t>(j) * stride];
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        if (lo[e] < hi[e]) {  // heads that need a lookup
-            int a = 0, b = n_samp;  // number of samples < key
-            while (a < b) {
-                const int mid = (a + b) >> 1;
-                if (s_samp[mid] < key[e]) a = mid + 1;
-                else b = mid;
-            }
-            lo[e] = a > 0 ? (a - 1) * stride + 1 : 0;
-            hi[e] = min(n_old, a * stride);
-            if (lo[e] > hi[e]) lo[e] = hi[e];
-        }
-    }
-    for (int step = 0; step < 32; ++step) {
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < PER; ++e) {
-            if (lo[e] < hi[e]) {
-                const int mid = (lo[e] + hi[e]) >> 1;
-                if (okeys[mid] < key[e]) lo[e] = mid + 1;
-                else hi[e] = mid;
-                any = true;
-            }
-        }
-        if (!any) break;
-    }
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int t = e * 1024 + tid;
-        if (t < n_eff) {
-            const bool matched = head[e] && !nom[e] && lo[e] < n_old && okeys[lo[e]] == key[e];
-            s_hm[t] = (head[e] ? 1 : 0) | (matched ? 2 : 0);
-            nw.lb[t] = lo[e];
-        }
+    for (int j = threadIdx.x; j < n_samp; j += 512) s_samp[j] = okeys[static_cast<size_t>(j) * stride];
+    const int t = blk * 512 + threadIdx.x;
+    unsigned long long key = 0;
+    bool head = false, nom = false;
+    int lo = 0, hi = 0;
+    if (t < n_eff) {
+        key = nw.sorted[t] >> MERGE_IDX_BITS;
+        nom = key_nomerge(key);
+        head = nom || t == 0 || (nw.sorted[t - 1] >> MERGE_IDX_BITS) != key;
+        if (head && !nom) hi = n_old;       // lower bound among the old keys
+        if (nom) lo = hi = n_old;           // behind every old point (NOMERGE is the largest old key)
     }
     __syncthreads();
-    if (cls == 1 && tid == 0) SCAL_STAMP(30);
-    // inserted runs in front of every sorted position
-    const int c0 = min(n_eff, tid * PER), c1 = min(n_eff, c0 + PER);
-    int ins = 0;
-    for (int t = c0; t < c1; ++t) ins += (s_hm[t] & 3) == 1;
+    if (lo < hi) {
+        int x = 0, y = n_samp;  // number of samples < key
+        while (x < y) {
+            const int mid = (x + y) >> 1;
+            if (s_samp[mid] < key) x = mid + 1;
+            else y = mid;
+        }
+        lo = x > 0 ? (x - 1) * stride + 1 : 0;
+        hi = min(n_old, x * stride);
+        if (lo > hi) lo = hi;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (okeys[mid] < key) lo = mid + 1;
+            else hi = mid;
+        }
+    }
+    const bool matched = head && !nom && lo < n_old && okeys[lo] == key;
+    const int ins = (head && !matched) ? 1 : 0;
     int total = 0;
-    int run = block_exclusive_scan(ins, s_scan, &total);
-    for (int t = c0; t < c1; ++t) {
-        nw.pre[t] = run;
-        run += (s_hm[t] & 3) == 1;
-        nw.hm[t] = s_hm[t];
-        nw.sorted[t] = sk[t];
+    const int pre = block_exclusive_scan(ins, s_scan, &total);
+    if (t < n_eff) {
+        nw.hm[t] = (head ? 1 : 0) | (matched ? 2 : 0);
+        nw.lb[t] = lo;
+        nw.pre[t] = pre;
     }
-    if (cls == 1 && tid == 0) SCAL_STAMP(31);
-    if (tid == 0) {
-        nw.pre[n_eff] = total;
-        C->merge_neff[cls] = n_eff;
-        C->n_map_new[cls] = n_old + total;
-        if (n_old + total > a.cap) C->merge_fail = 1;
-    }
+    if (threadIdx.x == 0) nw.blocktot[blk] = total;
 }
 
-__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, const MapCounters* __restrict__ C) {
+// A merge that cannot be done (merge_fail, map pool full) stops the speculative chain here: nothing has been committed yet, the
+// host redoes this insertion with the full sort and replays the steps queued behind it.
+__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, MapCounters* C) {
+    if (S->abort) return;
+    if (C->merge_fail) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) S->abort = MAP_ABORT_MERGE;
+        return;
+    }
+    __shared__ int s_base[MERGE_CHUNKS + 1];
     int b = blockIdx.x;
-    int cls, part;
-    if (b < a.nbo[0]) cls = 0, part = 0;
-    else if ((b -= a.nbo[0]) < a.nbo[1]) cls = 1, part = 0;
-    else if ((b -= a.nbo[1]) < MERGE_NEW_BLOCKS) cls = 0, part = 1;
-    else b -= MERGE_NEW_BLOCKS, cls = 1, part = 1;
-    const int i = b * 256 + threadIdx.x;
+    int cls, part, nblk;
+    if (b < MERGE_WB0) cls = 0, part = 0, nblk = MERGE_WB0;
+    else if ((b -= MERGE_WB0) < MERGE_WB1) cls = 1, part = 0, nblk = MERGE_WB1;
+    else if ((b -= MERGE_WB1) < MERGE_NEW_BLOCKS) cls = 0, part = 1, nblk = MERGE_NEW_BLOCKS;
+    else b -= MERGE_NEW_BLOCKS, cls = 1, part = 1, nblk = MERGE_NEW_BLOCKS;
     const MapCloud in = a.in[cls], out = a.out[cls];
     const MergeNew nw = a.nw[cls];
     const int n_eff = C->merge_neff[cls];
-    const int n_old = a.n_old[cls];
-    if (part == 0) {
-        if (i >= n_old) return;
-        const unsigned long long k = a.okeys[cls][i];
-        int lo = 0, hi = n_eff;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((nw.sorted[mid] >> MERGE_IDX_BITS) < k) lo = mid + 1;
-            else hi = mid;
+    const int n_old = S->n_map[cls];
+    if (threadIdx.x == 0) {  // inserted runs in front of every 512-block
+        int run = 0;
+        for (int q = 0; q < MERGE_CHUNKS; ++q) {
+            s_base[q] = run;
+            run += nw.blocktot[q];
         }
-        const int o = min(i + nw.pre[lo], a.cap - 1);
-        // (0 + x) / 1: what the re-filter computes for a voxel holding this point alone
-        float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-        ax += in.x[i], ay += in.y[i], az += in.z[i], aw += in.w[i];
-        int cnt = 1;
-        if (!key_nomerge(k)) {
-            int u = lo;
-            while (u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k) {  // new points of the same voxel, arrival order
-                const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
-                ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
-                ++u, ++cnt;
-            }
-        }
-        const float c = static_cast<float>(cnt);
-        out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c, out.cube[o] = in.cube[i];
+        s_base[MERGE_CHUNKS] = run;
+    }
+    __syncthreads();
+    const int total = s_base[MERGE_CHUNKS];
+    if (n_old + total > a.cap) {  // uniform over the grid
+        if (b == 0 && part == 0 && threadIdx.x == 0) S->abort = MAP_ABORT_MERGE;
         return;
     }
+    if (b == 0 && part == 0 && threadIdx.x == 0) C->n_map_new[cls] = n_old + total;
+    auto pre_at = [&](int t) { return t < n_eff ? nw.pre[t] + s_base[t >> 9] : total; };
+    if (part == 0) {
+        for (int i = b * 256 + threadIdx.x; i < n_old; i += nblk * 256) {
+            const unsigned long long k = a.okeys[cls][i];
+            int lo = 0, hi = n_eff;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((nw.sorted[mid] >> MERGE_IDX_BITS) < k) lo = mid + 1;
+                else hi = mid;
+            }
+            const int o = i + pre_at(lo);
+            // (0 + x) / 1: what the re-filter computes for a voxel holding this point alone
+            float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+            ax += in.x[i], ay += in.y[i], az += in.z[i], aw += in.w[i];
+            int cnt = 1;
+            if (!key_nomerge(k)) {
+                int u = lo;
+                while (u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k) {  // new points of the same voxel, arrival order
+                    const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
+                    ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
+                    ++u, ++cnt;
+                }
+            }
+            const float c = static_cast<float>(cnt);
+            out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c, out.cube[o] = in.cube[i];
+        }
+        return;
+    }
+    const int i = b * 256 + threadIdx.x;
     if (i >= n_eff || (nw.hm[i] & 3) != 1) return;  // only heads of inserted runs
     const unsigned long long k = nw.sorted[i] >> MERGE_IDX_BITS;
-    const int o = min(nw.lb[i] + nw.pre[i], a.cap - 1);
+    const int o = nw.lb[i] + pre_at(i);
     float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
     int u = i;
     do {
@@ -854,7 +927,9 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, const MapCount
     out.cube[o] = nw.cube[static_cast<int>(nw.sorted[i] & (MERGE_MAX - 1))];
 }
 
-__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st, SoA4 out) {
+__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st,
+                                                         const MapState* __restrict__ S, SoA4 out) {
+    if (S->abort) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*d_n, cap)) return;
     double x7[7];
@@ -888,12 +963,124 @@ __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ le
     }
 }
 
-__global__ void __launch_bounds__(256) k_export_valid(MapCloud m, int n, MapParams mp, int* __restrict__ counter, float* __restrict__ out, int cap) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && cube_valid(mp, m.cube[i])) {
-        const int p = atomicAdd(counter, 1);
-        if (p < cap) reinterpret_cast<float4*>(out)[p] = make_float4(m.x[i], m.y[i], m.z[i], m.w[i]);
+__global__ void __launch_bounds__(256) k_export_valid(MapCloud m, const MapState* __restrict__ S, int cls, int* __restrict__ counter,
+                                                      float* __restrict__ out, int cap) {
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (cube_valid(mp, m.cube[i])) {
+            const int p = atomicAdd(counter, 1);
+            if (p < cap) reinterpret_cast<float4*>(out)[p] = make_float4(m.x[i], m.y[i], m.z[i], m.w[i]);
+        }
+}
+
+// Eigen-equivalent quaternion helpers, storage (x,y,z,w); the same code on both sides of the launch
+__host__ __device__ inline void m_qmul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__host__ __device__ inline void m_rot(const double* q, const double* v, double* o) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux, uy += uy, uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
+}
+
+struct MapPoseIn {
+    double q_wodom[4], t_wodom[3];
+};
+
+// First kernel of a step: transformAssociateToMap (:143-147) and the rolling-window decision (:313-508) on the device.
+// The pointer shuffles of :324-508 are offset updates; the slabs they clear are dropped by the next re-filter.
+// allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
+// raises the sticky abort flag instead - the host then redoes this step on the general path and replays what was queued behind.
+__global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_window_change, float inv_line, float inv_plane) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (S->abort) return;
+    double x0[7];
+    m_qmul(S->q_wmap_wodom, in.q_wodom, x0);
+    double rt[3];
+    m_rot(S->q_wmap_wodom, in.t_wodom, rt);
+    x0[4] = rt[0] + S->t_wmap_wodom[0], x0[5] = rt[1] + S->t_wmap_wodom[1], x0[6] = rt[2] + S->t_wmap_wodom[2];
+    int cenW = S->mp.cenW, cenH = S->mp.cenH, cenD = S->mp.cenD;
+    // :313-322
+    int cI = int((x0[4] + 25.0) / 50.0) + cenW, cJ = int((x0[5] + 25.0) / 50.0) + cenH, cK = int((x0[6] + 25.0) / 50.0) + cenD;
+    if (x0[4] + 25.0 < 0) cI--;
+    if (x0[5] + 25.0 < 0) cJ--;
+    if (x0[6] + 25.0 < 0) cK--;
+    while (cI < 3) cI++, cenW++;
+    while (cI >= CW - 3) cI--, cenW--;
+    while (cJ < 3) cJ++, cenH++;
+    while (cJ >= CH - 3) cJ--, cenH--;
+    while (cK < 3) cK++, cenD++;
+    while (cK >= CD - 3) cK--, cenD--;
+    MapParams mp;
+    mp.cenW = cenW, mp.cenH = cenH, mp.cenD = cenD;
+    mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
+    mp.ox = 50 * (cI - 2 - cenW) - 25, mp.oy = 50 * (cJ - 2 - cenH) - 25, mp.oz = 50 * (cK - 1 - cenD) - 25;
+    mp.inv_line = inv_line, mp.inv_plane = inv_plane;
+    const MapParams o = S->mp;
+    const bool same = S->have_mp && o.cenW == mp.cenW && o.cenH == mp.cenH && o.cenD == mp.cenD && o.cI == mp.cI && o.cJ == mp.cJ && o.cK == mp.cK;
+    if (!allow_window_change && !same) {
+        S->abort = MAP_ABORT_WINDOW;
+        return;
     }
+    S->mp = mp;
+    S->have_mp = 1;
+    S->window_same = same ? 1 : 0;
+    S->seq++;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S->q_wodom[k] = in.q_wodom[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S->t_wodom[k] = in.t_wodom[k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st->x[k] = x0[k];
+}
+
+// What the host reads per step, in pinned memory: state + counters when the pose is ready (1) and after the insertion (2)
+struct MapResult {
+    LMState st;
+    MapCounters C1, C2;
+    MapState S1, S2;
+};
+
+__device__ __forceinline__ void copy_words(void* dst, const void* src, int bytes) {
+    const unsigned* s = static_cast<const unsigned*>(src);
+    unsigned* d = static_cast<unsigned*>(dst);
+    for (int i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
+}
+
+// After the solve: transformUpdate (:149-153) on the device, then pose, statistics and state go to the host slot.
+__global__ void __launch_bounds__(256) k_map_pose_done(MapState* S, const LMState* st, const MapCounters* C, MapResult* host) {
+    if (threadIdx.x == 0 && !S->abort) {
+        // q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
+        const double* q_wodom = S->q_wodom;
+        const double* xf = st->x;
+        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
+        const double qi[4] = {-q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2};
+        double qn[4];
+        m_qmul(xf, qi, qn);
+        double r2[3];
+        m_rot(qn, S->t_wodom, r2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) S->q_wmap_wodom[i] = qn[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) S->t_wmap_wodom[i] = xf[4 + i] - r2[i];
+    }
+    __syncthreads();
+    copy_words(&host->st, st, sizeof(LMState));
+    copy_words(&host->C1, C, sizeof(MapCounters));
+    copy_words(&host->S1, S, sizeof(MapState));
+}
+
+// End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
+__global__ void __launch_bounds__(256) k_map_end(MapState* S, const MapCounters* C, MapResult* host) {
+    if (threadIdx.x == 0 && !S->abort) S->n_map[0] = C->n_map_new[0], S->n_map[1] = C->n_map_new[1];
+    __syncthreads();
+    copy_words(&host->C2, C, sizeof(MapCounters));
+    copy_words(&host->S2, S, sizeof(MapState));
 }
 
 struct SoAStore {
@@ -912,8 +1099,7 @@ struct SoAStore {
 struct MapStore {
     SoAStore pts[2];  // double buffered
     DevBuf<int> cube[2];
-    int cur = 0;
-    int n = 0;  // host copy of the point count
+    int n = 0;  // host mirror of the point count (valid after scal_map_finish)
     MapCloud cloud(int b) { return MapCloud{pts[b].x.p, pts[b].y.p, pts[b].z.p, pts[b].w.p, cube[b].p}; }
 };
 
@@ -927,47 +1113,64 @@ SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
 }  // namespace scal
 
 using namespace scal;
+#include <deque>
+
+// A step in flight.  Steps are queued speculatively ("fast": merge insert, window unchanged, nothing read back) behind each other;
+// a step that meets a case the fast chain does not cover stops the chain on the device (MapState::abort) and is redone by
+// the host on the general path, after which the steps queued behind it are replayed.
+struct MapStep {
+    scal_features_t* feat = nullptr;  // null: inputs came from host arrays
+    MapPoseIn pose{};
+    int set = 0;          // input set (corner_in / surf_in / stacks / counters)
+    int slot = 0;         // result slot + events
+    int par = 0;          // map buffer parity before this step's insertion
+    bool prefetched = false, have_full = false, fast = false;
+    bool pose_collected = false;  // the caller has the pose
+    bool confirmed = false;       // the insertion is known to have completed; a step leaves the queue when both hold
+    int n_corner_bound = 0, n_surf_bound = 0;
+    int insert_path = 0;
+};
 
 struct scal_map {
     scal_map_config cfg;
     int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // side stream for scal_map_prefetch_features (lazily acquired)
-    hipEvent_t ev = nullptr;
-    // prefetches queued ahead of their step (at most two: the bench queues scan k+1's before scan k's step starts)
-    static constexpr int NSETS = 3;
+    static constexpr int NSETS = 8;      // input sets: steps in flight (<= MAX_STEPS) + prefetches queued ahead (<= MAX_PF) + 1
+    static constexpr int MAX_STEPS = 4;  // steps whose insertion has not been confirmed
+    static constexpr int MAX_PF = 3;
+    static constexpr int NSLOTS = MAX_STEPS + 1;
     struct Prefetch {
         scal_features_t* feat;
         int set;
     };
     std::mutex pf_mu;  // prefetches may come from a second host thread
-    Prefetch pf[2];
+    Prefetch pf[MAX_PF];
     int n_pf = 0;
+    int next_set = 0;  // ring allocation of input sets
     hipEvent_t ev_pre[NSETS] = {};
-    // asynchronous step: pose first (ev_pose), insertion + registration behind it (ev_done)
-    hipEvent_t ev_pose = nullptr, ev_done = nullptr;
-    bool pose_pending = false, insert_pending = false, insert_try_merge = false, pending_prefetched = false;
-    double pend_q_wodom[4] = {0, 0, 0, 1}, pend_t_wodom[3] = {0, 0, 0};
-    MapParams pend_mp{};
-    int deferred_error = SCAL_OK;
+    std::deque<MapStep> steps;
+    hipEvent_t ev_pose[NSLOTS] = {}, ev_done[NSLOTS] = {};
+    int next_slot = 0;
+    PinBuf<MapResult> res;
+    int n_fast = 0, n_general = 0, n_recover_pose = 0, n_recover_insert = 0;  // scal_map_get_path_counters
+    bool poll_on_enqueue = true;  // scal_map_set_poll
+    int cur = 0;                // parity of the map buffers once every queued step has been inserted
+    bool initialised = false;   // at least one step went through the general path
     int scan_cap = 0, map_cap = 0, slot_cap = 0;
-    // host-side pose state (laserMapping.cpp:110-120)
+    // host mirrors (laserMapping.cpp:110-120), refreshed when a pose is collected
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};
-    int cenW = 10, cenH = 10, cenD = 5;  // :74-76
-    MapParams last_mp{};
     bool have_mp = false;
     // device
+    DevBuf<MapState> d_S;
     DevBuf<float> aos;  // upload staging
-    // Per-step inputs live in a ring of three "sets": the side stream may gather + downsample scans k+1 and k+2 while scan k's
-    // association and insertion still read theirs; a step takes the set its prefetch filled (or the next free one).
-    int set = 0;
     SoAStore corner_in2[NSETS], surf_in2[NSETS], corner_stack2[NSETS], surf_stack2[NSETS];
     SoAStore full_in, full_out;
-    SoAStore& corner_in(int st = -1) { return corner_in2[st < 0 ? set : st]; }
-    SoAStore& surf_in(int st = -1) { return surf_in2[st < 0 ? set : st]; }
-    SoAStore& corner_stack(int st = -1) { return corner_stack2[st < 0 ? set : st]; }
-    SoAStore& surf_stack(int st = -1) { return surf_stack2[st < 0 ? set : st]; }
-    VoxelFilter vf;
+    SoAStore& corner_in(int st) { return corner_in2[st]; }
+    SoAStore& surf_in(int st) { return surf_in2[st]; }
+    SoAStore& corner_stack(int st) { return corner_stack2[st]; }
+    SoAStore& surf_stack(int st) { return surf_stack2[st]; }
+    VoxelFilter vf, vf_side;  // main stream / prefetch stream: no shared scratch
     MapStore map[2];  // corner, surf
     GridStore grid[2];
     RadixSort sorter;
@@ -977,11 +1180,11 @@ struct scal_map {
     bool merge_insert = true;
     int last_insert_path = 0;  // 0 full sort, 1 merge
     SoAStore mnew[2];
-    DevBuf<int> mcube[2], mpre[2], mlb[2];
-    DevBuf<unsigned long long> mkey[2], msorted[2];
+    DevBuf<int> mcube[2], mpre[2], mlb[2], mblocktot[2];
+    DevBuf<unsigned long long> msorted[2];
     DevBuf<unsigned char> mhm[2];
     MergeNew merge_new(int k) {
-        return MergeNew{mnew[k].x.p, mnew[k].y.p, mnew[k].z.p, mnew[k].w.p, mcube[k].p, mkey[k].p, msorted[k].p, mpre[k].p, mlb[k].p, mhm[k].p};
+        return MergeNew{mnew[k].x.p, mnew[k].y.p, mnew[k].z.p, mnew[k].w.p, mcube[k].p, msorted[k].p, mpre[k].p, mlb[k].p, mhm[k].p, mblocktot[k].p};
     }
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
@@ -990,14 +1193,17 @@ struct scal_map {
     NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
     DevBuf<MapCounters> d_C2[NSETS];
-    DevBuf<MapCounters>& d_C(int st = -1) { return d_C2[st < 0 ? set : st]; }
-    DevBuf<double> d_x0;
+    DevBuf<MapCounters>& d_C(int st) { return d_C2[st]; }
     DevBuf<int> d_nfull;
-    PinBuf<MapCounters> h_C, h_C1;  // counters at the end of the step / when the pose is ready
+    PinBuf<MapCounters> h_C;
+    PinBuf<MapState> h_S;
     PinBuf<int> h_misc;
-    PinBuf<double> h_x0;
-    PinBuf<LMState> h_st;
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
+    int alloc_set() {
+        const int st = next_set;
+        next_set = (next_set + 1) % NSETS;
+        return st;
+    }
 };
 
 extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
@@ -1026,6 +1232,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     }
     A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
     A(c->vf.init(c->scan_cap));
+    A(c->vf_side.init(c->scan_cap));
     for (int k = 0; k < 2; ++k) {
         for (int b = 0; b < 2; ++b) {
             A(c->map[k].pts[b].alloc(mc));
@@ -1038,22 +1245,31 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
     for (int k = 0; k < 2; ++k) {
         A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
-        A(c->mkey[k].alloc(MERGE_MAX)); A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX));
+        A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX)); A(c->mblocktot[k].alloc(MERGE_CHUNKS));
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
     A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
     A(c->lm_sync.alloc(1));
-    if (rc == SCAL_OK && hipMemset(c->lm_sync.p, 0, sizeof(LMSync)) != hipSuccess) rc = SCAL_E_HIP;
-    A(c->d_st.alloc(1)); A(c->d_x0.alloc(8)); A(c->d_nfull.alloc(4)); A(c->h_C1.alloc(1));
-    A(c->h_C.alloc(1)); A(c->h_st.alloc(1)); A(c->h_misc.alloc(4)); A(c->h_x0.alloc(8));
+    A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4));
+    A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     c->lane = stage_lane(STAGE_MAP);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
-    if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+    for (int k = 0; k < scal_map::NSLOTS && rc == SCAL_OK; ++k) {
+        if (hipEventCreateWithFlags(&c->ev_pose[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+    }
     if (rc == SCAL_OK) {
-        // the cell counters obey a zero invariant: every step clears exactly the cells it touched
+        // Everything is initialised on the context's own stream (the legacy null stream is not ordered against it).
+        // The cell counters obey a zero invariant: every step clears exactly the cells it touched.
         for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cnt.zero(c->stream);
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        MapState& H = *c->h_S.p;
+        std::memset(&H, 0, sizeof H);
+        H.q_wmap_wodom[3] = 1.0;
+        H.mp.cenW = 10, H.mp.cenH = 10, H.mp.cenD = 5;  // :74-76
+        if (rc == SCAL_OK && hipMemcpyAsync(c->d_S.p, c->h_S.p, sizeof(MapState), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
     if (rc != SCAL_OK) {
@@ -1076,288 +1292,402 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
         (void)hipStreamSynchronize(c->side);
         release_stream(c->cfg.device, 2);
     }
-    if (c->ev) (void)hipEventDestroy(c->ev);
     for (int k = 0; k < scal_map::NSETS; ++k)
         if (c->ev_pre[k]) (void)hipEventDestroy(c->ev_pre[k]);
-    if (c->ev_pose) (void)hipEventDestroy(c->ev_pose);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (int k = 0; k < scal_map::NSLOTS; ++k) {
+        if (c->ev_pose[k]) (void)hipEventDestroy(c->ev_pose[k]);
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    }
     delete c;
 }
 
 namespace {
 
-// Eigen-equivalent host quaternion helpers, storage (x,y,z,w)
-void h_qmul(const double* a, const double* b, double* o) {
-    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-}
-void h_rot(const double* q, const double* v, double* o) {
-    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
-    ux += ux, uy += uy, uz += uz;
-    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
-    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
-}
-
 // stack downsample (:543-551) of corner_in / surf_in into corner_stack / surf_stack; independent of the pose
-static int enqueue_stack_filters(scal_map* c, hipStream_t s, int n_corner_bound, int n_surf_bound, int st) {
+int enqueue_stack_filters(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_corner_bound, int n_surf_bound, int st) {
     MapCounters* C = c->d_C(st).p;
-    SCAL_TRY(c->vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack(st).v(), &C->n_corner_stack));
+    SCAL_TRY(vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack(st).v(), &C->n_corner_stack));
     if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
         // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
-        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, c->vf.meta.p, C);
+        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, vf.meta.p, C);
     }
-    SCAL_TRY(c->vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack(st).v(), &C->n_surf_stack));
-    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, c->vf.meta.p, C, c->slot_cap);
+    SCAL_TRY(vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack(st).v(), &C->n_surf_stack));
+    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, vf.meta.p, C, c->slot_cap);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
-// insert + re-filter (:738-802) by a full stable sort of the pool
-static int insert_full_sort(scal_map* c, const MapParams& mp) {
+GridArgs grid_args(scal_map* c, int par) {
+    GridArgs ga;
+    for (int k = 0; k < 2; ++k) {
+        GridStore& G = c->grid[k];
+        ga.m[k] = c->map[k].cloud(par);
+        ga.cnt[k] = G.cnt.p, ga.rank[k] = G.rank.p, ga.start[k] = G.start.p, ga.g[k] = G.pts();
+    }
+    return ga;
+}
+
+// insert + re-filter (:738-802) by a full stable sort of the pool; general path only: n_map[] = host copy of the map sizes
+int insert_full_sort(scal_map* c, const MapStep& e, const int* n_map) {
     hipStream_t s = c->stream;
-    MapCounters* C = c->d_C().p;
+    MapCounters* C = c->d_C(e.set).p;
     LMState* st = c->d_st.p;
     for (int k = 0; k < 2; ++k) {
         MapStore& M = c->map[k];
-        const int n_tot_max = std::min(c->map_cap, M.n + c->scan_cap);
+        const int n_tot_max = std::min(c->map_cap, n_map[k] + c->scan_cap);
         const int nb = std::max(1, div_up(n_tot_max, 256));
-        MapCloud in = M.cloud(M.cur), outc = M.cloud(M.cur ^ 1);
-        const CSoA4 stack = k == 0 ? c->corner_stack().cv() : c->surf_stack().cv();
+        MapCloud in = M.cloud(e.par), outc = M.cloud(e.par ^ 1);
+        const CSoA4 stack = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
         const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, M.n, stack, d_ns, st, mp, k == 0 ? mp.inv_line : mp.inv_plane, c->map_cap,
-                           c->keys.p, c->vals.p, C, k);
+        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, c->d_S.p, stack, d_ns, st, 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res),
+                           c->map_cap, c->keys.p, c->vals.p, C, k);
         SortedPairs sp;
         SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
         hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
         launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
         hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
     }
+    SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
-// waits for the insertion of the previous step (if any), redoes it with the full sort when the merge gave up, and publishes
-// the new map sizes.  Every entry point that touches the map calls this first.
-static int map_finish(scal_map* c) {
-    if (!c->insert_pending) return SCAL_OK;
-    c->insert_pending = false;
+// merge insert of the step's stack points (k_merge_*): no host-side sizes, stops the chain (MapState::abort) if it cannot be done
+int launch_insert_merge(scal_map* c, const MapStep& e) {
     hipStream_t s = c->stream;
-    SCAL_HIP(hipEventSynchronize(c->ev_done));
-    c->last_insert_path = c->insert_try_merge ? 1 : 0;
-    if (c->insert_try_merge && c->h_C.p->merge_fail && !c->h_C.p->error) {  // a case the merge does not cover: redo with the full sort
-        SCAL_TRY(insert_full_sort(c, c->pend_mp));
-        SCAL_HIP(hipGetLastError());
-        SCAL_HIP(hipMemcpyAsync(c->h_C.p, c->d_C().p, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
-        c->last_insert_path = 0;
-    }
-    for (int k = 0; k < 2; ++k) c->map[k].cur ^= 1;
-    const MapCounters& H = *c->h_C.p;
-    for (int k = 0; k < 2; ++k) c->map[k].n = H.n_map_new[k];
-    if (H.error) {
-        set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
-        return H.error;
-    }
-    return SCAL_OK;
-}
-
-// Enqueues one process() pass: everything after the inputs sit in corner_in / surf_in (/ full_in) with their counts in d_C.
-// ev_pose fires when the optimised pose has reached the host buffers, ev_done after insertion + registration.
-static int map_enqueue(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full,
-                       int n_corner_bound, int n_surf_bound, bool filters_done) {
-    SCAL_TRY(map_finish(c));
-    if (c->pose_pending) {
-        set_error("scal_map: the pose of the previous step has not been collected");
-        return SCAL_E_STATE;
-    }
-    if (!c->ev_pose) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pose, hipEventDisableTiming));
-    if (!c->ev_done) SCAL_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-    for (int i = 0; i < 4; ++i) c->pend_q_wodom[i] = q_wodom[i];
-    for (int i = 0; i < 3; ++i) c->pend_t_wodom[i] = t_wodom[i];
-    hipStream_t s = c->stream;
-    // transformAssociateToMap (:143-147)
-    double x0[8] = {0};
-    h_qmul(c->q_wmap_wodom, q_wodom, x0);
-    double rt[3];
-    h_rot(c->q_wmap_wodom, t_wodom, rt);
-    x0[4] = rt[0] + c->t_wmap_wodom[0], x0[5] = rt[1] + c->t_wmap_wodom[1], x0[6] = rt[2] + c->t_wmap_wodom[2];
-    // :313-322
-    int cI = int((x0[4] + 25.0) / 50.0) + c->cenW, cJ = int((x0[5] + 25.0) / 50.0) + c->cenH, cK = int((x0[6] + 25.0) / 50.0) + c->cenD;
-    if (x0[4] + 25.0 < 0) cI--;
-    if (x0[5] + 25.0 < 0) cJ--;
-    if (x0[6] + 25.0 < 0) cK--;
-    // :324-508 — the pointer shuffles become offset updates; the cleared slabs are dropped by k_insert_keys
-    while (cI < 3) cI++, c->cenW++;
-    while (cI >= CW - 3) cI--, c->cenW--;
-    while (cJ < 3) cJ++, c->cenH++;
-    while (cJ >= CH - 3) cJ--, c->cenH--;
-    while (cK < 3) cK++, c->cenD++;
-    while (cK >= CD - 3) cK--, c->cenD--;
-    MapParams mp;
-    mp.cenW = c->cenW, mp.cenH = c->cenH, mp.cenD = c->cenD;
-    mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
-    mp.ox = 50 * (cI - 2 - c->cenW) - 25, mp.oy = 50 * (cJ - 2 - c->cenH) - 25, mp.oz = 50 * (cK - 1 - c->cenD) - 25;
-    mp.inv_line = 1.0f / c->cfg.line_res, mp.inv_plane = 1.0f / c->cfg.plane_res;
-    const bool window_same = c->have_mp && c->last_mp.cenW == mp.cenW && c->last_mp.cenH == mp.cenH && c->last_mp.cenD == mp.cenD &&
-                             c->last_mp.cI == mp.cI && c->last_mp.cJ == mp.cJ && c->last_mp.cK == mp.cK;
-    c->last_mp = mp;
-    c->have_mp = true;
-
-    MapCounters* C = c->d_C().p;
-    LMState* st = c->d_st.p;
-    for (int i = 0; i < 7; ++i) c->h_x0.p[i] = x0[i];
-    SCAL_HIP(hipMemcpyAsync(st->x, c->h_x0.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));  // LMState::x is the first member
-
-    if (!filters_done) SCAL_TRY(enqueue_stack_filters(c, s, n_corner_bound, n_surf_bound, c->set));
-
-    // cell grids over the valid cubes (both classes per launch)
-    GridArgs ga;
+    MapCounters* C = c->d_C(e.set).p;
+    MergeArgs a;
     for (int k = 0; k < 2; ++k) {
         MapStore& M = c->map[k];
-        GridStore& G = c->grid[k];
-        ga.m[k] = M.cloud(M.cur), ga.n[k] = M.n;
-        ga.cnt[k] = G.cnt.p, ga.rank[k] = G.rank.p, ga.start[k] = G.start.p, ga.g[k] = G.pts();
+        a.in[k] = M.cloud(e.par), a.out[k] = M.cloud(e.par ^ 1);
+        a.stack[k] = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
+        a.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        a.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
+        a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
+        a.nw[k] = c->merge_new(k);
+        a.grid_cnt[k] = c->grid[k].cnt.p, a.grid_rank[k] = c->grid[k].rank.p;
     }
-    ga.nb0 = std::max(1, div_up(c->map[0].n, 256));
-    const int grid_blocks = ga.nb0 + std::max(1, div_up(c->map[1].n, 256));
-    hipLaunchKernelGGL(k_grid_count, dim3(grid_blocks), dim3(256), 0, s, ga, mp, C);
-    hipLaunchKernelGGL(k_grid_alloc, dim3(grid_blocks), dim3(256), 0, s, ga, mp, C);
-    hipLaunchKernelGGL(k_grid_fill, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
+    a.cap = c->map_cap;
+    static bool attr_set = false;
+    const int lds = sizeof(unsigned long long) * MERGE_MAX;
+    if (!attr_set) {
+        SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_keys), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
+    hipLaunchKernelGGL(k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
+    hipLaunchKernelGGL(k_merge_write, dim3(MERGE_WRITE_GRID), dim3(256), 0, s, a, c->d_S.p, C);
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
+// registration of the full-resolution cloud (:845-849), commit of the new map sizes, counters to the host; fires ev_done
+int launch_tail(scal_map* c, const MapStep& e) {
+    hipStream_t s = c->stream;
+    if (e.have_full) {
+        const int nb = std::max(1, div_up(c->scan_cap, 256));
+        if (e.feat) {
+            FeatDeviceView v = features_view(e.feat);
+            hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->scan_cap, c->d_st.p, c->d_S.p,
+                               c->full_out.v());
+        } else {
+            hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, c->scan_cap, c->d_st.p, c->d_S.p,
+                               c->full_out.v());
+        }
+    }
+    hipLaunchKernelGGL(k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipEventRecord(c->ev_done[e.slot], s));
+    if (e.feat) SCAL_TRY(features_note_reader(e.feat, s));  // the registration transform reads the full-resolution cloud last
+    return SCAL_OK;
+}
+
+// Everything of a step up to the pose: inputs (unless prefetched), k_map_begin, cell grids, 2 x (association + solve), transformUpdate.
+// ev_pose fires when pose and statistics have reached the host slot.
+int launch_pose_part(scal_map* c, const MapStep& e) {
+    hipStream_t s = c->stream;
+    const int st_ = e.set;
+    MapCounters* C = c->d_C(st_).p;
+    LMState* st = c->d_st.p;
+    MapState* S = c->d_S.p;
+    if (e.feat) {
+        if (e.prefetched) {
+            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled on the side stream
+        } else {
+            FeatDeviceView v = features_view(e.feat);
+            SCAL_TRY(features_wait_done(e.feat, s));
+            const int nbc = std::max(1, div_up(e.n_corner_bound, 256));
+            hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
+                               CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st_).v(), c->surf_in(st_).v(), C, c->scan_cap, nbc);
+        }
+    }
+    hipLaunchKernelGGL(k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res);
+    if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_));
+    // cell grids over the valid cubes (both classes per launch)
+    const GridArgs ga = grid_args(c, e.par);
+    hipLaunchKernelGGL(k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+    hipLaunchKernelGGL(k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+    hipLaunchKernelGGL(k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
     // two outer iterations (:563)
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(2048, div_up(c->slot_cap, 4)));
     for (int outer = 0; outer < 2; ++outer) {
         {
-            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack().cv(), c->surf_stack().cv(), mp, c->grid[0].cnt.p,
-                               c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C, c->nnbuf());
+            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
+                             c->grid[0].cnt.p, c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C,
+                             c->nnbuf());
         }
         {
-            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack().cv(), c->surf_stack().cv(), c->nnbuf(),
-                               C, outer, F);
+            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack(st_).cv(),
+                             c->surf_stack(st_).cv(), c->nnbuf(), S, C, outer, F);
         }
-        {
-                        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer);
-        }
+        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort);
     }
-    // the pose and the statistics known so far go to the host now; the map update follows behind
+    hipLaunchKernelGGL(k_map_pose_done, dim3(1), dim3(256), 0, s, S, st, C, c->res.p + e.slot);
     SCAL_HIP(hipGetLastError());
-    launch_publish(s, st, c->h_st.p, C, c->h_C1.p);
-    SCAL_HIP(hipEventRecord(c->ev_pose, s));
-    c->pose_pending = true;
-    // insert + re-filter (:738-802)
-    const bool try_merge = c->merge_insert && window_same && c->map[0].n + MERGE_MAX <= c->map_cap && c->map[1].n + MERGE_MAX <= c->map_cap;
-    // restore the zero invariant of the cell counters (the merge insert does it in its key kernel)
-    if (!try_merge) hipLaunchKernelGGL(k_grid_clear, dim3(grid_blocks), dim3(256), 0, s, ga, mp);
-    if (try_merge) {
-        MergeArgs a;
-        for (int k = 0; k < 2; ++k) {
-            MapStore& M = c->map[k];
-            a.in[k] = M.cloud(M.cur), a.out[k] = M.cloud(M.cur ^ 1);
-            a.n_old[k] = M.n;
-            a.stack[k] = k == 0 ? c->corner_stack().cv() : c->surf_stack().cv();
-            a.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-            a.inv_leaf[k] = k == 0 ? mp.inv_line : mp.inv_plane;
-            a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
-            a.nw[k] = c->merge_new(k);
-            a.nbo[k] = std::max(1, div_up(M.n, 256));
-            a.grid_cnt[k] = c->grid[k].cnt.p, a.grid_rank[k] = c->grid[k].rank.p;
-        }
-        a.cap = c->map_cap;
-        const int grid = a.nbo[0] + a.nbo[1] + 2 * MERGE_NEW_BLOCKS;
-        static bool attr_set = false;
-        const int lds = sizeof(unsigned long long) * MERGE_MAX;
-        if (!attr_set) {
-            SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_prepare), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_merge_keys, dim3(grid), dim3(256), 0, s, a, st, mp, C);
-        hipLaunchKernelGGL(k_merge_prepare, dim3(2), dim3(1024), lds, s, a, C);
-        hipLaunchKernelGGL(k_merge_write, dim3(grid), dim3(256), 0, s, a, C);
-    } else {
-        SCAL_TRY(insert_full_sort(c, mp));
-    }
-    if (have_full) {
-        const int nb = std::max(1, div_up(c->scan_cap, 256));
-        hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, full_view, d_n_full, c->scan_cap, st, c->full_out.v());
-    }
-    launch_publish(s, C, c->h_C.p, static_cast<const MapCounters*>(nullptr), static_cast<MapCounters*>(nullptr));
-    SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_done, s));
-    c->insert_pending = true, c->insert_try_merge = try_merge, c->pend_mp = mp;
+    SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
     return SCAL_OK;
 }
 
-// waits for the pose of the enqueued step; map sizes in `stats` are those before this step's insertion (insert_path = -1)
-static int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* stats) {
-    if (!c->pose_pending) {
+int report_device_error(scal_map* c, int err) {
+    set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
+    return err;
+}
+
+// General path, synchronous: the window may move, the insertion falls back to the full sort.  All earlier steps have finished.
+int run_general(scal_map* c, MapStep& e) {
+    hipStream_t s = c->stream;
+    e.fast = false;
+    e.par = c->cur;
+    c->n_general++;
+    SCAL_TRY(launch_pose_part(c, e));
+    SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    const MapResult& R = c->res.p[e.slot];
+    if (R.C1.error) return report_device_error(c, R.C1.error);
+    const int n_map[2] = {R.S1.n_map[0], R.S1.n_map[1]};
+    bool try_merge = c->merge_insert && R.S1.window_same && n_map[0] + MERGE_MAX <= c->map_cap && n_map[1] + MERGE_MAX <= c->map_cap;
+    MapCounters* C = c->d_C(e.set).p;
+    e.insert_path = 1;
+    if (try_merge) {
+        SCAL_TRY(launch_insert_merge(c, e));
+        hipLaunchKernelGGL(k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
+        SCAL_HIP(hipStreamSynchronize(s));
+        if (R.S2.abort) {  // a case the merge does not cover: redo with the full sort
+            SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+            try_merge = false;
+        } else if (R.C2.error) {
+            return report_device_error(c, R.C2.error);
+        }
+    } else {
+        // restore the zero invariant of the cell counters (the merge insert does it in its key kernel)
+        hipLaunchKernelGGL(k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+    }
+    if (!try_merge) {
+        e.insert_path = 0;
+        SCAL_TRY(insert_full_sort(c, e, n_map));
+    }
+    SCAL_TRY(launch_tail(c, e));
+    SCAL_HIP(hipEventSynchronize(c->ev_done[e.slot]));
+    if (R.C2.error) return report_device_error(c, R.C2.error);
+    c->cur = e.par ^ 1;
+    c->initialised = true;
+    return SCAL_OK;
+}
+
+// queues a step on the speculative chain: nothing is read back, the next step can be queued right behind
+int launch_fast(scal_map* c, MapStep& e) {
+    e.fast = true;
+    e.par = c->cur;
+    e.insert_path = 1;
+    c->n_fast++;
+    SCAL_TRY(launch_pose_part(c, e));
+    SCAL_TRY(launch_insert_merge(c, e));
+    SCAL_TRY(launch_tail(c, e));
+    c->cur = e.par ^ 1;
+    return SCAL_OK;
+}
+
+void confirm(scal_map* c, MapStep& e) {
+    const MapResult& R = c->res.p[e.slot];
+    for (int k = 0; k < 2; ++k) c->map[k].n = R.S2.n_map[k];
+    c->last_insert_path = e.insert_path;
+    e.confirmed = true;
+}
+void pop_done(scal_map* c) {
+    while (!c->steps.empty() && c->steps.front().confirmed && c->steps.front().pose_collected) c->steps.pop_front();
+}
+
+// The speculative chain stopped on the device.  Everything queued has drained as no-ops behind the stop; the step that raised the
+// flag is redone on the general path (from its start, or only its insertion), the steps behind it are queued again.
+int recover(scal_map* c) {
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipStreamSynchronize(s));
+    size_t origin = c->steps.size();
+    bool at_pose = false;
+    for (size_t i = 0; i < c->steps.size(); ++i) {
+        MapStep& e = c->steps[i];
+        if (e.confirmed) continue;
+        const MapResult& R = c->res.p[e.slot];
+        if (R.S1.abort) { origin = i, at_pose = true; break; }
+        if (R.S2.abort) { origin = i, at_pose = false; break; }
+        if (R.C2.error) return report_device_error(c, R.C2.error);
+        confirm(c, e);  // in front of the stop: completed
+    }
+    if (origin == c->steps.size()) return SCAL_OK;  // nothing stopped
+    SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+    MapStep& e = c->steps[origin];
+    c->cur = e.par;
+    if (at_pose) {
+        c->n_recover_pose++;
+        SCAL_TRY(run_general(c, e));
+    } else {
+        c->n_recover_insert++;  // the pose of this step stands; only its insertion is redone, with the full sort
+        const MapResult& R = c->res.p[e.slot];
+        const int n_map[2] = {R.S2.n_map[0], R.S2.n_map[1]};  // not committed: still the sizes before the insertion
+        e.fast = false, e.insert_path = 0;
+        SCAL_TRY(insert_full_sort(c, e, n_map));
+        SCAL_TRY(launch_tail(c, e));
+        SCAL_HIP(hipEventSynchronize(c->ev_done[e.slot]));
+        if (R.C2.error) return report_device_error(c, R.C2.error);
+        c->cur = e.par ^ 1;
+    }
+    confirm(c, e);
+    for (size_t i = origin + 1; i < c->steps.size(); ++i) SCAL_TRY(launch_fast(c, c->steps[i]));
+    return SCAL_OK;
+}
+
+// confirms the insertions of the queued steps in order; wait = false: only those that have already finished
+int confirm_steps(scal_map* c, bool wait) {
+    for (size_t i = 0; i < c->steps.size(); ++i) {
+        if (c->steps[i].confirmed) continue;
+        const int slot = c->steps[i].slot;
+        if (wait) {
+            SCAL_HIP(hipEventSynchronize(c->ev_done[slot]));
+        } else if (hipEventQuery(c->ev_done[slot]) != hipSuccess) {
+            break;
+        }
+        const MapResult& R = c->res.p[slot];
+        if (R.S1.abort || R.S2.abort) {
+            SCAL_TRY(recover(c));  // confirms at least this step
+            if (!c->steps[i].confirmed) {
+                set_error("scal_map: internal error (recovery did not complete the stopped step)");
+                return SCAL_E_STATE;
+            }
+            continue;
+        }
+        if (R.C2.error) {
+            confirm(c, c->steps[i]);
+            return report_device_error(c, R.C2.error);
+        }
+        confirm(c, c->steps[i]);
+    }
+    return SCAL_OK;
+}
+int map_finish(scal_map* c) {
+    SCAL_TRY(confirm_steps(c, true));
+    pop_done(c);
+    return SCAL_OK;
+}
+int map_poll(scal_map* c) {
+    SCAL_TRY(confirm_steps(c, false));
+    pop_done(c);
+    return SCAL_OK;
+}
+// room for one more step: MAX_STEPS bounds the steps whose pose has not been collected; collected ones whose insertion is still
+// running are waited for here
+int map_make_room(scal_map* c) {
+    if (c->poll_on_enqueue) SCAL_TRY(map_poll(c));
+    while (static_cast<int>(c->steps.size()) >= scal_map::MAX_STEPS) {
+        if (!c->steps.front().pose_collected) {
+            set_error("scal_map: %d steps are queued and not collected", scal_map::MAX_STEPS);
+            return SCAL_E_STATE;
+        }
+        const int slot = c->steps.front().slot;
+        SCAL_HIP(hipEventSynchronize(c->ev_done[slot]));
+        SCAL_TRY(map_poll(c));
+    }
+    return SCAL_OK;
+}
+
+int new_step(scal_map* c, MapStep* out) {
+    MapStep e;
+    e.slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % scal_map::NSLOTS;
+    *out = e;
+    return SCAL_OK;
+}
+
+// queues one process() pass; `e` describes the inputs.  Speculative when the previous steps allow it, general (synchronous) otherwise.
+int map_enqueue(scal_map* c, MapStep& e) {
+    // room for this step's points whatever the queued ones add (host mirror + worst case per queued step)
+    const int queued = static_cast<int>(c->steps.size()) + 1;
+    const bool room = c->map[0].n + queued * MERGE_MAX <= c->map_cap && c->map[1].n + queued * MERGE_MAX <= c->map_cap;
+    const bool fast = c->initialised && c->merge_insert && room && e.feat != nullptr;
+    if (fast) {
+        SCAL_TRY(launch_fast(c, e));
+        c->steps.push_back(e);
+        return SCAL_OK;
+    }
+    SCAL_TRY(map_finish(c));
+    SCAL_TRY(run_general(c, e));
+    c->steps.push_back(e);
+    confirm(c, c->steps.back());
+    return SCAL_OK;
+}
+
+// waits for the pose of the oldest uncollected step; map sizes in `stats` are those before this step's insertion (insert_path = -1)
+int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* stats) {
+    MapStep* pe = nullptr;
+    for (auto& e : c->steps)
+        if (!e.pose_collected) {
+            pe = &e;
+            break;
+        }
+    if (!pe) {
         set_error("scal_map_collect: no step enqueued");
         return SCAL_E_STATE;
     }
-    c->pose_pending = false;
-    SCAL_HIP(hipEventSynchronize(c->ev_pose));
-    const MapCounters& H = *c->h_C1.p;
-    if (H.error) {
-        set_error("scal_map_step: device capacity exceeded (map pool of %d points per class, or a voxel outside its cube)", c->map_cap);
-        return H.error;
+    const int slot = pe->slot;
+    for (int round = 0;; ++round) {
+        SCAL_HIP(hipEventSynchronize(c->ev_pose[slot]));
+        if (!c->res.p[slot].S1.abort) break;
+        if (round > scal_map::MAX_STEPS + 1) {
+            set_error("scal_map_collect: internal error (recovery does not converge)");
+            return SCAL_E_STATE;
+        }
+        SCAL_TRY(recover(c));  // redoes the stopped step on the general path and queues the ones behind it again
     }
-    if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+    pe->pose_collected = true;
+    const MapResult& R = c->res.p[slot];
+    const MapCounters& H = R.C1;
+    if (H.error) return report_device_error(c, H.error);
+    if (R.st.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
         (void)hipStreamSynchronize(c->stream);
-        (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
+        (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
+        (void)hipStreamSynchronize(c->stream);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
     }
-    const double* q_wodom = c->pend_q_wodom;
-    const double* t_wodom = c->pend_t_wodom;
-    const double* xf = c->h_st.p->x;
+    const double* xf = R.st.x;
     for (int i = 0; i < 4; ++i) q_out[i] = xf[i];
     for (int i = 0; i < 3; ++i) t_out[i] = xf[4 + i];
-    {  // transformUpdate (:149-153): q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
-        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
-        const double qi[4] = {-q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2};
-        h_qmul(xf, qi, c->q_wmap_wodom);
-        double r2[3];
-        h_rot(c->q_wmap_wodom, t_wodom, r2);
-        for (int i = 0; i < 3; ++i) c->t_wmap_wodom[i] = xf[4 + i] - r2[i];
-    }
+    for (int i = 0; i < 4; ++i) c->q_wmap_wodom[i] = R.S1.q_wmap_wodom[i];
+    for (int i = 0; i < 3; ++i) c->t_wmap_wodom[i] = R.S1.t_wmap_wodom[i];
+    c->have_mp = true;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->n_corner_stack = H.n_corner_stack, stats->n_surf_stack = H.n_surf_stack;
         stats->n_corner_map = H.n_valid[0], stats->n_surf_map = H.n_valid[1];
         for (int o = 0; o < 2; ++o) {
-            const LMState& L = *c->h_st.p;
+            const LMState& L = R.st;
             stats->n_edge[o] = H.solve_on ? L.log_n_edge[o] : 0, stats->n_plane[o] = H.solve_on ? L.log_n_plane[o] : 0;
             stats->lm_iters[o] = H.solve_on ? L.log_iters[o] : 0, stats->lm_success[o] = H.solve_on ? L.log_success[o] : 0;
             stats->cost_init[o] = H.solve_on ? L.log_cost_init[o] : 0.0, stats->cost_final[o] = H.solve_on ? L.log_cost_final[o] : 0.0;
         }
         stats->solved = H.solve_on;
-        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
+        stats->n_map_corner_total = R.S1.n_map[0], stats->n_map_surf_total = R.S1.n_map[1];
         stats->insert_path = -1;
     }
-    return SCAL_OK;
-}
-
-// synchronous form: enqueue, pose, insertion finished, final map sizes
-int run_step(scal_map* c, const double* q_wodom, const double* t_wodom, bool have_full, CSoA4 full_view, const int* d_n_full, int n_corner_bound,
-             int n_surf_bound, bool filters_done, double* q_out, double* t_out, scal_map_stats* stats) {
-    SCAL_TRY(map_enqueue(c, q_wodom, t_wodom, have_full, full_view, d_n_full, n_corner_bound, n_surf_bound, filters_done));
-    SCAL_TRY(map_collect_pose(c, q_out, t_out, stats));
-    SCAL_TRY(map_finish(c));
-    if (stats) {
-        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
-        stats->insert_path = c->last_insert_path;
-    }
-    return SCAL_OK;
-}
-
-int reset_counters(scal_map* c, int n_corner, int n_surf, int n_full) {
-    MapCounters z;
-    std::memset(&z, 0, sizeof z);
-    z.n_corner_in = n_corner, z.n_surf_in = n_surf;
-    *c->h_C.p = z;
-    SCAL_HIP(hipMemcpyAsync(c->d_C().p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, c->stream));
-    c->h_misc.p[0] = n_full;
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    pop_done(c);
     return SCAL_OK;
 }
 
@@ -1378,28 +1708,49 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     const bool have_full = full_res != nullptr && n_full > 0;
-    int nf = have_full ? n_full : 0;
-    SCAL_TRY(map_finish(c));  // a pending insertion of an asynchronous step still owns the current set
+    SCAL_TRY(map_finish(c));  // synchronous entry point: nothing may be in flight
+    if (!c->steps.empty()) {
+        set_error("scal_map_step: a queued step has not been collected");
+        return SCAL_E_STATE;
+    }
+    MapStep e;
+    SCAL_TRY(new_step(c, &e));
     {
         std::lock_guard<std::mutex> lk(c->pf_mu);
         c->n_pf = 0;  // queued prefetches belong to a features context: not used by this entry point
-        c->set = (c->set + 1) % scal_map::NSETS;
+        e.set = c->alloc_set();
     }
-    c->pending_prefetched = false;
-    // n_full lives in pinned-less host memory for the async copy: stage through the counters struct instead
-    SCAL_TRY(reset_counters(c, n_corner, n_surf, nf));
-    SCAL_HIP(hipStreamSynchronize(s));  // &nf must not be read after return
+    // per-scan counters and inputs, staged through pinned memory
+    MapCounters z;
+    std::memset(&z, 0, sizeof z);
+    z.n_corner_in = n_corner, z.n_surf_in = n_surf;
+    *c->h_C.p = z;
+    SCAL_HIP(hipMemcpyAsync(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
+    c->h_misc.p[0] = have_full ? n_full : 0;
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, SoAStore& dst) -> int {
         if (n > 0) {
             SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
             launch_deinterleave(s, c->aos.p, n, dst.v());
+            SCAL_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next upload
         }
         return SCAL_OK;
     };
-    SCAL_TRY(up(corner_last, n_corner, c->corner_in()));
-    SCAL_TRY(up(surf_last, n_surf, c->surf_in()));
+    SCAL_TRY(up(corner_last, n_corner, c->corner_in(e.set)));
+    SCAL_TRY(up(surf_last, n_surf, c->surf_in(e.set)));
     if (have_full) SCAL_TRY(up(full_res, n_full, c->full_in));
-    SCAL_TRY(run_step(c, q_wodom, t_wodom, have_full, c->full_in.cv(), c->d_nfull.p, n_corner, n_surf, false, q_w_curr, t_w_curr, stats));
+    for (int i = 0; i < 4; ++i) e.pose.q_wodom[i] = q_wodom[i];
+    for (int i = 0; i < 3; ++i) e.pose.t_wodom[i] = t_wodom[i];
+    e.have_full = have_full, e.n_corner_bound = n_corner, e.n_surf_bound = n_surf;
+    SCAL_TRY(run_general(c, e));
+    c->steps.push_back(e);
+    confirm(c, c->steps.back());
+    SCAL_TRY(map_collect_pose(c, q_w_curr, t_w_curr, stats));
+    SCAL_TRY(map_finish(c));
+    if (stats) {
+        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
+        stats->insert_path = c->last_insert_path;
+    }
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
         SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
@@ -1410,14 +1761,6 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
 
 // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
 // read in place by the registration transform
-static int enqueue_gather(scal_map* c, const FeatDeviceView& v, hipStream_t s, int ls_cap, int cap, int st) {
-    const int nbc = std::max(1, div_up(ls_cap, 256));
-    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
-                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st).v(), c->surf_in(st).v(), c->d_C(st).p, c->scan_cap, nbc);
-    SCAL_HIP(hipGetLastError());
-    return SCAL_OK;
-}
-
 extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) {
     if (!c || !feat) {
         set_error("scal_map_prefetch_features: null argument");
@@ -1433,18 +1776,17 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
     std::lock_guard<std::mutex> lk(c->pf_mu);
-    if (c->n_pf >= 2) {
-        set_error("scal_map_prefetch_features: two prefetches are already queued ahead of their steps");
+    if (c->n_pf >= scal_map::MAX_PF) {
+        set_error("scal_map_prefetch_features: %d prefetches are already queued ahead of their steps", scal_map::MAX_PF);
         return SCAL_E_STATE;
     }
-    // the step in flight owns set `c->set`, queued prefetches own the following ones; this one takes the next in the ring
-    const int nset = ((c->n_pf ? c->pf[c->n_pf - 1].set : c->set) + 1) % scal_map::NSETS;
+    const int nset = c->alloc_set();
     if (!c->ev_pre[nset]) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], hipEventDisableTiming));
     SCAL_TRY(features_wait_done(feat, c->side));
-    // The filter scratch (c->vf) is shared with a step that ran its filters on the main stream: wait for that step in that case.
-    if (c->insert_pending && !c->pending_prefetched) SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_done, 0));
-    SCAL_TRY(enqueue_gather(c, v, c->side, ls_cap, cap, nset));
-    SCAL_TRY(enqueue_stack_filters(c, c->side, ls_cap, cap, nset));
+    const int nbc = std::max(1, div_up(ls_cap, 256));
+    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, c->side, v.less_xyzi, &v.P->n_less_sharp,
+                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc);
+    SCAL_TRY(enqueue_stack_filters(c, c->vf_side, c->side, ls_cap, cap, nset));
     SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
     SCAL_TRY(features_note_reader(feat, c->side));
     c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
@@ -1459,32 +1801,28 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
         return SCAL_E_ARG;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_TRY(map_finish(c));  // the previous insertion still owns the counters and the stack buffers
-    hipStream_t s = c->stream;
-    const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
-    const int cap = std::min(c->scan_cap, v.cap);
-    bool pre = false;
+    SCAL_TRY(map_make_room(c));
+    MapStep e;
+    SCAL_TRY(new_step(c, &e));
+    e.feat = feat;
+    e.n_corner_bound = std::min(c->scan_cap, v.n_scans * 120);
+    e.n_surf_bound = std::min(c->scan_cap, v.cap);
+    e.have_full = true;
+    for (int i = 0; i < 4; ++i) e.pose.q_wodom[i] = q_wodom[i];
+    for (int i = 0; i < 3; ++i) e.pose.t_wodom[i] = t_wodom[i];
     {
         std::lock_guard<std::mutex> lk(c->pf_mu);
         if (c->n_pf > 0 && c->pf[0].feat == feat) {  // the oldest queued prefetch belongs to this step: take its set
-            pre = true;
-            c->set = c->pf[0].set;
-            c->pf[0] = c->pf[1];
+            e.prefetched = true;
+            e.set = c->pf[0].set;
+            for (int i = 1; i < c->n_pf; ++i) c->pf[i - 1] = c->pf[i];
             c->n_pf--;
-        } else {  // no (matching) prefetch: drop what was queued and take the next set of the ring
-            c->set = ((c->n_pf ? c->pf[c->n_pf - 1].set : c->set) + 1) % scal_map::NSETS;
+        } else {  // no (matching) prefetch: drop what was queued and take a fresh set
             c->n_pf = 0;
+            e.set = c->alloc_set();
         }
     }
-    c->pending_prefetched = pre;
-    if (pre) {
-        SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[c->set], 0));  // inputs gathered and downsampled on the side stream
-    } else {
-        SCAL_TRY(features_wait_done(feat, s));
-        SCAL_TRY(enqueue_gather(c, v, s, ls_cap, cap, c->set));
-    }
-    SCAL_TRY(map_enqueue(c, q_wodom, t_wodom, true, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, ls_cap, cap, pre));
-    return features_note_reader(feat, s);  // the registration transform reads the full-resolution cloud last
+    return map_enqueue(c, e);
 }
 
 extern "C" int scal_map_step_features(scal_map_t* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom, double* q_w_curr,
@@ -1536,15 +1874,14 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
     if (!c->have_mp || c->map[which].n == 0) return 0;
     hipStream_t s = c->stream;
     MapStore& M = c->map[which];
-    int zero = 0;
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p + 1, &zero, sizeof(int), hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    c->h_misc.p[1] = 0;
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
     const int room = std::min(cap, c->scan_cap);
-    hipLaunchKernelGGL(k_export_valid, dim3(std::max(1, div_up(M.n, 256))), dim3(256), 0, s, M.cloud(M.cur), M.n, c->last_mp, c->d_nfull.p + 1, c->aos.p,
-                       out_xyzi ? room : 0);
-    int n = 0;
-    SCAL_HIP(hipMemcpyAsync(&n, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
+                       c->d_nfull.p + 1, c->aos.p, out_xyzi ? room : 0);
+    SCAL_HIP(hipMemcpyAsync(c->h_misc.p + 2, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));
+    const int n = c->h_misc.p[2];
     if (out_xyzi && room > 0) {
         const int m = std::min(n, room);
         SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
@@ -1564,5 +1901,17 @@ extern "C" int scal_map_get_wmap_wodom(scal_map_t* c, double* q, double* t) {
     if (!c || !q || !t) return SCAL_E_ARG;
     for (int i = 0; i < 4; ++i) q[i] = c->q_wmap_wodom[i];
     for (int i = 0; i < 3; ++i) t[i] = c->t_wmap_wodom[i];
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_get_path_counters(scal_map_t* c, int* out4) {
+    if (!c || !out4) return SCAL_E_ARG;
+    out4[0] = c->n_fast, out4[1] = c->n_general, out4[2] = c->n_recover_pose, out4[3] = c->n_recover_insert;
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_set_poll(scal_map_t* c, int enable) {
+    if (!c) return SCAL_E_ARG;
+    c->poll_on_enqueue = enable != 0;
     return SCAL_OK;
 }

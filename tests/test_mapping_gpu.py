@@ -119,3 +119,65 @@ def test_merge_insert_equals_full_sort(S, stage_ab):
             assert ma.shape == mb.shape and np.array_equal(ma, mb), (k, which)
     assert used >= len(frames) - 3, used  # first scan and window moves take the full sort
     a.close(), b.close()
+
+
+@pytest.mark.parametrize("plane_res", [0.8, 0.25])
+def test_queued_steps_equal_general_path(S, hdl64_stream, plane_res):
+    """Steps queued behind each other (pose composition, window decision and map sizes stay on the device; nothing is read back
+    between them) against one synchronous step at a time and against the general path with the full-sort insertion.  The odometry
+    poses jump across a cube boundary twice, so a queued step meets a moved window: the device stops the speculative chain, the
+    host redoes that step on the general path and replays the ones queued behind it.  plane_res 0.25 gives more than 8192 stack
+    points per scan: every merge insert gives up and every insertion is redone with the full sort.  All three must agree bit for bit."""
+    n, depth = 14, 3
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(depth + 2)]
+    od = S.LaserOdometry(max_points=200000)
+    mk = lambda: S.LaserMapping(0.4, plane_res, max_scan_points=200000, max_map_points=3000000)
+    a, b, g = mk(), mk(), mk()
+    g.set_merge_insert(False)
+    b.set_poll(False)   # a stopped chain is noticed by collect only: the steps queued behind it meanwhile must be replayed
+    poses_a, poses_b, poses_g, paths = [], [], [], []
+    inflight = []
+    for k in range(n):
+        r = regs[k % len(regs)]
+        r.laserCloudHandler(hdl64_stream(k))
+        qlc, tlc, qw, tw, _ = od.step_features(r)
+        tw = tw + np.array([30.0 if 6 <= k < 10 else 0.0, 0.0, 0.0])
+        qa, ta, sa = a.process_features(r, qw, tw)
+        qg, tg, sg = g.process_features(r, qw, tw)
+        assert sg.insert_path == 0
+        paths.append(sa.insert_path)
+        poses_a.append(np.concatenate([qa, ta])), poses_g.append(np.concatenate([qg, tg]))
+        b.enqueue_features(r, qw, tw)
+        inflight.append(k)
+        if len(inflight) == depth:
+            qb, tb, sb = b.collect()
+            poses_b.append(np.concatenate([qb, tb]))
+            inflight.pop(0)
+    while inflight:
+        qb, tb, sb = b.collect()
+        poses_b.append(np.concatenate([qb, tb]))
+        inflight.pop(0)
+    b.finish()
+    for k in range(n):
+        assert np.array_equal(poses_a[k], poses_g[k]), (k, np.abs(poses_a[k] - poses_g[k]).max())
+        assert np.array_equal(poses_b[k], poses_g[k]), (k, np.abs(poses_b[k] - poses_g[k]).max())
+    for which in (0, 1):
+        ma, mb, mg = _sorted_rows(a.export(which)), _sorted_rows(b.export(which)), _sorted_rows(g.export(which))
+        assert ma.shape == mg.shape and np.array_equal(ma, mg), which
+        assert mb.shape == mg.shape and np.array_equal(mb, mg), which
+    qa_, ta_ = a.wmap_wodom()
+    qb_, tb_ = b.wmap_wodom()
+    qg_, tg_ = g.wmap_wodom()
+    assert np.array_equal(qa_, qg_) and np.array_equal(ta_, tg_) and np.array_equal(qb_, qg_) and np.array_equal(tb_, tg_)
+    ca, cb, cg = a.path_counters(), b.path_counters(), g.path_counters()
+    print("path counters (speculative, general, redone after a window move, insertion redone):", ca, cb, cg)
+    assert cg[0] == 0 and cg[1] == n
+    if plane_res == 0.8:
+        assert sum(paths) >= n - 4, paths   # first scan and the two window moves take the full sort
+        assert ca[2] == 2 and cb[2] >= 2 and ca[3] == 0 and cb[3] == 0, (ca, cb)
+        assert cb[0] > n, cb                # steps queued behind a stopped one were replayed
+    else:
+        assert sum(paths) == 0, paths       # too many new points for the merge: always redone with the full sort
+        assert ca[3] >= n - 4 and cb[3] >= n - 4, (ca, cb)
+    for m in (a, b, g):
+        m.close()

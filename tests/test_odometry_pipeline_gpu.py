@@ -303,8 +303,8 @@ def test_sharded_stage_d_flow_equals_single_context(S, hdl64_stream):
 
 
 def test_async_entry_points_reject_misuse(S, hdl64_stream):
-    """The split entry points keep one step in flight per context: collecting nothing, or queueing a second step before the first
-    has been collected, is an error (SCAL_E_STATE), and the context stays usable."""
+    """The split entry points keep a bounded number of steps in flight per context (odometry 1, mapping 4, prefetches 3): collecting
+    nothing, or queueing more, is an error (SCAL_E_STATE), and the context stays usable."""
     reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
     od = S.LaserOdometry(max_points=200000)
     mp = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=1000000)
@@ -327,17 +327,22 @@ def test_async_entry_points_reject_misuse(S, hdl64_stream):
         od.enqueue_features(reg)
     assert e.value.code == S.E_STATE
     qlc, tlc, qw, tw, st = od.collect()
-    mp.enqueue_features(reg, qw, tw)
-    with pytest.raises(S.ScalError) as e:
+    for _ in range(4):
         mp.enqueue_features(reg, qw, tw)
+    with pytest.raises(S.ScalError) as e:
+        mp.enqueue_features(reg, qw, tw)   # a fifth step before any pose has been collected
     assert e.value.code == S.E_STATE
-    q, t, ms = mp.collect()
-    assert ms.insert_path == -1          # the insertion is still behind the pose
+    for _ in range(4):
+        q, t, ms = mp.collect()
+        assert ms.insert_path == -1          # the insertion may still be behind the pose
+    with pytest.raises(S.ScalError) as e:
+        mp.collect()
+    assert e.value.code == S.E_STATE
     mp.finish()
     assert mp.export(0).shape[0] > 0
-    # three prefetches without a step in between: the third is refused
-    mp.prefetch_features(reg)
-    mp.prefetch_features(reg)
+    # four prefetches without a step in between: the fourth is refused
+    for _ in range(3):
+        mp.prefetch_features(reg)
     with pytest.raises(S.ScalError) as e:
         mp.prefetch_features(reg)
     assert e.value.code == S.E_STATE
