@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
     ap.add_argument("--side-thread", type=int, default=1, help="queue the side-stream work from a second host thread (0/1)")
-    ap.add_argument("--ring", type=int, default=4, help="features contexts used in turn by the stage pipeline")
+    ap.add_argument("--ring", type=int, default=6, help="features contexts used in turn by the stage pipeline")
     ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
@@ -116,7 +116,8 @@ def main():
     # One stream per stage, consecutive scans overlapping like the reference's four ROS nodes (scanRegistration, laserOdometry,
     # laserMapping, laserPosegraphOptimization run concurrently on different scans); two features contexts used alternately.
     S.set_stream_mode(1 if pipelined else 0)
-    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range((max(a.ring, 6) if world > 1 else a.ring) if pipelined else 1)]  # N > 1: the exchange thread may lag 3 scans
+    # pipelined: a features context is not run again before the stage-C step that used it has been collected (scal_map_enqueue_features)
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range((max(a.ring, 8) if world > 1 else a.ring) if pipelined else 1)]  # N > 1: the exchange thread may lag 3 scans
     reg = regs[0]
     od = S.LaserOdometry(max_points=cap, device=local)
     mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
@@ -193,11 +194,14 @@ def main():
             r = sc_sharded(k)
         account(mst, r)
 
-    pipe = dict(map_pending=False, loop=None, a_queued=-1, accounts=[])
+    # ---- stage-pipelined schedule.  Nothing on the pose chains waits for the host any more: stage C composes its prior, decides
+    # the rolling window and tracks the map sizes on the device, so scan k's stage C is queued while scan k-1's (and k-2's) still
+    # runs; stage B is kept one scan ahead of the pose it hands to stage C, stage A two scans ahead.
+    pipe = dict(c_inflight=[], loops={}, side_inflight=False, b_queued=-1, started=False)
     PENDING = object()
+    C_DEPTH = 2   # stage-C steps queued and not collected (the library allows 4)
 
-    # A second host thread queues the side-stream work (the library calls release the GIL): the launch calls of one scan
-    # cost the host ~330 us, more than any single stage costs the GPU.
+    # A second host thread queues the side-stream work and stage A (the library calls release the GIL).
     import queue
     import threading
     side_q, side_done = queue.Queue(), queue.Queue()
@@ -208,8 +212,7 @@ def main():
             if job is None:
                 return
             try:
-                for fn, args in job:
-                    fn(*args)
+                job()
                 side_done.put(None)
             except Exception as e:  # surfaced in the main thread
                 side_done.put(e)
@@ -243,79 +246,94 @@ def main():
     if xchg_thread:
         xchg_thread.start()
 
-    def loop_result(v):
-        if v is not PENDING:
-            return v
+    def loop_result(k):
+        if world == 1:
+            return pipe["loops"].pop(k)
         r = loop_q.get()
         if isinstance(r, Exception):
             raise r
         return r
 
-    def queue_front(k, last):
-        """everything of scan k that does not need a pose: stage B, the side-stream work, and stage A of scan k+1"""
-        r_ = regs[k % len(regs)]
-        if pipe["a_queued"] < k:
-            timed("A.run_device", r_.run_device, d_scans[k].data_ptr(), npts[k], 3)
-            pipe["a_queued"] = k
-        side = [(mp.prefetch_features, (r_,))]
-        if world == 1:
-            side += [(sc.insert_features, (r_,)), (sc.detect_enqueue, ())]
-        else:
-            xchg_q.put((k, r_))
-        nxt = None
-        if k + 1 < last:
-            nxt = (regs[(k + 1) % len(regs)].run_device, (d_scans[k + 1].data_ptr(), npts[k + 1], 3))
-            pipe["a_queued"] = k + 1
-        if side_thread:
-            # stage A of the NEXT scan goes to the side thread as well (its last job): nothing on the main thread needs it before
-            # the join of this job, which precedes the next scan's B.enqueue
-            side_q.put(side[:1] + ([nxt] if nxt else []) + side[1:])  # prefetch (stage C waits for it), then A, then stage D
-        timed("B.enqueue", od.enqueue_features, r_)
-        if not side_thread:
-            for fn, args in side:
-                timed("side." + fn.__name__, fn, *args)
-            if nxt:
-                timed("A.run_device", nxt[0], *nxt[1])
-        pipe["front"] = k
+    def side_job(j, last):
+        """Everything that only needs stage A, queued one iteration ahead of its use: the loop answer of scan j (its search was
+        queued by the previous job), stage A of scan j+2, and for scan j+1 the stage-C prefetch and the ScanContext insert + search."""
+        def run():
+            if world == 1 and j in pipe.get("d_queued", ()):
+                pipe["loops"][j] = timed("D.detect_collect", sc.detect_collect)
+                pipe["d_queued"].discard(j)
+            if j + 2 < last:
+                timed("A.run_device", regs[(j + 2) % len(regs)].run_device, d_scans[j + 2].data_ptr(), npts[j + 2], 3)
+            if j + 1 < last:
+                r_ = regs[(j + 1) % len(regs)]
+                timed("side.prefetch", mp.prefetch_features, r_)
+                if world == 1:
+                    timed("D.insert", sc.insert_features, r_)
+                    timed("D.detect_enqueue", sc.detect_enqueue)
+                    pipe.setdefault("d_queued", set()).add(j + 1)
+                else:
+                    xchg_q.put((j + 1, r_))
+        return run
 
-    def step_pipelined(k, last):
-        """Software pipeline over the stage streams.  The front of scan k (stage B, the work that only needs stage A - C's input
-        gather + stack downsample, D's insert + search - and stage A of the next scan) was queued during the previous step.
-        Here: B's pose is collected and the front of scan k+1 is queued at once, so stage B never idles; then the pose of the
-        PREVIOUS scan's stage C is collected (its map insertion continues behind it) and this scan's stage C is queued."""
-        r_ = regs[k % len(regs)]
-        if pipe.get("front", -1) < k:
-            queue_front(k, last)
-        qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+    def run_side(job):
         if side_thread:
-            err = timed("side.join", side_done.get)  # scan k's side work is queued (stage C waits for the prefetch event)
+            side_q.put(job)
+            pipe["side_inflight"] = True
+        else:
+            job()
+
+    def join_side():
+        if pipe["side_inflight"]:
+            err = timed("side.join", side_done.get)
+            pipe["side_inflight"] = False
             if err is not None:
                 raise err
-        loop = timed("D.detect_collect", sc.detect_collect) if world == 1 else None
-        if k + 1 < last:
-            queue_front(k + 1, last)
-        if pipe["map_pending"]:
-            qm, tm, mst = timed("C.collect", mp.collect)
-            last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
-            pipe["accounts"].append((mst, pipe["loop"]))
-            while len(pipe["accounts"]) > 2:  # the exchange thread may lag two scans behind (their features contexts are still intact)
-                m_, l_ = pipe["accounts"].pop(0)
-                account(m_, timed("D.loop_result", loop_result, l_))
-        timed("C.enqueue", mp.enqueue_features, r_, qw, tw)
-        pipe["map_pending"] = True
-        pipe["loop"] = loop if world == 1 else PENDING
+
+    def collect_c():
+        k = pipe["c_inflight"].pop(0)
+        qm, tm, mst = timed("C.collect", mp.collect)
+        last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
+        return k, mst
+
+    def step_pipelined(k, last):
+        """Iteration k of the software pipeline: stage B of scan k+1 is queued before the pose of scan k's stage B is collected,
+        that pose goes straight into scan k's stage C, which queues behind the stage-C steps still running; the oldest of those
+        is collected when more than C_DEPTH are outstanding."""
+        if not pipe["started"]:  # first scan of a run: what the previous iterations would have queued
+            regs[k % len(regs)].run_device(d_scans[k].data_ptr(), npts[k], 3)
+            od.enqueue_features(regs[k % len(regs)])
+            pipe["b_queued"] = k
+            pipe["started"] = True
+            side_job(k - 1, last)()   # A(k+1), prefetch(k), D(k)
+        join_side()                   # job k-1: A(k+1), prefetch(k), D(k) are queued
+        run_side(side_job(k, last))
+        if k + 1 < last and pipe["b_queued"] < k + 1:
+            timed("B.enqueue", od.enqueue_features, regs[(k + 1) % len(regs)])
+            pipe["b_queued"] = k + 1
+        qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+        timed("C.enqueue", mp.enqueue_features, regs[k % len(regs)], qw, tw)
+        pipe["c_inflight"].append(k)
+        while len(pipe["c_inflight"]) > C_DEPTH:
+            kk, mst = collect_c()
+            pipe.setdefault("accounts", []).append((kk, mst))
+        # N > 1: the exchange thread may lag two scans behind (their features contexts are still intact)
+        while pipe.get("accounts") and (len(pipe["accounts"]) > 2 if world > 1 else pipe["accounts"][0][0] in pipe["loops"]):
+            kk, mst = pipe["accounts"].pop(0)
+            account(mst, timed("D.loop_result", loop_result, kk))
 
     def drain():
-        if pipe["map_pending"]:
-            qm, tm, mst = mp.collect()
-            last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
-            pipe["accounts"].append((mst, pipe["loop"]))
-            pipe["map_pending"] = False
-        if xchg_thread and any(l_ is PENDING for _, l_ in pipe["accounts"]):
+        join_side()
+        while pipe["c_inflight"]:
+            pipe.setdefault("accounts", []).append(collect_c())
+        if world == 1:
+            for j in sorted(pipe.get("d_queued", ())):
+                pipe["loops"][j] = sc.detect_collect()
+            pipe["d_queued"] = set()
+        elif xchg_thread and pipe.get("accounts"):
             xchg_q.put("flush")  # the exchange of the last scan runs one job late
-        for m_, l_ in pipe["accounts"]:
-            account(m_, loop_result(l_))
+        for kk, mst in pipe.get("accounts", []):
+            account(mst, loop_result(kk))
         pipe["accounts"] = []
+        pipe["started"] = False
         mp.finish()
 
     step = step_pipelined if pipelined else (lambda k, last: step_serial(k))

@@ -283,7 +283,9 @@ int scal_odom_step(scal_odom_t* ctx, const float* sharp, int n_sharp, const floa
                    double* t_last_curr, double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
 int scal_odom_step_features(scal_odom_t* ctx, scal_features_t* feat, double* q_last_curr, double* t_last_curr,
                             double* q_w_curr, double* t_w_curr, scal_odom_stats* stats);
-/* the same in two halves (= enqueue + collect): the caller can queue other work while the step runs */
+/* the same in two halves (= enqueue + collect): the caller can queue other work while the step runs.  Up to four steps may be
+ * queued before the first is collected (a step only needs its predecessor's device state: the last clouds and the pose increment
+ * of :97-101); collect returns them in order and integrates the pose (:504-505) on the host. */
 int scal_odom_enqueue_features(scal_odom_t* ctx, scal_features_t* feat);
 int scal_odom_collect(scal_odom_t* ctx, double* q_last_curr, double* t_last_curr, double* q_w_curr, double* t_w_curr,
                       scal_odom_stats* stats);

@@ -776,9 +776,8 @@ __global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState*
     for (int c = half; c < nc; c += 2) {
         if (c == tile) continue;
         const unsigned long long* ch = sk + c * 512;
-        int lo = 0, hi = 512;
-#pragma unroll
-        for (int step = 0; step < 9; ++step) {  // 512 = 2^9: lo ends as the number of entries < key
+        int lo = 0, hi = 512;  // lower bound: 513 possible answers, at most 10 probes
+        while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if (ch[mid] < key) lo = mid + 1;
             else hi = mid;

@@ -12,6 +12,7 @@
 //   lm_dev.hpp     the Ceres-equivalent solve, state persists across scans (para_q / para_t, :97-101).
 // Clouds are SoA x[] y[] z[] intensity[] in HBM; intensity carries the ring id in its integer part (:308).
 #include "common.hpp"
+#include <deque>
 #include "device_utils.hpp"
 #include "voxel_dev.hpp"
 #include "lm_dev.hpp"
@@ -366,11 +367,18 @@ using namespace scal;
 struct scal_odom {
     scal_odom_config cfg;
     hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
     int cap = 0, feat_cap = 0, slot_cap = 0;
     int lane = 0;
     bool systemInited = false;
-    bool pending = false, pending_solve = false;  // a step is enqueued and not collected yet
+    // steps enqueued and not collected yet: B(k+1) only needs B(k)'s device state, so it can be queued right behind it
+    static constexpr int MAX_STEPS = 4;
+    struct Pending {
+        int slot;
+        bool solve;
+    };
+    std::deque<Pending> pending;
+    hipEvent_t ev[MAX_STEPS] = {};
+    int next_slot = 0;
     double q_w_curr[4] = {0, 0, 0, 1}, t_w_curr[3] = {0, 0, 0};  // :93-94
     DevBuf<float> aos;
     OSoA sharp, flat, less_sharp, less_flat;  // current scan
@@ -384,8 +392,9 @@ struct scal_odom {
     int tab_cur = 0;       // set read by this scan's association
     DevBuf<LMState> d_st;
     DevBuf<OdomCounters> d_C;
-    PinBuf<OdomCounters> h_C;
-    PinBuf<LMState> h_st;
+    PinBuf<OdomCounters> h_C;   // [MAX_STEPS] result slots
+    PinBuf<LMState> h_st;       // [MAX_STEPS]
+    PinBuf<OdomCounters> h_up;  // upload staging of scal_odom_step
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
 };
 
@@ -411,16 +420,18 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
     A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
     A(c->lm_sync.alloc(1));
-    if (rc == SCAL_OK && hipMemset(c->lm_sync.p, 0, sizeof(LMSync)) != hipSuccess) rc = SCAL_E_HIP;
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->ring_tab.alloc(8 * RING_TAB));
-    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(1)); A(c->h_st.alloc(1));
+    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(scal_odom::MAX_STEPS)); A(c->h_st.alloc(scal_odom::MAX_STEPS)); A(c->h_up.alloc(1));
     c->lane = stage_lane(STAGE_ODOM);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
-    if (rc == SCAL_OK && hipEventCreateWithFlags(&c->ev, hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
+    for (int k = 0; k < scal_odom::MAX_STEPS && rc == SCAL_OK; ++k)
+        if (hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
-        if (hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        // everything is initialised on the context's own stream (the legacy null stream is not ordered against it)
+        if (hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         hipLaunchKernelGGL(k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
         if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
@@ -441,7 +452,8 @@ extern "C" void scal_odom_destroy(scal_odom_t* c) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device, c->lane);
     }
-    if (c->ev) (void)hipEventDestroy(c->ev);
+    for (int k = 0; k < scal_odom::MAX_STEPS; ++k)
+        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
     delete c;
 }
 
@@ -467,6 +479,9 @@ int odom_enqueue(scal_odom* c) {
     LMState* st = c->d_st.p;
     FactorSoA F = c->factors();
     const bool solve = c->systemInited;  // first frame: no optimisation (:267-271)
+    c->systemInited = true;
+    const int slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % scal_odom::MAX_STEPS;
     if (solve) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
             {
@@ -498,27 +513,32 @@ int odom_enqueue(scal_odom* c) {
         c->tab_cur ^= 1;
     }
     SCAL_HIP(hipGetLastError());
-    launch_publish(s, st, c->h_st.p, static_cast<const OdomCounters*>(C), c->h_C.p);
+    launch_publish(s, st, c->h_st.p + slot, static_cast<const OdomCounters*>(C), c->h_C.p + slot);
     SCAL_HIP(hipGetLastError());
-    c->pending = true, c->pending_solve = solve;
+    SCAL_HIP(hipEventRecord(c->ev[slot], s));
+    c->pending.push_back({slot, solve});
     return SCAL_OK;
 }
 
 // waits for the enqueued step and integrates the pose on the host (:504-505)
 int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* t_w, scal_odom_stats* stats) {
-    if (!c->pending) {
+    if (c->pending.empty()) {
         set_error("scal_odom_collect: no step enqueued");
         return SCAL_E_STATE;
     }
-    c->pending = false;
-    const bool solve = c->pending_solve;
-    SCAL_HIP(hipStreamSynchronize(c->stream));
-    if (c->h_st.p->termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
-        (void)hipMemset(c->lm_sync.p, 0, sizeof(LMSync));
+    const int slot = c->pending.front().slot;
+    const bool solve = c->pending.front().solve;
+    c->pending.pop_front();
+    SCAL_HIP(hipEventSynchronize(c->ev[slot]));
+    const LMState& L = c->h_st.p[slot];
+    if (L.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
+        (void)hipStreamSynchronize(c->stream);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
     }
-    const double* x = c->h_st.p->x;
+    const double* x = L.x;
     if (solve) {  // :504-505
         double r[3];
         o_rot(c->q_w_curr, x + 4, r);
@@ -527,13 +547,11 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
         o_qmul(c->q_w_curr, x, qn);
         for (int i = 0; i < 4; ++i) c->q_w_curr[i] = qn[i];
     }
-    c->systemInited = true;
     for (int i = 0; i < 4; ++i) q_lc[i] = x[i], q_w[i] = c->q_w_curr[i];
     for (int i = 0; i < 3; ++i) t_lc[i] = x[4 + i], t_w[i] = c->t_w_curr[i];
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         if (solve) {
-            const LMState& L = *c->h_st.p;
             for (int o = 0; o < 2; ++o) {
                 stats->n_edge[o] = L.log_n_edge[o], stats->n_plane[o] = L.log_n_plane[o];
                 stats->lm_iters[o] = L.log_iters[o], stats->lm_success[o] = L.log_success[o];
@@ -560,8 +578,13 @@ extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, c
         return SCAL_E_TOO_MANY;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (!c->pending.empty()) {
+        set_error("scal_odom_step: a queued step has not been collected");
+        return SCAL_E_STATE;
+    }
     hipStream_t s = c->stream;
-    OdomCounters& H = *c->h_C.p;
+    SCAL_HIP(hipStreamSynchronize(s));  // the upload staging may still feed the previous call's copy
+    OdomCounters& H = *c->h_up.p;
     // keep the device-resident n_corner_last / n_surf_last, refresh the per-scan part from pinned memory
     OdomCounters fresh;
     std::memset(&fresh, 0, sizeof fresh);
@@ -590,8 +613,8 @@ extern "C" int scal_odom_enqueue_features(scal_odom_t* c, scal_features_t* feat)
         set_error("scal_odom_enqueue_features: null argument");
         return SCAL_E_ARG;
     }
-    if (c->pending) {
-        set_error("scal_odom_enqueue_features: the previous step has not been collected");
+    if (static_cast<int>(c->pending.size()) >= scal_odom::MAX_STEPS) {
+        set_error("scal_odom_enqueue_features: %d steps are queued and not collected", scal_odom::MAX_STEPS);
         return SCAL_E_STATE;
     }
     FeatDeviceView v = features_view(feat);

@@ -182,7 +182,9 @@ def test_sc_side_stream_overlap_is_ordered(O, S, hdl64_stream):
 def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
     """scal_set_stream_mode(1): every stage on its own stream, consecutive scans overlapping like the reference's four nodes
     (A and B of scan k+1, and its stage-C prefetch, while C of scan k still runs; map insertion behind the pose).  Software-
-    pipelined exactly as bench.py does it, with a ring of features contexts and two prefetches in flight.  Every pose and every loop-closure answer must equal the oracle chain."""
+    pipelined exactly as bench.py does it: a ring of features contexts, stage A two scans ahead, stage B one scan ahead of the
+    pose it hands over, stage-C steps queued behind each other (two uncollected).  Every pose and every loop-closure answer must
+    equal the oracle chain."""
     n = 8
     S.set_stream_mode(1)
     try:
@@ -196,28 +198,47 @@ def test_pipelined_stages_match_oracle(O, S, hdl64_stream):
             d = rng.uniform(-2, 18, (20, 60)) * (rng.uniform(size=(20, 60)) < 0.5)
             sc.saveScancontextAndKeys(d)
             osc.saveScancontextAndKeys(d)
-        poses, loops = [], []
-        regs += [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(2)]  # ring of four, as bench.py uses
+        poses, loops = [], {}
+        regs += [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(4)]  # ring of six, as bench.py uses
+        R = len(regs)
 
-        def front(k):  # everything of scan k that needs no pose: stage A, stage B, C's prefetch, stage D
-            reg = regs[k % 4]
-            reg.laserCloudHandler(hdl64_stream(k))
-            od.enqueue_features(reg)
-            mp.prefetch_features(reg)
-            sc.insert_features(reg)
-            sc.detect_enqueue()
+        def side(j):  # bench.py's side job j: loop answer of scan j, stage A of scan j+2, prefetch + ScanContext of scan j+1
+            if j >= 1:
+                loops[j] = sc.detect_collect()
+            if j + 2 < n:
+                regs[(j + 2) % R].laserCloudHandler(hdl64_stream(j + 2))
+            if j + 1 < n:
+                mp.prefetch_features(regs[(j + 1) % R])
+                sc.insert_features(regs[(j + 1) % R])
+                sc.detect_enqueue()
 
-        front(0)
+        regs[0].laserCloudHandler(hdl64_stream(0))
+        od.enqueue_features(regs[0])
+        side(-1)
+        loops[0] = sc.detect_collect()
+        inflight = 0
         for k in range(n):
-            qlc, tlc, qw, tw, ost = od.collect()
-            loops.append(sc.detect_collect())
-            if k + 1 < n:
-                front(k + 1)                 # scan k+1's prefetch is queued while scan k's stage C has not even started
             if k > 0:
+                side(k)
+            else:  # job 0 without the collect (done above, nothing was queued in between)
+                regs[2 % R].laserCloudHandler(hdl64_stream(2))
+                mp.prefetch_features(regs[1])
+                sc.insert_features(regs[1])
+                sc.detect_enqueue()
+            if k + 1 < n:
+                od.enqueue_features(regs[(k + 1) % R])   # stage B of scan k+1 queued before scan k's pose is collected
+            qlc, tlc, qw, tw, ost = od.collect()
+            mp.enqueue_features(regs[k % R], qw, tw)     # queues behind the stage-C steps still running
+            inflight += 1
+            if inflight > 2:
                 poses.append(mp.collect()[:2])
-            mp.enqueue_features(regs[k % 4], qw, tw)
-        poses.append(mp.collect()[:2])
+                inflight -= 1
+        while inflight:
+            poses.append(mp.collect()[:2])
+            inflight -= 1
         mp.finish()
+        print("stage C paths (speculative, general, redone after window move, insertion redone):", mp.path_counters())
+        loops = [loops[k] for k in range(n)]
         oo, om = O.Odometry(), O.Mapper(0.4, 0.8)
         for k in range(n):
             fo = O.features(hdl64_stream(k), O.HDL64, 5.0)
@@ -303,7 +324,7 @@ def test_sharded_stage_d_flow_equals_single_context(S, hdl64_stream):
 
 
 def test_async_entry_points_reject_misuse(S, hdl64_stream):
-    """The split entry points keep a bounded number of steps in flight per context (odometry 1, mapping 4, prefetches 3): collecting
+    """The split entry points keep a bounded number of steps in flight per context (odometry 4, mapping 4, prefetches 3): collecting
     nothing, or queueing more, is an error (SCAL_E_STATE), and the context stays usable."""
     reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
     od = S.LaserOdometry(max_points=200000)
@@ -322,11 +343,16 @@ def test_async_entry_points_reject_misuse(S, hdl64_stream):
         sc.wait_descriptor()
     assert e.value.code == S.E_STATE
     reg.laserCloudHandler(hdl64_stream(0))
-    od.enqueue_features(reg)
+    for _ in range(4):
+        od.enqueue_features(reg)
     with pytest.raises(S.ScalError) as e:
         od.enqueue_features(reg)
     assert e.value.code == S.E_STATE
-    qlc, tlc, qw, tw, st = od.collect()
+    for _ in range(4):
+        qlc, tlc, qw, tw, st = od.collect()
+    with pytest.raises(S.ScalError) as e:
+        od.collect()
+    assert e.value.code == S.E_STATE
     for _ in range(4):
         mp.enqueue_features(reg, qw, tw)
     with pytest.raises(S.ScalError) as e:
