@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
+    ap.add_argument("--timeline-kernels", default="", help="with --timeline: only these kernels (comma separated), over the whole timed region")
+    ap.add_argument("--timeline", default="", help="development aid: write (kernel, start ms, stop ms) of every dispatch of six timed steps to this CSV")
     ap.add_argument("--sync-dir", default="", help="start the timed region together with --sync-n other bench.py processes (ready files in this directory)")
     ap.add_argument("--sync-n", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
@@ -255,23 +257,24 @@ def main():
         return r
 
     def side_job(j, last):
-        """Everything that only needs stage A, queued one iteration ahead of its use: the loop answer of scan j (its search was
-        queued by the previous job), stage A of scan j+2, and for scan j+1 the stage-C prefetch and the ScanContext insert + search."""
+        """Everything that only needs stage A, queued one iteration ahead of its use: for scan j+1 the stage-C prefetch, stage A of
+        scan j+2, the loop answer of scan j (its search was queued by the previous job), then scan j+1's ScanContext insert + search."""
         def run():
-            if world == 1 and j in pipe.get("d_queued", ()):
-                pipe["loops"][j] = timed("D.detect_collect", sc.detect_collect)
-                pipe["d_queued"].discard(j)
+            r_ = regs[(j + 1) % len(regs)] if j + 1 < last else None
+            if r_ is not None:
+                timed("side.prefetch", mp.prefetch_features, r_)   # first: its gather + corner filter ride on stage A's stream
             if j + 2 < last:
                 timed("A.run_device", regs[(j + 2) % len(regs)].run_device, d_scans[j + 2].data_ptr(), npts[j + 2], 3)
-            if j + 1 < last:
-                r_ = regs[(j + 1) % len(regs)]
-                timed("side.prefetch", mp.prefetch_features, r_)
+            if r_ is not None:
                 if world == 1:
                     timed("D.insert", sc.insert_features, r_)
                     timed("D.detect_enqueue", sc.detect_enqueue)
                     pipe.setdefault("d_queued", set()).add(j + 1)
                 else:
                     xchg_q.put((j + 1, r_))
+            if world == 1 and j in pipe.get("d_queued", ()):      # queued by the previous job: a whole period to finish
+                pipe["loops"][j] = timed("D.detect_collect", sc.detect_collect)
+                pipe["d_queued"].discard(j)
         return run
 
     def run_side(job):
@@ -365,7 +368,10 @@ def main():
     n_prof_steps = 0
     for k in range(W, W + K):
         on = a.prof_every > 0 and (k - W) % a.prof_every == 0
-        S.prof_enable(on)  # per-kernel timestamps on the sampled steps of the timed region
+        if a.timeline:
+            on = True if a.timeline_kernels else K // 2 <= k - W < K // 2 + 6
+            S.prof_timeline(on)
+        S.prof_enable(on, a.timeline_kernels or None)  # per-kernel timestamps on the sampled steps of the timed region
         n_prof_steps += on
         step(k, W + K)
     if pipelined:
@@ -375,6 +381,8 @@ def main():
     gc.enable()
     S.prof_enable(False)
     prof = S.prof_read_all()
+    if a.timeline:
+        S.prof_timeline_dump(a.timeline)
     # sizes of one representative scan (outside the timed region) for the algorithmic-byte formulas
     reg.run_device(d_scans[W + K - 1].data_ptr(), npts[W + K - 1], 3)
     fz = reg.fetch()

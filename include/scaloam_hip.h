@@ -53,6 +53,10 @@ int scal_prof_filter(const char* kernel_name); /* time only this kernel (NULL/""
 int scal_prof_reset(void);
 int scal_prof_read(const char* kernel_name, double* total_ms, long* count);
 int scal_prof_names(char* buf, int cap);
+/* development aid: while on (together with scal_prof_enable), every timed dispatch is also kept as (kernel, start ms, stop ms)
+ * relative to one base event; scal_prof_timeline_dump writes them as CSV and clears the list */
+int scal_prof_timeline(int on);
+int scal_prof_timeline_dump(const char* path);
 
 /* ------------------------------------------------------------------ stage A: feature extraction
  * Replaces laserCloudHandler, src/scanRegistration.cpp:134-421 (NaN/range filter, ring id + relative
@@ -171,8 +175,9 @@ int scal_sc_make_descriptor(scal_sc_t* ctx, const float* xyzi, int n, double* de
 /* detectLoopClosureID(): query = newest keyframe; reproduces the >=31 gate, the 30-query tree period,
  * the exclusion of the newest 30 keys and the 3-candidate / 7-shift search (Scancontext.cpp:336-427). */
 int scal_sc_detect(scal_sc_t* ctx, scal_sc_result* res);
-/* the same in two halves: enqueue launches the search for the newest keyframe and returns, collect waits for it.
- * scal_sc_detect = enqueue + collect.  No other query may run on the context in between. */
+/* the same in two halves: enqueue launches the search for the newest keyframe and returns, collect waits for the oldest search
+ * not yet collected (its own event: nothing queued on the stream behind it is waited for).  scal_sc_detect = enqueue + collect.
+ * Up to four searches may be in flight, each for the keyframe that was newest when it was enqueued. */
 int scal_sc_detect_enqueue(scal_sc_t* ctx);
 int scal_sc_detect_collect(scal_sc_t* ctx, scal_sc_result* res);
 /* distanceBtnScanContext for descriptor pairs already in the database */

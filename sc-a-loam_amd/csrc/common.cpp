@@ -74,8 +74,11 @@ int acquire_stream(int device, hipStream_t* out, int lane) {
 
 int stage_lane(int stage) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    if (g_stream_mode == 0) return 0;
-    return stage == STAGE_ODOM ? 3 : stage == STAGE_MAP ? 4 : stage == STAGE_SC ? 1 : 0;
+    if (g_stream_mode == 0) return stage == STAGE_MAP_PREFETCH ? 2 : 0;
+    // Four streams, not five: an MI355X advances four dependent kernel chains at full rate, and with more streams than that they
+    // all slow down together (tools/stream_probe.hip: 0.62 M kernels/s with 4 streams, 0.25-0.35 M with 6-8).  So the two side
+    // jobs that only depend on stage A - stage C's prefetch and ScanContext - share one stream.
+    return stage == STAGE_ODOM ? 3 : stage == STAGE_MAP ? 4 : (stage == STAGE_SC || stage == STAGE_MAP_PREFETCH) ? 1 : 0;
 }
 
 void release_stream(int device, int lane) {
@@ -95,6 +98,7 @@ namespace {
 struct ProfEntry {
     std::string name;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<const void*> pending_tl;  // keep this dispatch for the timeline: its stream (null = do not keep)
     double total_ms = 0;
     long count = 0;
 };
@@ -103,6 +107,15 @@ std::vector<ProfEntry> g_prof;
 std::vector<hipEvent_t> g_event_pool;
 bool g_prof_on = false;
 std::string g_prof_filter;  // empty = every instrumented kernel
+// optional raw timeline: (kernel, start, stop) in ms since a base event, for the dispatches timed while it is on
+struct TimelineRow {
+    std::string name;
+    float t0, t1;
+    const void* stream;
+};
+bool g_timeline_on = false;
+hipEvent_t g_timeline_base = nullptr;
+std::vector<TimelineRow> g_timeline;
 
 hipEvent_t take_event() {
     if (!g_event_pool.empty()) {
@@ -120,24 +133,32 @@ void drain_locked() {
 }
 void drain_entry(ProfEntry& p) {
     {
-        for (auto& ev : p.pending) {
+        for (size_t q = 0; q < p.pending.size(); ++q) {
+            auto& ev = p.pending[q];
             float ms = 0.f;
             if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
                 p.total_ms += ms;
                 p.count++;
+                float a = 0.f;
+                if (p.pending_tl[q] && g_timeline_base && hipEventElapsedTime(&a, g_timeline_base, ev.first) == hipSuccess)
+                    g_timeline.push_back({p.name, a, a + ms, p.pending_tl[q]});
             }
             g_event_pool.push_back(ev.first);
             g_event_pool.push_back(ev.second);
         }
         p.pending.clear();
+        p.pending_tl.clear();
     }
 }
 }  // namespace
 
-bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop) {
     if (!g_prof_on) return false;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_filter.empty() && g_prof_filter != name) return false;
+    if (!g_prof_filter.empty()) {  // one name, or several separated by commas
+        const std::string f = "," + g_prof_filter + ",";
+        if (f.find("," + std::string(name) + ",") == std::string::npos) return false;
+    }
     int slot = -1;
     for (size_t i = 0; i < g_prof.size(); ++i)
         if (g_prof[i].name == name) slot = static_cast<int>(i);
@@ -150,6 +171,7 @@ bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop) {
     hipEvent_t a = take_event(), b = take_event();
     if (!a || !b) return false;
     g_prof[slot].pending.push_back({a, b});
+    g_prof[slot].pending_tl.push_back(g_timeline_on ? (stream ? static_cast<const void*>(stream) : static_cast<const void*>(&g_timeline_on)) : nullptr);
     *start = a, *stop = b;
     return true;
 }
@@ -159,6 +181,26 @@ bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop) {
 extern "C" int scal_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(scal::g_prof_mu);
     scal::g_prof_on = on != 0;
+    return SCAL_OK;
+}
+extern "C" int scal_prof_timeline(int on) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    if (on && !scal::g_timeline_base) {
+        if (hipEventCreate(&scal::g_timeline_base) != hipSuccess) return SCAL_E_HIP;
+        if (hipEventRecord(scal::g_timeline_base, nullptr) != hipSuccess) return SCAL_E_HIP;
+        if (hipEventSynchronize(scal::g_timeline_base) != hipSuccess) return SCAL_E_HIP;
+    }
+    scal::g_timeline_on = on != 0;
+    return SCAL_OK;
+}
+extern "C" int scal_prof_timeline_dump(const char* path) {
+    std::lock_guard<std::mutex> lk(scal::g_prof_mu);
+    scal::drain_locked();
+    FILE* f = std::fopen(path, "w");
+    if (!f) return SCAL_E_ARG;
+    for (auto& r : scal::g_timeline) std::fprintf(f, "%s,%.6f,%.6f,%p\n", r.name.c_str(), r.t0, r.t1, r.stream);
+    std::fclose(f);
+    scal::g_timeline.clear();
     return SCAL_OK;
 }
 extern "C" int scal_prof_filter(const char* kernel_name) {

@@ -38,7 +38,7 @@ int select_device(int device);
 // scans overlap the way the reference's four ROS nodes do; every hand-over between contexts is ordered by events in both
 // directions (features_wait_done / features_note_reader).  Lane 5 is free for a context that must not queue behind another one
 // of its kind (scal_sc_config::side_stream = 5: the sharded database next to the descriptor builder, bench.py --gpus N).
-enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4 };
+enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4, STAGE_MAP_PREFETCH = 2 };
 int stage_lane(int stage);
 int acquire_stream(int device, hipStream_t* out, int lane = 0);
 void release_stream(int device, int lane = 0);
@@ -109,12 +109,12 @@ inline int div_up(int a, int b) { return (a + b - 1) / b; }
 // (hipExtLaunchKernelGGL), so they read the dispatch's begin/end timestamps and put no extra packet on the stream: separate
 // hipEventRecord calls cost ~5 us of stream time each, more than many of the kernels they would bracket.
 // Disabled by default: SCAL_LAUNCH_PROF is then one branch + a plain launch.
-bool prof_begin(const char* name, hipEvent_t* start, hipEvent_t* stop);
+bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);
 
 #define SCAL_LAUNCH_PROF(name, kernel, grid, block, lds, stream, ...)                                   \
     do {                                                                                                \
         hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                      \
-        if (::scal::prof_begin(name, &pe0_, &pe1_))                                                     \
+        if (::scal::prof_begin(name, stream, &pe0_, &pe1_))                                                     \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, pe0_, pe1_, 0, __VA_ARGS__);        \
         else                                                                                            \
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                          \

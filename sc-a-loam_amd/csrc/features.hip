@@ -846,21 +846,21 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
         }
     c->done_recorded = false;
     ev_lk.unlock();
-    hipLaunchKernelGGL(k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
-    hipLaunchKernelGGL(k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
-    hipLaunchKernelGGL(k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
+    SCAL_LAUNCH_PROF("k_pre", k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
+    SCAL_LAUNCH_PROF("k_classify", k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
+    SCAL_LAUNCH_PROF("k_ringscan", k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
+    SCAL_LAUNCH_PROF("k_scatter", k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
                        c->oz.p, c->oi.p, c->d_src.p);
     const int nb256 = max(1, div_up(n, 256));
-    hipLaunchKernelGGL(k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p);
+    SCAL_LAUNCH_PROF("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p);
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
     {
         SCAL_LAUNCH_PROF("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
                        c->d_gap.p, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->sx.p, c->sy.p, c->sz.p, c->si.p);
     }
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
+    SCAL_LAUNCH_PROF("k_finalize", k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p);
-    hipLaunchKernelGGL(k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
+    SCAL_LAUNCH_PROF("k_compact", k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->f_sharp.p, c->f_less.p, c->f_flat.p);
     SCAL_HIP(hipGetLastError());
     ev_lk.lock();
@@ -923,12 +923,12 @@ extern "C" int scal_features_fetch(scal_features_t* c, scal_features_out* o) {
     const int nk = P.n_kept;
     const int nb = max(1, div_up(nk, 256));
     if (o->cloud && nk) {
-        hipLaunchKernelGGL(k_interleave, dim3(nb), dim3(256), 0, s, &c->d_P.p->n_kept, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_aos.p);
+        SCAL_LAUNCH_PROF("k_interleave", k_interleave, dim3(nb), dim3(256), 0, s, &c->d_P.p->n_kept, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_aos.p);
         SCAL_HIP(hipMemcpyAsync(o->cloud, c->d_aos.p, sizeof(float) * 4 * nk, hipMemcpyDeviceToHost, s));
         SCAL_HIP(hipStreamSynchronize(s));
     }
     if (o->less_flat && P.n_less_flat) {
-        hipLaunchKernelGGL(k_interleave, dim3(max(1, div_up(P.n_less_flat, 256))), dim3(256), 0, s, &c->d_P.p->n_less_flat, c->lx.p, c->ly.p,
+        SCAL_LAUNCH_PROF("k_interleave", k_interleave, dim3(max(1, div_up(P.n_less_flat, 256))), dim3(256), 0, s, &c->d_P.p->n_less_flat, c->lx.p, c->ly.p,
                            c->lz.p, c->li.p, c->d_aos.p);
         SCAL_HIP(hipMemcpyAsync(o->less_flat, c->d_aos.p, sizeof(float) * 4 * P.n_less_flat, hipMemcpyDeviceToHost, s));
         SCAL_HIP(hipStreamSynchronize(s));

@@ -305,7 +305,12 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 // Trust-region bookkeeping after one evaluation (TrustRegionMinimizer: IterationZero / candidate evaluation).
 __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phase) {
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
+    // max-norm of x - Plus(x, -g), only ever compared with gradient_tolerance.  The translation part of that difference is g_t
+    // itself (up to the rounding of x - (x - g), far below the tolerance's scale), so when one of its components already exceeds
+    // the tolerance by a factor of two the answer is known without the quaternion exponential (sqrt, sin, cos, a division).
     auto grad_max_norm = [&]() {
+        const double gt = fmax(fmax(fabs(st->g[3]), fabs(st->g[4])), fabs(st->g[5]));
+        if (gt > 2.0 * gradient_tolerance && gt > 1e-6 * (1.0 + fmax(fmax(fabs(st->x[4]), fabs(st->x[5])), fabs(st->x[6])))) return gt;
         double neg[6], proj[7], m = 0.0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) neg[a] = -st->g[a];
@@ -536,7 +541,7 @@ static __global__ void __launch_bounds__(256) k_publish(const void* a, void* hos
 template <class A, class B>
 inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* host_b) {
     static_assert(sizeof(A) % 4 == 0 && sizeof(B) % 4 == 0, "word copies");
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, static_cast<const void*>(a), static_cast<void*>(host_a),
+    SCAL_LAUNCH_PROF("k_publish", k_publish, dim3(1), dim3(256), 0, s, static_cast<const void*>(a), static_cast<void*>(host_a),
                        a ? static_cast<int>(sizeof(A) / 4) : 0, static_cast<const void*>(b), static_cast<void*>(host_b),
                        b ? static_cast<int>(sizeof(B) / 4) : 0);
 }

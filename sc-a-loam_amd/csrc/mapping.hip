@@ -110,14 +110,13 @@ struct GridPts {
 };
 struct GridArgs {
     MapCloud m[2];
-    int* cnt[2];
+    int2* cell[2];  // per cell (count, start in the point pool): one 8-byte load per neighbour cell
     int* rank[2];
-    int* start[2];
     GridPts g[2];
 };
 // Fixed launch shape (the map sizes are device words): a quarter of the blocks walks the corner map, the rest the surf map,
 // each with a block-stride loop.  `i0` is the first point of this block's current tile, uniform over the block.
-constexpr int GRID_BLOCKS = 512;
+constexpr int GRID_BLOCKS = 2048;
 __device__ __forceinline__ void grid_part(int& cls, int& first, int& stride) {
     const int nb0 = gridDim.x / 4;
     const int b = blockIdx.x;
@@ -142,7 +141,7 @@ __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* 
         bool v = false;
         if (in && cube_valid(mp, m.cube[i])) {
             v = true;
-            a.rank[cls][i] = atomicAdd(&a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])], 1);
+            a.rank[cls][i] = atomicAdd(&a.cell[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])].x, 1);
         } else if (in) {
             a.rank[cls][i] = -1;
         }
@@ -170,13 +169,13 @@ __global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, const MapState* 
         int c = -1, mine = 0;
         if (i < n && a.rank[cls][i] == 0) {
             c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-            mine = a.cnt[cls][c];
+            mine = a.cell[cls][c].x;
         }
         int total = 0;
         const int off = block_exclusive_scan(mine, s_scan, &total);
         if (threadIdx.x == 0) s_base = total ? atomicAdd(&C->cursor[cls], total) : 0;
         __syncthreads();
-        if (c >= 0) a.start[cls][c] = s_base + off;
+        if (c >= 0) a.cell[cls][c].y = s_base + off;
         __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555
@@ -193,7 +192,7 @@ __global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, const MapState* _
     for (int i = first + threadIdx.x; i < n; i += stride) {
         if (a.rank[cls][i] >= 0) {
             const int c = grid_cell(mp, m.x[i], m.y[i], m.z[i]);
-            const int p = a.start[cls][c] + a.rank[cls][i];
+            const int p = a.cell[cls][c].y + a.rank[cls][i];
             g.p[p] = make_float4(m.x[i], m.y[i], m.z[i], __int_as_float(i));
         }
     }
@@ -206,7 +205,7 @@ __global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* 
     const int n = S->n_map[cls];
     const MapCloud& m = a.m[cls];
     for (int i = first + threadIdx.x; i < n; i += stride)
-        if (a.rank[cls][i] >= 0) a.cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;
+        if (a.rank[cls][i] >= 0) a.cell[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])].x = 0;
 }
 
 // ---------------------------------------------------------------------------------------------- association
@@ -218,7 +217,7 @@ __global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* 
 // map index) keys stay in registers and five wave-argmin rounds per chunk pick the result.
 // Every lane returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
 constexpr int KNN_CHUNK = 256;
-__device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __restrict__ cnt, const int* __restrict__ start, const GridPts& g,
+__device__ __forceinline__ void knn5_wave(const MapParams& mp, const int2* __restrict__ cell, const GridPts& g,
                                           float qx, float qy, float qz, unsigned long long (&bk)[5], int (&bp)[5]) {
     const int lane = lane_id();
 #pragma unroll
@@ -230,9 +229,8 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int* __rest
     if (inside && lane < 27) {
         const int xx = cx + (lane % 3) - 1, yy = cy + ((lane / 3) % 3) - 1, zz = cz + (lane / 9) - 1;
         if (xx >= 0 && xx < GX && yy >= 0 && yy < GY && zz >= 0 && zz < GZ) {
-            const int c = xx + GX * (yy + GY * zz);
-            my_cnt = cnt[c];
-            if (my_cnt) my_start = start[c];
+            const int2 h = cell[xx + GX * (yy + GY * zz)];
+            my_cnt = h.x, my_start = h.y;
         }
     }
     const int incl = wave_inclusive_scan(my_cnt);
@@ -431,9 +429,8 @@ struct NNBuf {
 // k_assoc_knn: one WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
 // many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
 // so it wants every lane busy with a different point).
-__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const MapState* __restrict__ S, const int* __restrict__ ccnt,
-                                                   const int* __restrict__ cstart, GridPts cg, const int* __restrict__ scnt,
-                                                   const int* __restrict__ sstart, GridPts sg, const LMState* __restrict__ st,
+__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, GridPts cg,
+                                                   const int2* __restrict__ scell, GridPts sg, const LMState* __restrict__ st,
                                                    const MapCounters* __restrict__ C, NNBuf nb) {
     if (S->abort || !C->solve_on) return;
     const MapParams mp = S->mp;
@@ -454,9 +451,9 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const Map
         int bp[5];
         const GridPts& g = is_edge ? cg : sg;
         if (is_edge)
-            knn5_wave(mp, ccnt, cstart, cg, sel[0], sel[1], sel[2], bk, bp);
+            knn5_wave(mp, ccell, cg, sel[0], sel[1], sel[2], bk, bp);
         else
-            knn5_wave(mp, scnt, sstart, sg, sel[0], sel[1], sel[2], bk, bp);
+            knn5_wave(mp, scell, sg, sel[0], sel[1], sel[2], bk, bp);
         // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
         int mine = bp[0];
 #pragma unroll
@@ -534,15 +531,6 @@ __global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, 
         f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
         f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
     }
-}
-
-__global__ void k_keep_error(const VoxMeta* m, MapCounters* C) {
-    if (m->error) C->error = m->error;
-}
-// after both stack filters: propagate their verdict, fix the number of residual-block slots
-__global__ void k_after_stack(const VoxMeta* m, MapCounters* C, int cap) {
-    if (m->error) C->error = m->error;
-    C->n_slots = min(C->n_corner_stack + C->n_surf_stack, cap);
 }
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
@@ -672,7 +660,9 @@ constexpr int MERGE_SAMPLES = 4096;  // old keys staged in LDS for the two-level
 struct MergeNew {            // per class, MERGE_MAX entries
     float *x, *y, *z, *w;    // new points in the map frame, arrival order
     int* cube;
-    unsigned long long* sorted;  // (key << 13 | arrival index), ascending; n_eff entries
+    unsigned long long* pkey;    // (key << 13 | arrival index) in arrival order, ~0 = outside the cube window (k_map_pose_done)
+    unsigned long long* sorted;  // the same, ascending; n_eff entries
+    unsigned long long* samp;    // [MERGE_MAX / 16] key of every 16th sorted entry (top level of k_merge_write's search)
     int* pre;                    // inserted (unmatched) runs that start before sorted position t, counted inside t's 512-block
     int* lb;                     // run heads: number of old points in front of the run
     unsigned char* hm;           // bit 0: run head, bit 1: run joins an old point
@@ -686,7 +676,7 @@ struct MergeArgs {
     unsigned long long* okeys[2];  // keys of the old points
     MergeNew nw[2];
     int cap;
-    int* grid_cnt[2];              // cell counters of the neighbour grid: restored to zero here (saves a launch)
+    int2* grid_cell[2];            // cell headers of the neighbour grid: counts restored to zero here (saves a launch)
     const int* grid_rank[2];
 };
 // Launch shapes (the map sizes are device words, so the old points are walked with block-stride loops):
@@ -698,15 +688,15 @@ constexpr int MERGE_CHUNKS = MERGE_MAX / 512;
 constexpr int MERGE_KB0 = 24, MERGE_KB1 = 88;
 constexpr int MERGE_KEYS_GRID = MERGE_KB0 + MERGE_KB1 + 2 * MERGE_CHUNKS;
 constexpr int MERGE_NEW_BLOCKS = MERGE_MAX / 256;
-constexpr int MERGE_WB0 = 96, MERGE_WB1 = 352;
+constexpr int MERGE_WB0 = 256, MERGE_WB1 = 1536;
 constexpr int MERGE_WRITE_GRID = MERGE_WB0 + MERGE_WB1 + 2 * MERGE_NEW_BLOCKS;
 
 __device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >> 27) == MAP_NOMERGE; }
 
 // Old points: their keys, the sortedness check, the zero invariant of the cell grid.  New points: every sorting block stages ALL
-// new keys of its class in LDS (map-frame point + key are cheap to recompute), sorts the 512-chunks in registers (one wave
-// each), then ranks the keys of ITS chunk against the other chunks with binary searches - rank = sorted position, the keys are
-// distinct because they carry the arrival index - and scatters them.  No merge network across workgroups, no second launch.
+// new keys of its class in LDS (written by k_map_pose_done), sorts the 512-chunks in registers (one wave each), then ranks the
+// keys of ITS chunk against the other chunks with binary searches - rank = sorted position, the keys are distinct because they
+// carry the arrival index - and scatters them.  No merge network across workgroups, no second launch.
 __global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
     if (S->abort) return;
     extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX packed keys
@@ -722,7 +712,7 @@ __global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState*
         for (int i = b * 1024 + threadIdx.x; i < n_old; i += nblk * 1024) {
             const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
             a.okeys[cls][i] = k;
-            if (a.grid_rank[cls][i] >= 0) a.grid_cnt[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])] = 0;  // zero invariant of the cell grid
+            if (a.grid_rank[cls][i] >= 0) a.grid_cell[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])].x = 0;  // zero invariant of the cell grid
             bool bad = k == ~0ull;
             if (i > 0) {
                 const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
@@ -739,22 +729,11 @@ __global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState*
     const int nc = (n_new + 511) >> 9;
     if (tile == 0 && threadIdx.x == 0 && (ns > MERGE_MAX || S->n_map[cls] + ns > a.cap || !S->window_same)) C->merge_fail = 1;
     if (tile > 0 && tile >= nc) return;
-    double x7[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-    const CSoA4 stack = a.stack[cls];
     const MergeNew nw = a.nw[cls];
     int mine = 0;
     for (int i = threadIdx.x; i < nc * 512; i += 1024) {
-        unsigned long long pk = ~0ull;
-        if (i < n_new) {
-            float sel[3];
-            associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);  // :740 / :764
-            const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
-            const unsigned long long k = map_key(mp, a.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
-            if (k != ~0ull) pk = (k << MERGE_IDX_BITS) | static_cast<unsigned long long>(i), ++mine;
-            if ((i >> 9) == tile) nw.x[i] = sel[0], nw.y[i] = sel[1], nw.z[i] = sel[2], nw.w[i] = stack.w[i], nw.cube[i] = pc;
-        }
+        const unsigned long long pk = i < n_new ? nw.pkey[i] : ~0ull;
+        mine += pk != ~0ull;
         sk[i] = pk;
     }
     int n_eff = 0;
@@ -844,6 +823,7 @@ __global__ void __launch_bounds__(512) k_merge_lookup(MergeArgs a, const MapStat
         nw.hm[t] = (head ? 1 : 0) | (matched ? 2 : 0);
         nw.lb[t] = lo;
         nw.pre[t] = pre;
+        if ((t & 15) == 0) nw.samp[t >> 4] = key;
     }
     if (threadIdx.x == 0) nw.blocktot[blk] = total;
 }
@@ -857,6 +837,7 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
         return;
     }
     __shared__ int s_base[MERGE_CHUNKS + 1];
+    __shared__ unsigned long long s_samp[MERGE_MAX / 16];
     int b = blockIdx.x;
     int cls, part, nblk;
     if (b < MERGE_WB0) cls = 0, part = 0, nblk = MERGE_WB0;
@@ -867,11 +848,18 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
     const MergeNew nw = a.nw[cls];
     const int n_eff = C->merge_neff[cls];
     const int n_old = S->n_map[cls];
+    if (part == 0 && b * 256 >= n_old && b > 0) return;  // nothing to do (block 0 of each class always commits the new size)
+    const int n_samp = (n_eff + 15) >> 4;
+    if (part == 0)
+        for (int q = threadIdx.x; q < n_samp; q += 256) s_samp[q] = nw.samp[q];
+    if (threadIdx.x < MERGE_CHUNKS) s_base[threadIdx.x + 1] = nw.blocktot[threadIdx.x];
+    __syncthreads();
     if (threadIdx.x == 0) {  // inserted runs in front of every 512-block
         int run = 0;
         for (int q = 0; q < MERGE_CHUNKS; ++q) {
+            const int v = s_base[q + 1];
             s_base[q] = run;
-            run += nw.blocktot[q];
+            run += v;
         }
         s_base[MERGE_CHUNKS] = run;
     }
@@ -886,7 +874,18 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
     if (part == 0) {
         for (int i = b * 256 + threadIdx.x; i < n_old; i += nblk * 256) {
             const unsigned long long k = a.okeys[cls][i];
-            int lo = 0, hi = n_eff;
+            int lo, hi;
+            {   // two-level lower bound among the sorted new keys: samples in LDS, then a window of <= 16 entries
+                int x = 0, y = n_samp;
+                while (x < y) {
+                    const int mid = (x + y) >> 1;
+                    if (s_samp[mid] < k) x = mid + 1;
+                    else y = mid;
+                }
+                lo = x > 0 ? (x - 1) * 16 + 1 : 0;
+                hi = min(n_eff, x * 16);
+                if (lo > hi) lo = hi;
+            }
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if ((nw.sorted[mid] >> MERGE_IDX_BITS) < k) lo = mid + 1;
@@ -941,9 +940,10 @@ __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __
 
 // Start of a device-resident step in ONE launch: clears the per-scan counters and copies the lessSharp cloud (xyzi records)
 // and the lessFlat cloud (SoA) of a features context into corner_in / surf_in.  Blocks [0,nbc) corner, the rest surf.
+// surf_box != null: the bounding box of the surf cloud is folded into that VoxMeta on the way (stands in for k_vox_bbox).
 __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ less_aos, const int* __restrict__ d_n_less, CSoA4 less_flat,
                                                     const int* __restrict__ d_n_less_flat, SoA4 corner_in, SoA4 surf_in, MapCounters* C, int cap,
-                                                    int nbc) {
+                                                    int nbc, VoxMeta* surf_box) {
     const bool corner = static_cast<int>(blockIdx.x) < nbc;
     const int b = corner ? blockIdx.x : blockIdx.x - nbc;
     const int n = min(corner ? *d_n_less : *d_n_less_flat, cap);
@@ -953,12 +953,18 @@ __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ le
         for (int t = 2 + threadIdx.x; t < static_cast<int>(sizeof(MapCounters) / sizeof(int)); t += 256) w[t] = 0;
     }
     if (i == 0) (corner ? C->n_corner_in : C->n_surf_in) = n;
-    if (i >= n) return;
     if (corner) {
+        if (i >= n) return;
         const float4 p = reinterpret_cast<const float4*>(less_aos)[i];
         corner_in.x[i] = p.x, corner_in.y[i] = p.y, corner_in.z[i] = p.z, corner_in.w[i] = p.w;
     } else {
-        surf_in.x[i] = less_flat.x[i], surf_in.y[i] = less_flat.y[i], surf_in.z[i] = less_flat.z[i], surf_in.w[i] = less_flat.w[i];
+        if (b * 256 >= n) return;  // uniform over the block
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < n) {
+            x = less_flat.x[i], y = less_flat.y[i], z = less_flat.z[i];
+            surf_in.x[i] = x, surf_in.y[i] = y, surf_in.z[i] = z, surf_in.w[i] = less_flat.w[i];
+        }
+        if (surf_box) vox_bbox_accumulate(surf_box, i < n, x, y, z);
     }
 }
 
@@ -995,9 +1001,11 @@ struct MapPoseIn {
 // The pointer shuffles of :324-508 are offset updates; the slabs they clear are dropped by the next re-filter.
 // allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
 // raises the sticky abort flag instead - the host then redoes this step on the general path and replays what was queued behind.
-__global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_window_change, float inv_line, float inv_plane) {
+__global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_window_change, float inv_line, float inv_plane, MapCounters* C,
+                            int slot_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (S->abort) return;
+    C->n_slots = min(C->n_corner_stack + C->n_surf_stack, slot_cap);  // residual-block slots (both stack filters have finished)
     double x0[7];
     m_qmul(S->q_wmap_wodom, in.q_wodom, x0);
     double rt[3];
@@ -1051,8 +1059,37 @@ __device__ __forceinline__ void copy_words(void* dst, const void* src, int bytes
     for (int i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
 }
 
-// After the solve: transformUpdate (:149-153) on the device, then pose, statistics and state go to the host slot.
-__global__ void __launch_bounds__(256) k_map_pose_done(MapState* S, const LMState* st, const MapCounters* C, MapResult* host) {
+// After the solve.  Block 0: transformUpdate (:149-153) on the device, then pose, statistics and state go to the host slot.
+// The other blocks (MERGE_NEW_BLOCKS per class) already prepare the insertion: the scan's stack points in the map frame
+// (:740 / :764), their cube and their packed sort key, once, for every consumer of the merge insert.
+struct PoseDoneNew {
+    CSoA4 stack[2];
+    const int* d_ns[2];
+    float inv_leaf[2];
+    float *x[2], *y[2], *z[2], *w[2];
+    int* cube[2];
+    unsigned long long* pkey[2];
+};
+__global__ void __launch_bounds__(256) k_map_pose_done(MapState* S, const LMState* st, MapCounters* C, MapResult* host, PoseDoneNew nw) {
+    if (blockIdx.x > 0) {
+        if (S->abort) return;
+        const int b = blockIdx.x - 1;
+        const int cls = b / MERGE_NEW_BLOCKS;
+        const int i = (b % MERGE_NEW_BLOCKS) * 256 + threadIdx.x;
+        if (i >= min(*nw.d_ns[cls], MERGE_MAX)) return;
+        const MapParams mp = S->mp;
+        double x7[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
+        float sel[3];
+        const CSoA4 stack = nw.stack[cls];
+        associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);
+        const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
+        const unsigned long long k = map_key(mp, nw.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
+        nw.x[cls][i] = sel[0], nw.y[cls][i] = sel[1], nw.z[cls][i] = sel[2], nw.w[cls][i] = stack.w[i], nw.cube[cls][i] = pc;
+        nw.pkey[cls][i] = k == ~0ull ? ~0ull : ((k << MERGE_IDX_BITS) | static_cast<unsigned long long>(i));
+        return;
+    }
     if (threadIdx.x == 0 && !S->abort) {
         // q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
         const double* q_wodom = S->q_wodom;
@@ -1103,7 +1140,8 @@ struct MapStore {
 };
 
 struct GridStore {
-    DevBuf<int> cnt, start, rank;
+    DevBuf<int2> cell;
+    DevBuf<int> rank;
     DevBuf<float4> g;
     GridPts pts() { return GridPts{g.p}; }
 };
@@ -1135,6 +1173,7 @@ struct scal_map {
     int lane = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // side stream for scal_map_prefetch_features (lazily acquired)
+    int side_lane = 2;
     static constexpr int NSETS = 8;      // input sets: steps in flight (<= MAX_STEPS) + prefetches queued ahead (<= MAX_PF) + 1
     static constexpr int MAX_STEPS = 4;  // steps whose insertion has not been confirmed
     static constexpr int MAX_PF = 3;
@@ -1147,7 +1186,10 @@ struct scal_map {
     Prefetch pf[MAX_PF];
     int n_pf = 0;
     int next_set = 0;  // ring allocation of input sets
-    hipEvent_t ev_pre[NSETS] = {};
+    hipEvent_t ev_pre[NSETS] = {};    // side stream: surf stack ready
+    hipEvent_t ev_pre_a[NSETS] = {};  // features stream: corner stack ready
+    hipEvent_t ev_gather[NSETS] = {}; // features stream: inputs gathered
+    bool pre_a_used[NSETS] = {};
     std::deque<MapStep> steps;
     hipEvent_t ev_pose[NSLOTS] = {}, ev_done[NSLOTS] = {};
     int next_slot = 0;
@@ -1169,7 +1211,7 @@ struct scal_map {
     SoAStore& surf_in(int st) { return surf_in2[st]; }
     SoAStore& corner_stack(int st) { return corner_stack2[st]; }
     SoAStore& surf_stack(int st) { return surf_stack2[st]; }
-    VoxelFilter vf, vf_side;  // main stream / prefetch stream: no shared scratch
+    VoxelFilter vf, vf_side, vf_corner;  // main stream / prefetch (surf) / prefetch (corner, behind stage A): no shared scratch
     MapStore map[2];  // corner, surf
     GridStore grid[2];
     RadixSort sorter;
@@ -1180,10 +1222,10 @@ struct scal_map {
     int last_insert_path = 0;  // 0 full sort, 1 merge
     SoAStore mnew[2];
     DevBuf<int> mcube[2], mpre[2], mlb[2], mblocktot[2];
-    DevBuf<unsigned long long> msorted[2];
+    DevBuf<unsigned long long> msorted[2], mpkey[2], msamp[2];
     DevBuf<unsigned char> mhm[2];
     MergeNew merge_new(int k) {
-        return MergeNew{mnew[k].x.p, mnew[k].y.p, mnew[k].z.p, mnew[k].w.p, mcube[k].p, msorted[k].p, mpre[k].p, mlb[k].p, mhm[k].p, mblocktot[k].p};
+        return MergeNew{mnew[k].x.p, mnew[k].y.p, mnew[k].z.p, mnew[k].w.p, mcube[k].p, mpkey[k].p, msorted[k].p, msamp[k].p, mpre[k].p, mlb[k].p, mhm[k].p, mblocktot[k].p};
     }
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
@@ -1232,12 +1274,13 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
     A(c->vf.init(c->scan_cap));
     A(c->vf_side.init(c->scan_cap));
+    A(c->vf_corner.init(8192));
     for (int k = 0; k < 2; ++k) {
         for (int b = 0; b < 2; ++b) {
             A(c->map[k].pts[b].alloc(mc));
             A(c->map[k].cube[b].alloc(mc));
         }
-        A(c->grid[k].cnt.alloc(GCELLS)); A(c->grid[k].start.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
+        A(c->grid[k].cell.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
         A(c->grid[k].g.alloc(mc));
     }
     A(c->sorter.init(c->map_cap));
@@ -1245,6 +1288,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     for (int k = 0; k < 2; ++k) {
         A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
         A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX)); A(c->mblocktot[k].alloc(MERGE_CHUNKS));
+        A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 16));
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
@@ -1261,9 +1305,10 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     if (rc == SCAL_OK) {
         // Everything is initialised on the context's own stream (the legacy null stream is not ordered against it).
         // The cell counters obey a zero invariant: every step clears exactly the cells it touched.
-        for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cnt.zero(c->stream);
+        for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cell.zero(c->stream);
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK) rc = c->vf_side.reset_box(c->stream);  // the prefetch's gather accumulates into it, every run leaves it reset
         MapState& H = *c->h_S.p;
         std::memset(&H, 0, sizeof H);
         H.q_wmap_wodom[3] = 1.0;
@@ -1289,10 +1334,13 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     }
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
-        release_stream(c->cfg.device, 2);
+        release_stream(c->cfg.device, c->side_lane);
     }
-    for (int k = 0; k < scal_map::NSETS; ++k)
+    for (int k = 0; k < scal_map::NSETS; ++k) {
         if (c->ev_pre[k]) (void)hipEventDestroy(c->ev_pre[k]);
+        if (c->ev_pre_a[k]) (void)hipEventDestroy(c->ev_pre_a[k]);
+        if (c->ev_gather[k]) (void)hipEventDestroy(c->ev_gather[k]);
+    }
     for (int k = 0; k < scal_map::NSLOTS; ++k) {
         if (c->ev_pose[k]) (void)hipEventDestroy(c->ev_pose[k]);
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
@@ -1302,18 +1350,29 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
 
 namespace {
 
-// stack downsample (:543-551) of corner_in / surf_in into corner_stack / surf_stack; independent of the pose
-int enqueue_stack_filters(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_corner_bound, int n_surf_bound, int st) {
+// stack downsample (:543-551) of corner_in / surf_in into corner_stack / surf_stack; independent of the pose.  The filters'
+// verdicts land in the counters from inside their last kernels.
+// surf_box_done: the gather has already folded the surf cloud's bounding box into vfs.meta.
+// Key bits: a stack cloud spans the sensor's range, <= 1024 voxels per axis at the launch files' resolutions -> three radix passes.
+int enqueue_corner_filter(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_corner_bound, int st) {
     MapCounters* C = c->d_C(st).p;
-    SCAL_TRY(vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, 36, c->corner_stack(st).v(), &C->n_corner_stack));
-    if (n_corner_bound <= 8192 && n_surf_bound > 8192) {
-        // the two filters share one VoxMeta: keep the small-path verdict of the corner cloud
-        hipLaunchKernelGGL(k_keep_error, dim3(1), dim3(1), 0, s, vf.meta.p, C);
-    }
-    SCAL_TRY(vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, 36, c->surf_stack(st).v(), &C->n_surf_stack));
-    hipLaunchKernelGGL(k_after_stack, dim3(1), dim3(1), 0, s, vf.meta.p, C, c->slot_cap);
-    SCAL_HIP(hipGetLastError());
-    return SCAL_OK;
+    VoxTail tc;
+    tc.err_out = &C->error;
+    const int bits_c = c->cfg.line_res >= 0.35f ? 30 : 40;
+    return vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, bits_c, c->corner_stack(st).v(), &C->n_corner_stack, false, &tc);
+}
+int enqueue_surf_filter(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_surf_bound, int st, bool surf_box_done) {
+    MapCounters* C = c->d_C(st).p;
+    VoxTail ts;
+    ts.err_out = &C->error;
+    const int bits_s = c->cfg.plane_res >= 0.35f ? 30 : 40;
+    const bool box = surf_box_done && n_surf_bound > 8192;
+    return vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, bits_s, c->surf_stack(st).v(), &C->n_surf_stack, box, &ts);
+}
+int enqueue_stack_filters(scal_map* c, VoxelFilter& vfc, VoxelFilter& vfs, hipStream_t s, int n_corner_bound, int n_surf_bound, int st,
+                          bool surf_box_done) {
+    SCAL_TRY(enqueue_corner_filter(c, vfc, s, n_corner_bound, st));
+    return enqueue_surf_filter(c, vfs, s, n_surf_bound, st, surf_box_done);
 }
 
 GridArgs grid_args(scal_map* c, int par) {
@@ -1321,7 +1380,7 @@ GridArgs grid_args(scal_map* c, int par) {
     for (int k = 0; k < 2; ++k) {
         GridStore& G = c->grid[k];
         ga.m[k] = c->map[k].cloud(par);
-        ga.cnt[k] = G.cnt.p, ga.rank[k] = G.rank.p, ga.start[k] = G.start.p, ga.g[k] = G.pts();
+        ga.cell[k] = G.cell.p, ga.rank[k] = G.rank.p, ga.g[k] = G.pts();
     }
     return ga;
 }
@@ -1338,13 +1397,13 @@ int insert_full_sort(scal_map* c, const MapStep& e, const int* n_map) {
         MapCloud in = M.cloud(e.par), outc = M.cloud(e.par ^ 1);
         const CSoA4 stack = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
         const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        hipLaunchKernelGGL(k_insert_keys, dim3(nb), dim3(256), 0, s, in, c->d_S.p, stack, d_ns, st, 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res),
+        SCAL_LAUNCH_PROF("k_insert_keys", k_insert_keys, dim3(nb), dim3(256), 0, s, in, c->d_S.p, stack, d_ns, st, 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res),
                            c->map_cap, c->keys.p, c->vals.p, C, k);
         SortedPairs sp;
         SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
-        hipLaunchKernelGGL(k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
+        SCAL_LAUNCH_PROF("k_map_heads", k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
         launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
-        hipLaunchKernelGGL(k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
+        SCAL_LAUNCH_PROF("k_map_reduce", k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
     }
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
@@ -1363,7 +1422,7 @@ int launch_insert_merge(scal_map* c, const MapStep& e) {
         a.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
         a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
         a.nw[k] = c->merge_new(k);
-        a.grid_cnt[k] = c->grid[k].cnt.p, a.grid_rank[k] = c->grid[k].rank.p;
+        a.grid_cell[k] = c->grid[k].cell.p, a.grid_rank[k] = c->grid[k].rank.p;
     }
     a.cap = c->map_cap;
     static bool attr_set = false;
@@ -1372,9 +1431,9 @@ int launch_insert_merge(scal_map* c, const MapStep& e) {
         SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_keys), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
-    hipLaunchKernelGGL(k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
-    hipLaunchKernelGGL(k_merge_write, dim3(MERGE_WRITE_GRID), dim3(256), 0, s, a, c->d_S.p, C);
+    SCAL_LAUNCH_PROF("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
+    SCAL_LAUNCH_PROF("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
+    SCAL_LAUNCH_PROF("k_merge_write", k_merge_write, dim3(MERGE_WRITE_GRID), dim3(256), 0, s, a, c->d_S.p, C);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -1386,14 +1445,14 @@ int launch_tail(scal_map* c, const MapStep& e) {
         const int nb = std::max(1, div_up(c->scan_cap, 256));
         if (e.feat) {
             FeatDeviceView v = features_view(e.feat);
-            hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->scan_cap, c->d_st.p, c->d_S.p,
+            SCAL_LAUNCH_PROF("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->scan_cap, c->d_st.p, c->d_S.p,
                                c->full_out.v());
         } else {
-            hipLaunchKernelGGL(k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, c->scan_cap, c->d_st.p, c->d_S.p,
+            SCAL_LAUNCH_PROF("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, c->scan_cap, c->d_st.p, c->d_S.p,
                                c->full_out.v());
         }
     }
-    hipLaunchKernelGGL(k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_done[e.slot], s));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, s));  // the registration transform reads the full-resolution cloud last
@@ -1410,30 +1469,32 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
     MapState* S = c->d_S.p;
     if (e.feat) {
         if (e.prefetched) {
-            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled on the side stream
+            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled on the side stream ...
+            if (c->pre_a_used[st_]) SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre_a[st_], 0));  // ... the corner cloud behind stage A
         } else {
             FeatDeviceView v = features_view(e.feat);
             SCAL_TRY(features_wait_done(e.feat, s));
             const int nbc = std::max(1, div_up(e.n_corner_bound, 256));
-            hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
-                               CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st_).v(), c->surf_in(st_).v(), C, c->scan_cap, nbc);
+            SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
+                               CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st_).v(), c->surf_in(st_).v(), C, c->scan_cap, nbc,
+                               static_cast<VoxMeta*>(nullptr));
         }
     }
-    hipLaunchKernelGGL(k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res);
-    if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_));
+    if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
+    SCAL_LAUNCH_PROF("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
+                     c->slot_cap);
     // cell grids over the valid cubes (both classes per launch)
     const GridArgs ga = grid_args(c, e.par);
-    hipLaunchKernelGGL(k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-    hipLaunchKernelGGL(k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-    hipLaunchKernelGGL(k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
+    SCAL_LAUNCH_PROF("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+    SCAL_LAUNCH_PROF("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+    SCAL_LAUNCH_PROF("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
     // two outer iterations (:563)
     FactorSoA F = c->factors();
-    const int assoc_blocks = std::max(1, std::min(2048, div_up(c->slot_cap, 4)));
+    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
     for (int outer = 0; outer < 2; ++outer) {
         {
             SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
-                             c->grid[0].cnt.p, c->grid[0].start.p, c->grid[0].pts(), c->grid[1].cnt.p, c->grid[1].start.p, c->grid[1].pts(), st, C,
-                             c->nnbuf());
+                             c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), st, C, c->nnbuf());
         }
         {
             SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack(st_).cv(),
@@ -1441,7 +1502,15 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
         }
         launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort);
     }
-    hipLaunchKernelGGL(k_map_pose_done, dim3(1), dim3(256), 0, s, S, st, C, c->res.p + e.slot);
+    PoseDoneNew pn;
+    for (int k = 0; k < 2; ++k) {
+        pn.stack[k] = k == 0 ? c->corner_stack(st_).cv() : c->surf_stack(st_).cv();
+        pn.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        pn.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
+        pn.x[k] = c->mnew[k].x.p, pn.y[k] = c->mnew[k].y.p, pn.z[k] = c->mnew[k].z.p, pn.w[k] = c->mnew[k].w.p;
+        pn.cube[k] = c->mcube[k].p, pn.pkey[k] = c->mpkey[k].p;
+    }
+    SCAL_LAUNCH_PROF("k_map_pose_done", k_map_pose_done, dim3(1 + 2 * MERGE_NEW_BLOCKS), dim3(256), 0, s, S, st, C, c->res.p + e.slot, pn);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
     return SCAL_OK;
@@ -1468,7 +1537,7 @@ int run_general(scal_map* c, MapStep& e) {
     e.insert_path = 1;
     if (try_merge) {
         SCAL_TRY(launch_insert_merge(c, e));
-        hipLaunchKernelGGL(k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
+        SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
         SCAL_HIP(hipStreamSynchronize(s));
         if (R.S2.abort) {  // a case the merge does not cover: redo with the full sort
             SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
@@ -1478,7 +1547,7 @@ int run_general(scal_map* c, MapStep& e) {
         }
     } else {
         // restore the zero invariant of the cell counters (the merge insert does it in its key kernel)
-        hipLaunchKernelGGL(k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+        SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
     }
     if (!try_merge) {
         e.insert_path = 0;
@@ -1771,7 +1840,7 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
         return SCAL_E_ARG;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, 2));
+    if (!c->side) SCAL_TRY(acquire_stream(c->cfg.device, &c->side, c->side_lane = stage_lane(STAGE_MAP_PREFETCH)));
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
     std::lock_guard<std::mutex> lk(c->pf_mu);
@@ -1780,14 +1849,30 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
         return SCAL_E_STATE;
     }
     const int nset = c->alloc_set();
-    if (!c->ev_pre[nset]) SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], hipEventDisableTiming));
-    SCAL_TRY(features_wait_done(feat, c->side));
+    if (!c->ev_pre[nset]) {
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], hipEventDisableTiming));
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre_a[nset], hipEventDisableTiming));
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_gather[nset], hipEventDisableTiming));
+    }
+    // The gather (it also folds the surf cloud's bounding box into the filter's state) and the small corner filter ride on the
+    // features context's own stream, right behind stage A; the surf filter runs on the side stream.  (More than four busy streams
+    // slow every stream down on this GPU, and stage A's stream has room.)
+    hipStream_t sa = v.stream;
     const int nbc = std::max(1, div_up(ls_cap, 256));
-    hipLaunchKernelGGL(k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, c->side, v.less_xyzi, &v.P->n_less_sharp,
-                       CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc);
-    SCAL_TRY(enqueue_stack_filters(c, c->vf_side, c->side, ls_cap, cap, nset));
+    c->pre_a_used[nset] = ls_cap <= 8192;  // else the corner cloud takes the radix path on the side stream and owns vf_side's box first
+    SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, sa, v.less_xyzi, &v.P->n_less_sharp,
+                     CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc,
+                     c->pre_a_used[nset] ? c->vf_side.meta.p : static_cast<VoxMeta*>(nullptr));
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipEventRecord(c->ev_gather[nset], sa));
+    if (c->pre_a_used[nset]) {
+        SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, sa, ls_cap, nset));
+        SCAL_HIP(hipEventRecord(c->ev_pre_a[nset], sa));
+    }
+    SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_gather[nset], 0));
+    if (!c->pre_a_used[nset]) SCAL_TRY(enqueue_corner_filter(c, c->vf_side, c->side, ls_cap, nset));
+    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, c->pre_a_used[nset]));
     SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
-    SCAL_TRY(features_note_reader(feat, c->side));
     c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
     c->n_pf++;
     return SCAL_OK;
@@ -1876,7 +1961,7 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
     c->h_misc.p[1] = 0;
     SCAL_HIP(hipMemcpyAsync(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
     const int room = std::min(cap, c->scan_cap);
-    hipLaunchKernelGGL(k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
+    SCAL_LAUNCH_PROF("k_export_valid", k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
                        c->d_nfull.p + 1, c->aos.p, out_xyzi ? room : 0);
     SCAL_HIP(hipMemcpyAsync(c->h_misc.p + 2, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SCAL_HIP(hipStreamSynchronize(s));

@@ -433,7 +433,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
         if (hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        hipLaunchKernelGGL(k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
+        SCAL_LAUNCH_PROF("k_odom_init_pose", k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
         if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
     if (rc != SCAL_OK) {
@@ -509,7 +509,7 @@ int odom_enqueue(scal_odom* c) {
         h.nb0 = std::max(1, div_up(c->feat_cap, 256));
         h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
         h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
-        hipLaunchKernelGGL(k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
+        SCAL_LAUNCH_PROF("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
         c->tab_cur ^= 1;
     }
     SCAL_HIP(hipGetLastError());
@@ -632,7 +632,7 @@ extern "C" int scal_odom_enqueue_features(scal_odom_t* c, scal_features_t* feat)
     a.slot_cap = c->slot_cap, a.feat_cap = c->feat_cap, a.cap = std::min(c->cap, v.cap);
     a.nbs = std::max(1, div_up(c->slot_cap, 256)), a.nbf = std::max(1, div_up(c->feat_cap, 256));
     SCAL_TRY(features_wait_done(feat, s));
-    hipLaunchKernelGGL(k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
+    SCAL_LAUNCH_PROF("k_odom_gather", k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
     SCAL_TRY(features_note_reader(feat, s));  // everything stage B needs has been copied out of the features context
     return odom_enqueue(c);
 }

@@ -1,9 +1,9 @@
-// Stable LSD radix sort (9-bit digits) for gfx950.  Two kernels per pass:
+// Stable LSD radix sort (digits of up to 10 bits, width adapted to the key bits in use) for gfx950.  Two kernels per pass:
 //   k_rs_hist     per-block digit histogram (LDS atomics) -> histogram matrix
 //   k_rs_scatter  every block first derives its own scatter bases from the histogram matrix (sum of the earlier blocks'
 //                 counts per digit + exclusive prefix of the digit totals, 512 x nb L2-resident words - cheaper than a
 //                 separate scan launch while nb is small), then scatters stably: per wave, items are ranked with
-//                 ballot-based digit matching (9 ballots give the lanes holding the same digit), per-wave digit
+//                 ballot-based digit matching (ten ballots give the lanes holding the same digit), per-wave digit
 //                 counters live in LDS.
 // The element handled by (wave w, item j, lane l) of a block is base + w*ITEMS*64 + j*64 + l, so (w, j, l) order is
 // arrival order and equal keys keep their relative order.
@@ -14,31 +14,40 @@ namespace scal {
 
 constexpr int RS_ITEMS = RadixSort::ITEMS;
 constexpr int RS_TILE = RadixSort::TILE;
-constexpr int RS_DIGIT = RadixSort::DIGIT;
-constexpr int RS_BINS = RadixSort::BINS;
+constexpr int RS_DIGIT_MAX = RadixSort::DIGIT_MAX;
+constexpr int RS_BINS_MAX = RadixSort::BINS_MAX;
 
-__device__ __forceinline__ bool pass_active(const int* d_used_bits, int shift) { return d_used_bits == nullptr || shift < *d_used_bits; }
+// this pass's digit position; false when the pass has nothing to do.  used = *d_used_bits, or the host's max_bits
+__device__ __forceinline__ bool pass_plan(const int* d_used_bits, int max_bits, int pass, int& shift, int& width) {
+    const int used = d_used_bits ? *d_used_bits : max_bits;
+    int passes;
+    rs_plan(used, passes, width);
+    shift = pass * width;
+    return pass < passes;
+}
 
 // Histogram matrix layout: [block][digit] for ordinary sorts (a wave of the scatter kernel then reads 64 consecutive digits of
 // one block = one or two cache lines per load), [digit][block] for sorts that go through the hierarchical scan (its flattened
 // order must be digit-major).
-__global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int shift,
+__global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int pass, int max_bits,
                                                  const int* __restrict__ d_used_bits, int* __restrict__ hist, int digit_major) {
-    if (!pass_active(d_used_bits, shift)) return;
+    int shift, width;
+    if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
+    const int bins = 1 << width;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
     if (static_cast<int>(blockIdx.x) >= nb) return;
-    __shared__ int h[RS_BINS];
-    for (int i = threadIdx.x; i < RS_BINS; i += 256) h[i] = 0;
+    __shared__ int h[RS_BINS_MAX];
+    for (int i = threadIdx.x; i < bins; i += 256) h[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE;
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int e = base + j * 256 + threadIdx.x;
-        if (e < n) atomicAdd(&h[(keys[e] >> shift) & (RS_BINS - 1)], 1);
+        if (e < n) atomicAdd(&h[(keys[e] >> shift) & (bins - 1)], 1);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RS_BINS; i += 256) hist[digit_major ? i * nb + blockIdx.x : blockIdx.x * RS_BINS + i] = h[i];
+    for (int i = threadIdx.x; i < bins; i += 256) hist[digit_major ? i * nb + blockIdx.x : blockIdx.x * RS_BINS_MAX + i] = h[i];
 }
 
 __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int* __restrict__ d_n, int tile, int bins, int* __restrict__ d_total) {
@@ -60,49 +69,49 @@ __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int
 }
 
 __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
-                                                    const int* __restrict__ d_n, int shift, const int* __restrict__ d_used_bits,
+                                                    const int* __restrict__ d_n, int pass, int max_bits, const int* __restrict__ d_used_bits,
                                                     const int* __restrict__ hist, unsigned long long* __restrict__ okeys, int* __restrict__ ovals,
                                                     int scanned) {
-    if (!pass_active(d_used_bits, shift)) return;
+    int shift, width;
+    if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
+    const int bins = 1 << width;
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
     if (static_cast<int>(blockIdx.x) >= nb) return;
-    __shared__ int cnt[4][RS_BINS];
-    __shared__ int sbase[RS_BINS];
+    __shared__ int cnt[4][RS_BINS_MAX];
+    __shared__ int sbase[RS_BINS_MAX];
     __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
     // scatter base of digit d for this block = (exclusive prefix of the digit totals)[d] + sum_{b < block} hist[d][b]
     if (scanned) {  // large sorts: the histogram matrix has been turned into scatter bases by the hierarchical scan
-        sbase[2 * threadIdx.x] = hist[(2 * threadIdx.x) * nb + blockIdx.x];
-        sbase[2 * threadIdx.x + 1] = hist[(2 * threadIdx.x + 1) * nb + blockIdx.x];
+        for (int d = threadIdx.x; d < bins; d += 256) sbase[d] = hist[d * nb + blockIdx.x];
     } else {
-        int before[2] = {0, 0}, totals[2] = {0, 0};
-        // [block][digit] layout: thread t owns digits t and t + 256, so a wave reads 64 consecutive words of one block's row;
-        // the columns are walked in batches of 8 independent loads
+        // [block][digit] layout: thread t owns digits t, t + 256, ... so a wave reads 64 consecutive words of one block's row;
+        // the rows are walked in batches of 8 independent loads
         const int me = static_cast<int>(blockIdx.x);
-        for (int b0 = 0; b0 < nb; b0 += 8) {
-            int v0[8], v1[8];
+        int run = 0;  // digits below this group of 256
+        for (int g = 0; g < bins; g += 256) {
+            const int d = g + threadIdx.x;
+            int before = 0, total = 0;
+            if (d < bins) {
+                for (int b0 = 0; b0 < nb; b0 += 8) {
+                    int v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bool in = b0 + q < nb;
-                v0[q] = in ? hist[(b0 + q) * RS_BINS + threadIdx.x] : 0;
-                v1[q] = in ? hist[(b0 + q) * RS_BINS + 256 + threadIdx.x] : 0;
-            }
+                    for (int q = 0; q < 8; ++q) v[q] = b0 + q < nb ? hist[(b0 + q) * RS_BINS_MAX + d] : 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                totals[0] += v0[q], totals[1] += v1[q];
-                if (b0 + q < me) before[0] += v0[q], before[1] += v1[q];
+                    for (int q = 0; q < 8; ++q) {
+                        total += v[q];
+                        if (b0 + q < me) before += v[q];
+                    }
+                }
             }
+            int sum;
+            const int pre = block_exclusive_scan(total, smem, &sum);
+            if (d < bins) sbase[d] = run + pre + before;
+            run += sum;
         }
-        // exclusive prefix of the digit totals in digit order: digits 0..255 (one per thread), then 256..511
-        int sum_lo;
-        const int pre_lo = block_exclusive_scan(totals[0], smem, &sum_lo);
-        int sum_hi;
-        const int pre_hi = block_exclusive_scan(totals[1], smem, &sum_hi);
-        sbase[threadIdx.x] = pre_lo + before[0];
-        sbase[256 + threadIdx.x] = sum_lo + pre_hi + before[1];
     }
-    for (int i = threadIdx.x; i < 4 * RS_BINS; i += 256) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 4 * RS_BINS_MAX; i += 256) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
     unsigned long long k[RS_ITEMS];
@@ -112,8 +121,8 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
         const int e = base + j * 64 + l;
         const bool valid = e < n;
         k[j] = valid ? keys[e] : 0ull;
-        const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (RS_BINS - 1);
-        const uint64_t m = wave_match<RS_DIGIT>(d, valid);
+        const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (bins - 1);
+        const uint64_t m = wave_match<RS_DIGIT_MAX>(d, valid);
         int prev = 0;
         if (valid) prev = cnt[w][d];
         rk[j] = prev + __popcll(m & lanemask_lt());
@@ -126,7 +135,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int e = base + j * 64 + l;
         if (e < n) {
-            const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (RS_BINS - 1);
+            const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (bins - 1);
             int prew = 0;
             for (int ww = 0; ww < w; ++ww) prew += cnt[ww][d];
             const int pos = sbase[d] + prew + rk[j];
@@ -137,14 +146,15 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
 }
 
 // ---- hierarchical exclusive scan of the flattened histogram matrix (digit-major: exactly the scatter base of (digit, block)),
-// used when the sort has too many blocks for every scatter workgroup to sum the matrix rows itself.  m = BINS * nb.
+// used when the sort has too many blocks for every scatter workgroup to sum the matrix rows itself.  m = bins * nb.
 constexpr int HS_TILE = 4096;
-__global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data, const int* __restrict__ d_n, int shift,
+__global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
                                                      const int* __restrict__ d_used_bits, int* __restrict__ tile_sum) {
-    if (!pass_active(d_used_bits, shift)) return;
+    int shift, width;
+    if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
     __shared__ int smem[17];
     const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
-    const int m = RS_BINS * nb;
+    const int m = (1 << width) * nb;
     const int base = blockIdx.x * HS_TILE;
     if (base >= m) return;
     int sum = 0;
@@ -157,12 +167,13 @@ __global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data
     block_exclusive_scan(sum, smem, &total);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, const int* __restrict__ d_n, int shift,
+__global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, const int* __restrict__ d_n, int pass, int max_bits,
                                                     const int* __restrict__ d_used_bits) {
-    if (!pass_active(d_used_bits, shift)) return;
+    int shift, width;
+    if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
     __shared__ int smem[17];
     const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
-    const int nt = (RS_BINS * nb + HS_TILE - 1) / HS_TILE;
+    const int nt = ((1 << width) * nb + HS_TILE - 1) / HS_TILE;
     const int per = (nt + 1023) / 1024;
     const int b0 = min(nt, static_cast<int>(threadIdx.x) * per), b1 = min(nt, b0 + per);
     int sum = 0;
@@ -175,12 +186,13 @@ __global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, c
         run += v;
     }
 }
-__global__ void __launch_bounds__(1024) k_hs_apply(int* __restrict__ data, const int* __restrict__ d_n, int shift, const int* __restrict__ d_used_bits,
-                                                    const int* __restrict__ tile_off) {
-    if (!pass_active(d_used_bits, shift)) return;
+__global__ void __launch_bounds__(1024) k_hs_apply(int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
+                                                    const int* __restrict__ d_used_bits, const int* __restrict__ tile_off) {
+    int shift, width;
+    if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
     __shared__ int smem[17];
     const int nb = (*d_n + RS_TILE - 1) / RS_TILE;
-    const int m = RS_BINS * nb;
+    const int m = (1 << width) * nb;
     const int base = blockIdx.x * HS_TILE;
     if (base >= m) return;
     // thread t owns elements base + 4t .. base + 4t + 3 (consecutive), so one block scan orders the whole tile
@@ -205,8 +217,8 @@ int RadixSort::init(int capacity) {
     cap = capacity;
     SCAL_TRY(keys_alt.alloc(cap));
     SCAL_TRY(vals_alt.alloc(cap));
-    SCAL_TRY(hist.alloc((size_t)BINS * div_up(cap, TILE) + BINS));
-    SCAL_TRY(tile_sum.alloc(div_up(BINS * div_up(cap, TILE), HS_TILE) + 1));
+    SCAL_TRY(hist.alloc((size_t)BINS_MAX * div_up(cap, TILE) + BINS_MAX));
+    SCAL_TRY(tile_sum.alloc(div_up(BINS_MAX * div_up(cap, TILE), HS_TILE) + 1));
     return SCAL_OK;
 }
 
@@ -215,32 +227,30 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     unsigned long long* kb[2] = {keys, keys_alt.p};
     int* vb[2] = {vals, vals_alt.p};
     const int nb = max(1, div_up(min(cap, max(n_bound, 1)), TILE));
-    const bool big = nb > 256;  // every scatter workgroup summing 2 x nb matrix entries per thread stops paying off
-    const int nt = div_up(BINS * nb, HS_TILE);
-    int pass = 0;
-    for (int shift = 0; shift < max_bits; shift += DIGIT, ++pass) {
+    const bool big = nb > 256;  // every scatter workgroup summing the matrix rows itself stops paying off
+    const int nt = div_up(BINS_MAX * nb, HS_TILE);
+    const int passes = div_up(max_bits, DIGIT_MAX);
+    for (int pass = 0; pass < passes; ++pass) {
         const int in = pass & 1, o = in ^ 1;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, shift, d_used_bits, hist.p, big ? 1 : 0);
+        SCAL_LAUNCH_PROF("k_rs_hist", k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, pass, max_bits, d_used_bits, hist.p, big ? 1 : 0);
         if (big) {
-            hipLaunchKernelGGL(k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, shift, d_used_bits, tile_sum.p);
-            hipLaunchKernelGGL(k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, shift, d_used_bits);
-            hipLaunchKernelGGL(k_hs_apply, dim3(nt), dim3(1024), 0, s, hist.p, d_n, shift, d_used_bits, tile_sum.p);
+            SCAL_LAUNCH_PROF("k_hs_reduce", k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
+            SCAL_LAUNCH_PROF("k_hs_tiles", k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, pass, max_bits, d_used_bits);
+            SCAL_LAUNCH_PROF("k_hs_apply", k_hs_apply, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
         }
-        {
-            SCAL_LAUNCH_PROF("k_rs_scatter", k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, shift, d_used_bits, hist.p, kb[o], vb[o],
-                             big ? 1 : 0);
-        }
+        SCAL_LAUNCH_PROF("k_rs_scatter", k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, pass, max_bits, d_used_bits, hist.p, kb[o],
+                         vb[o], big ? 1 : 0);
     }
     out->keys[0] = kb[0], out->keys[1] = kb[1];
     out->vals[0] = vb[0], out->vals[1] = vb[1];
     out->d_used_bits = d_used_bits;
-    out->fixed_sel = d_used_bits ? -1 : (pass & 1);
+    out->fixed_sel = d_used_bits ? -1 : (passes & 1);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
 void launch_scan_inplace(hipStream_t s, int* data, const int* d_n, int tile, int bins, int* d_total) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, data, d_n, tile, bins, d_total);
+    SCAL_LAUNCH_PROF("k_scan", k_scan, dim3(1), dim3(1024), 0, s, data, d_n, tile, bins, d_total);
 }
 
 }  // namespace scal

@@ -1,14 +1,16 @@
-// Device-wide stable LSD radix sort of (uint64 key, int32 value) pairs (9-bit digits) and a small exclusive-scan
-// helper.  Counts live on the device (`d_n`): grids are sized for the capacity and surplus blocks exit, so a whole
-// kernel chain can be enqueued without a host round trip.  The number of key bits actually in use may also live on the
-// device (`d_used_bits`): passes above it return immediately and the result buffer is selected by parity on the device.
+// Device-wide stable LSD radix sort of (uint64 key, int32 value) pairs and a small exclusive-scan helper.  Counts live on the
+// device (`d_n`): grids are sized for the capacity and surplus blocks exit, so a whole kernel chain can be enqueued without a
+// host round trip.  The number of key bits actually in use may also live on the device (`d_used_bits`): the digit width adapts
+// to it - ceil(used / 10) passes of ceil(used / passes) bits each, at most 10 - so a 25..27-bit voxel key takes three passes of
+// nine bits and a 28..30-bit one three of ten; passes beyond that return immediately and the result buffer is selected by
+// parity on the device.  The host enqueues ceil(max_bits / 10) passes.
 #pragma once
 #include "common.hpp"
 
 namespace scal {
 
 struct SortedPairs {
-    // result is in (keys[sel], vals[sel]) with sel = passes_executed & 1; passes_executed = ceil(used_bits / DIGIT)
+    // result is in (keys[sel], vals[sel]) with sel = passes_executed & 1; passes_executed = ceil(used_bits / DIGIT_MAX)
     unsigned long long* keys[2];
     int* vals[2];
     int fixed_sel;            // >= 0 when the number of executed passes is known on the host
@@ -16,26 +18,31 @@ struct SortedPairs {
 };
 
 struct RadixSort {
-    static constexpr int DIGIT = 9;
-    static constexpr int BINS = 1 << DIGIT;
+    static constexpr int DIGIT_MAX = 10;
+    static constexpr int BINS_MAX = 1 << DIGIT_MAX;
     static constexpr int ITEMS = 8;
     static constexpr int TILE = 256 * ITEMS;  // elements per block
     int cap = 0;
     DevBuf<unsigned long long> keys_alt;
     DevBuf<int> vals_alt;
-    DevBuf<int> hist;  // [BINS][nb]
+    DevBuf<int> hist;  // [nb][BINS_MAX] or [bins][nb]
     DevBuf<int> tile_sum;  // hierarchical scan of hist for large sorts
 
     int init(int capacity);
     // Sorts the first *d_n pairs (*d_n <= n_bound, host-known) by bits [0, max_bits) of the key, ascending, stable.
-    // If d_used_bits is given, only ceil(*d_used_bits / DIGIT) passes do work.
+    // If d_used_bits is given, only ceil(*d_used_bits / DIGIT_MAX) passes do work.
     int sort(hipStream_t s, unsigned long long* keys, int* vals, const int* d_n, int n_bound, int max_bits, const int* d_used_bits,
              SortedPairs* out);
 };
 
+// passes that do work and their digit width for a key of `used` bits
+__device__ __forceinline__ void rs_plan(int used, int& passes, int& width) {
+    passes = (used + RadixSort::DIGIT_MAX - 1) / RadixSort::DIGIT_MAX;
+    width = passes > 0 ? (used + passes - 1) / passes : 0;
+}
 __device__ __forceinline__ int sorted_sel(const SortedPairs& p) {
     if (p.fixed_sel >= 0) return p.fixed_sel;
-    return ((*p.d_used_bits + RadixSort::DIGIT - 1) / RadixSort::DIGIT) & 1;
+    return ((*p.d_used_bits + RadixSort::DIGIT_MAX - 1) / RadixSort::DIGIT_MAX) & 1;
 }
 
 // in-place exclusive scan of data[0 .. m) with m = bins * ceil(*d_n / tile), by one block; total -> *d_total (may be null)

@@ -682,7 +682,12 @@ struct scal_sc {
     DevBuf<int> bq_limits;
     PinBuf<int> bq_hlimits;
     int bq_cap = 0, bq_nb = 0;
-    int detect_pending = 0;  // 1: search launched, 2: database too small (nothing launched)
+    // detections enqueued and not collected: 1 = search launched, 2 = database too small (nothing launched); up to DET_DEPTH in flight,
+    // each with its own record slot and event, so collecting one does not wait for anything queued on the stream behind it
+    static constexpr int DET_DEPTH = 4;
+    int det_mode[DET_DEPTH] = {};
+    hipEvent_t det_ev[DET_DEPTH] = {};
+    int det_head = 0, det_count = 0;
     hipEvent_t made_ev[4] = {};  // descriptors queued by scal_sc_make_features_enqueue, oldest first
     unsigned made_head = 0, made_tail = 0;
     SCDb db() const { return SCDb{desc.p, rkey.p, skey.p, cnorm.p}; }
@@ -715,10 +720,10 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->rkey.alloc((size_t)c->cap * NR));
     A(c->qdesc.alloc(DESC)); A(c->qskey.alloc(NS)); A(c->qnorm.alloc(NS)); A(c->qrkey.alloc(NR));
     A(c->block_best.alloc((size_t)3 * div_up(c->cap, 256) + 3));
-    A(c->d_rec.alloc(4));
+    A(c->d_rec.alloc(4 * scal_sc::DET_DEPTH));
     A(c->gcell.alloc(DESC));
     if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
-    A(c->h_rec.alloc(4));
+    A(c->h_rec.alloc(4 * scal_sc::DET_DEPTH));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane = (c->cfg.side_stream > 0 ? std::min(c->cfg.side_stream, 5) : stage_lane(STAGE_SC))) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
@@ -739,6 +744,8 @@ extern "C" void scal_sc_destroy(scal_sc_t* c) {
         release_stream(c->cfg.device, c->lane);
     }
     if (c->ev) (void)hipEventDestroy(c->ev);
+    for (int k = 0; k < scal_sc::DET_DEPTH; ++k)
+        if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     delete c;
 }
 
@@ -757,7 +764,7 @@ static int commit_staged(scal_sc* c) {
             set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
             return SCAL_E_CAPACITY;
         }
-        hipLaunchKernelGGL(k_sc_store, dim3(1), dim3(256), 0, s, c->staging(), c->slot(c->n_local));
+        SCAL_LAUNCH_PROF("k_sc_store", k_sc_store, dim3(1), dim3(256), 0, s, c->staging(), c->slot(c->n_local));
         SCAL_HIP(hipGetLastError());
         c->n_local++;
     }
@@ -779,8 +786,8 @@ static int make_into(scal_sc* c, const float* px, const float* py, const float* 
         db = c->slot(c->n_local);
     }
     const int nblk = std::max(1, std::min(64, div_up(n_host, 1024)));
-    hipLaunchKernelGGL(k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
-    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->staging(), db);
+    SCAL_LAUNCH_PROF("k_sc_bin", k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
+    SCAL_LAUNCH_PROF("k_sc_finish", k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->staging(), db);
     SCAL_HIP(hipGetLastError());
     if (store) c->n_local++;
     if (insert) c->n_global++;
@@ -842,7 +849,7 @@ extern "C" int scal_sc_insert_descriptor(scal_sc_t* c, const double* desc) {
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->qdesc.p, desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(commit_staged(c));
     SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
@@ -936,7 +943,7 @@ extern "C" int scal_sc_insert_descriptor_device(scal_sc_t* c, const double* d_de
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_desc, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(commit_staged(c));
     SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
@@ -953,10 +960,10 @@ extern "C" int scal_sc_shard_query_device(scal_sc_t* c, const double* d_queries,
     const int nb = std::max(1, div_up(c->n_local, 256));
     for (int q = 0; q < nq; ++q) {
         SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_queries + (size_t)q * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
-        hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard,
-                           global_size_at_rebuild - 30, c->block_best.p);
-        hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
+        SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+        SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard,
+                           global_size_at_rebuild - 30, c->block_best.p, static_cast<const int*>(nullptr));
+        SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
                            c->qnorm.p, 1, reinterpret_cast<SCRec*>(d_out) + 3 * (size_t)q);
     }
     SCAL_HIP(hipGetLastError());
@@ -984,7 +991,7 @@ extern "C" int scal_sc_insert_descriptors_device(scal_sc_t* c, const double* d_d
             }
             sl.slot[r] = n_local++;
         }
-    if (n > 0) hipLaunchKernelGGL(k_sc_store_batch, dim3(n), dim3(128), 0, c->stream, d_descs, sl, c->slot(0));
+    if (n > 0) SCAL_LAUNCH_PROF("k_sc_store_batch", k_sc_store_batch, dim3(n), dim3(128), 0, c->stream, d_descs, sl, c->slot(0));
     SCAL_HIP(hipGetLastError());
     c->n_local = n_local;
     c->n_global += n;
@@ -1016,10 +1023,10 @@ extern "C" int scal_sc_shard_query_batch_device(scal_sc_t* c, const double* d_qu
     for (int q = 0; q < nq; ++q) c->bq_hlimits.p[q] = limits[q] - 30;  // NUM_EXCLUDE_RECENT
     SCAL_HIP(hipMemcpyAsync(c->bq_limits.p, c->bq_hlimits.p, sizeof(int) * nq, hipMemcpyHostToDevice, s));
     if (nq > 0) {
-        hipLaunchKernelGGL(k_sc_keys, dim3(nq), dim3(128), 0, s, d_queries, c->bq_rkey.p, c->bq_skey.p, c->bq_norm.p);
-        hipLaunchKernelGGL(k_sc_topk, dim3(nb, nq), dim3(256), 0, s, c->rkey.p, c->bq_rkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, 0,
+        SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(nq), dim3(128), 0, s, d_queries, c->bq_rkey.p, c->bq_skey.p, c->bq_norm.p);
+        SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb, nq), dim3(256), 0, s, c->rkey.p, c->bq_rkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, 0,
                            c->bq_best.p, c->bq_limits.p);
-        hipLaunchKernelGGL(k_sc_detect, dim3(1, nq), dim3(256), 0, s, c->bq_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, d_queries, c->bq_skey.p,
+        SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1, nq), dim3(256), 0, s, c->bq_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, d_queries, c->bq_skey.p,
                            c->bq_norm.p, 1, reinterpret_cast<SCRec*>(d_out));
     }
     SCAL_HIP(hipGetLastError());
@@ -1050,15 +1057,17 @@ extern "C" int scal_sc_get_descriptor(scal_sc_t* c, int idx, double* desc, float
 }
 
 // ring-key top-3 over global indices < limit on this shard + SC distance of the three; records -> h_rec[0..2]
-static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q, bool wait = true) {
+static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q, bool wait = true, int slot = 0) {
     hipStream_t s = c->stream;
+    SCRec* d_rec = c->d_rec.p + 4 * slot;
+    SCRec* h_rec = c->h_rec.p + 4 * slot;
     const int nb = std::max(1, div_up(c->n_local, 256));
-    hipLaunchKernelGGL(k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
-                       c->block_best.p);
-    hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
-                       q.cnorm, fill_zero ? 1 : 0, c->d_rec.p);
+    SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
+                       c->block_best.p, static_cast<const int*>(nullptr));
+    SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
+                       q.cnorm, fill_zero ? 1 : 0, d_rec);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_rec.p, c->d_rec.p, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(h_rec, d_rec, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
     if (wait) SCAL_HIP(hipStreamSynchronize(s));
     return SCAL_OK;
 }
@@ -1094,36 +1103,44 @@ static int detect_enqueue(scal_sc* c) {
         set_error("scal_sc_detect needs the whole database on one context; use scal_sc_shard_query + scal_sc_merge_candidates");
         return SCAL_E_STATE;
     }
-    if (c->detect_pending) {
-        set_error("scal_sc_detect_enqueue: the previous detection has not been collected");
+    if (c->det_count >= scal_sc::DET_DEPTH) {
+        set_error("scal_sc_detect_enqueue: %d detections are queued and not collected", scal_sc::DET_DEPTH);
         return SCAL_E_STATE;
     }
     const int NUM_EXCLUDE_RECENT = 30, TREE_MAKING_PERIOD_ = 30;
-    c->detect_pending = 1;
+    const int slot = (c->det_head + c->det_count) % scal_sc::DET_DEPTH;
     if (c->n_global < NUM_EXCLUDE_RECENT + 1) {  // :346-350
-        c->detect_pending = 2;  // nothing launched
+        c->det_mode[slot] = 2;  // nothing launched
+        c->det_count++;
         return SCAL_OK;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (!c->det_ev[slot]) SCAL_HIP(hipEventCreateWithFlags(&c->det_ev[slot], hipEventDisableTiming));
     if (c->tree_making_period_conter % TREE_MAKING_PERIOD_ == 0) c->size_at_rebuild = c->n_global;  // :353-364
     c->tree_making_period_conter++;
     // query = newest keyframe (:340-341), read in place from its database slot
-    return search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1), false);
+    SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1), false, slot));
+    SCAL_HIP(hipEventRecord(c->det_ev[slot], c->stream));
+    c->det_mode[slot] = 1;
+    c->det_count++;
+    return SCAL_OK;
 }
 static int detect_collect(scal_sc* c, scal_sc_result* res) {
     std::memset(res, 0, sizeof *res);
     res->loop_id = -1;
     res->min_dist = 10000000;
-    if (!c->detect_pending) {
+    if (c->det_count == 0) {
         set_error("scal_sc_detect_collect: no detection enqueued");
         return SCAL_E_STATE;
     }
-    const int mode = c->detect_pending;
-    c->detect_pending = 0;
+    const int slot = c->det_head;
+    const int mode = c->det_mode[slot];
+    c->det_head = (c->det_head + 1) % scal_sc::DET_DEPTH;
+    c->det_count--;
     if (mode == 2) return SCAL_OK;
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
-    finish_result(c->h_rec.p, 3, c->cfg.dist_thres, res);
+    SCAL_HIP(hipEventSynchronize(c->det_ev[slot]));
+    finish_result(c->h_rec.p + 4 * slot, 3, c->cfg.dist_thres, res);
     return SCAL_OK;
 }
 
@@ -1165,7 +1182,7 @@ extern "C" int scal_sc_shard_query(scal_sc_t* c, const double* query_desc, int g
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->qdesc.p, query_desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(search_local(c, global_size_at_rebuild - 30, true, c->staging()));
     static_assert(sizeof(SCRec) == sizeof(scal_sc_cand), "record layout");
     std::memcpy(out, c->h_rec.p, sizeof(SCRec) * 3);
@@ -1223,7 +1240,7 @@ extern "C" int scal_sc_distance_pairs(scal_sc_t* c, const int* idx_a, const int*
     hipStream_t s = c->stream;
     SCAL_HIP(hipMemcpyAsync(c->d_pairs.p, idx_a, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
     SCAL_HIP(hipMemcpyAsync(c->d_pairs.p + n_pairs, idx_b, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_sc_pairs, dim3(div_up(n_pairs, 4)), dim3(256), 0, s, c->db(), c->d_pairs.p, c->d_pairs.p + n_pairs, n_pairs, c->d_dist.p,
+    SCAL_LAUNCH_PROF("k_sc_pairs", k_sc_pairs, dim3(div_up(n_pairs, 4)), dim3(256), 0, s, c->db(), c->d_pairs.p, c->d_pairs.p + n_pairs, n_pairs, c->d_dist.p,
                        c->d_shift.p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * n_pairs, hipMemcpyDeviceToHost, s));

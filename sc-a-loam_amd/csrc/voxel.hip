@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restric
         m->guard = guard ? 1 : 0;
         m->b0 = b0, m->b1 = b1;
         m->used_bits = n > 0 ? min(used, max_bits) : 0;
-        if (n > 0 && used > max_bits) m->error = SCAL_E_CAPACITY;
+        m->error = (n > 0 && used > max_bits) ? SCAL_E_CAPACITY : 0;
     }
     if (i >= n) return;
     unsigned long long k;
@@ -118,9 +118,19 @@ __global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __
 // additions of a run are inherently serial, the loads need not be: the block stages its 256 sorted positions plus a
 // 256-position look-ahead (keys + gathered points) in LDS with independent loads, the per-run loops then read LDS; only a
 // run longer than the look-ahead finishes from global memory.
-__global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, CSoA4 in, SoA4 out) {
+// The block's output offset is the sum of the earlier blocks' head counts (k_vox_heads), summed here instead of in a scan
+// launch of its own; the last block publishes the total, runs the optional epilogue and leaves the bounding box reset.
+__global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockcnt, CSoA4 in, SoA4 out,
+                                                    int* __restrict__ d_n_out, VoxMeta* m, VoxTail tail, int reset_box) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        *d_n_out = 0;
+        if (tail.slots_out) *tail.slots_out = min(*tail.other_n, tail.slots_cap);
+        if (tail.err_out && m->error) *tail.err_out = m->error;
+        if (reset_box)
+            for (int a = 0; a < 3; ++a) m->umin[a] = 0xffffffffu, m->umax[a] = 0u;
+    }
     if (static_cast<int>(blockIdx.x) >= nb) return;
     constexpr int SPAN = 512;
     __shared__ int s[17];
@@ -130,6 +140,8 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
     const unsigned long long* keys = sp.keys[sel];
     const int* vals = sp.vals[sel];
     const int base = blockIdx.x * 256;
+    int before = 0;
+    for (int b = threadIdx.x; b < static_cast<int>(blockIdx.x); b += 256) before += blockcnt[b];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int t = h * 256 + threadIdx.x;
@@ -139,10 +151,20 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
             sx[t] = in.x[g], sy[t] = in.y[g], sz[t] = in.z[g], sw[t] = in.w[g];
         }
     }
+    int block_off;
+    block_exclusive_scan(before, s, &block_off);
     const int i = base + threadIdx.x;
     const int head = (i < n) && (i == 0 || keys[i] != keys[i - 1]);
     int total;
     const int rank = block_exclusive_scan(head, s, &total);  // contains the barrier that publishes the staged span
+    if (static_cast<int>(blockIdx.x) == nb - 1 && threadIdx.x == 0) {
+        const int n_out = block_off + total;
+        *d_n_out = n_out;
+        if (tail.slots_out) *tail.slots_out = min(*tail.other_n + n_out, tail.slots_cap);
+        if (tail.err_out && m->error) *tail.err_out = m->error;
+        if (reset_box)
+            for (int a = 0; a < 3; ++a) m->umin[a] = 0xffffffffu, m->umax[a] = 0u;
+    }
     if (!head) return;
     const unsigned long long k = skey[threadIdx.x];
     const int lim = min(n - base, SPAN);
@@ -161,14 +183,15 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
         }
     }
     const float c = static_cast<float>(u - i);
-    const int o = blockoff[blockIdx.x] + rank;
+    const int o = block_off + rank;
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
 
 // Whole filter for a cloud of <= VOX_SMALL points in ONE workgroup: bounding box, keys (14-bit voxel coordinates + arrival
 // index), LDS bitonic sort, run heads, ordered f32 centroids.  Replaces ~20 launches for the corner clouds.
 constexpr int VOX_SMALL = 8192;
-__global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restrict__ d_n, float inv, SoA4 out, int* __restrict__ d_n_out, VoxMeta* m) {
+__global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restrict__ d_n, float inv, SoA4 out, int* __restrict__ d_n_out, VoxMeta* m,
+                                                    VoxTail tail) {
     extern __shared__ __align__(16) unsigned long long skeys[];
     __shared__ int s_scan[17];
     __shared__ unsigned s_lo[3][16], s_hi[3][16];
@@ -176,9 +199,15 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
     const int n = min(*d_n, VOX_SMALL);
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     if (tid == 0) SCAL_STAMP(0);
-    if (tid == 0) m->error = (*d_n > VOX_SMALL) ? SCAL_E_CAPACITY : 0, m->guard = 0;
+    if (tid == 0) {
+        m->error = (*d_n > VOX_SMALL) ? SCAL_E_CAPACITY : 0, m->guard = 0;
+        if (m->error && tail.err_out) *tail.err_out = m->error;
+    }
     if (n == 0) {
-        if (tid == 0) *d_n_out = 0;
+        if (tid == 0) {
+            *d_n_out = 0;
+            if (tail.slots_out) *tail.slots_out = min(*tail.other_n, tail.slots_cap);
+        }
         return;
     }
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -212,7 +241,10 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
         const bool guard = d[0] * d[1] * d[2] > 2147483647ll;
         s_mb[3] = guard ? 1 : 0;
         m->guard = s_mb[3];
-        if (!guard && wide) m->error = SCAL_E_CAPACITY;
+        if (!guard && wide) {
+            m->error = SCAL_E_CAPACITY;
+            if (tail.err_out) *tail.err_out = SCAL_E_CAPACITY;
+        }
     }
     __syncthreads();
     const bool guard = s_mb[3] != 0;
@@ -281,7 +313,10 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
             ++opos;
         }
     }
-    if (tid == 0) *d_n_out = n_out;
+    if (tid == 0) {
+        *d_n_out = n_out;
+        if (tail.slots_out) *tail.slots_out = min(*tail.other_n + n_out, tail.slots_cap);
+    }
     if (tid == 0) SCAL_STAMP(5);
 }
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_voxel)
@@ -296,8 +331,16 @@ int VoxelFilter::init(int capacity) {
     return SCAL_OK;
 }
 
-int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out) {
+int VoxelFilter::reset_box(hipStream_t s) {
+    SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
+    SCAL_HIP(hipGetLastError());
+    return SCAL_OK;
+}
+
+int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done,
+                     const VoxTail* tail) {
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
+    const VoxTail tl = tail ? *tail : VoxTail();
     if (n_bound <= VOX_SMALL) {
         static bool attr_set = false;
         const int lds = sizeof(unsigned long long) * VOX_SMALL;
@@ -306,20 +349,21 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
             attr_set = true;
         }
         {
-            SCAL_LAUNCH_PROF("k_vox_small", k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p);
+            SCAL_LAUNCH_PROF("k_vox_small", k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p, tl);
         }
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
     }
     const int nb = max(1, div_up(min(cap, n_bound), 256));
-    hipLaunchKernelGGL(k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
-    hipLaunchKernelGGL(k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p);
+    if (!bbox_done) {
+        SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
+        SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
+    }
+    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
-    hipLaunchKernelGGL(k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    launch_scan_inplace(s, blockcnt.p, d_n, 256, 1, d_n_out);
-    hipLaunchKernelGGL(k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out);
+    SCAL_LAUNCH_PROF("k_vox_heads", k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
+    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, bbox_done ? 1 : 0);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -337,10 +381,10 @@ __global__ void k_interleave4(const int* __restrict__ d_n, CSoA4 in, float* __re
 }
 
 void launch_deinterleave(hipStream_t s, const float* aos, int n, SoA4 o) {
-    if (n > 0) hipLaunchKernelGGL(k_deinterleave, dim3(div_up(n, 256)), dim3(256), 0, s, aos, n, o);
+    if (n > 0) SCAL_LAUNCH_PROF("k_deinterleave", k_deinterleave, dim3(div_up(n, 256)), dim3(256), 0, s, aos, n, o);
 }
 void launch_interleave(hipStream_t s, const int* d_n, int n_cap, CSoA4 in, float* aos) {
-    if (n_cap > 0) hipLaunchKernelGGL(k_interleave4, dim3(div_up(n_cap, 256)), dim3(256), 0, s, d_n, in, aos);
+    if (n_cap > 0) SCAL_LAUNCH_PROF("k_interleave4", k_interleave4, dim3(div_up(n_cap, 256)), dim3(256), 0, s, d_n, in, aos);
 }
 
 }  // namespace scal

@@ -21,6 +21,15 @@ struct CSoA4 {
     const float *x, *y, *z, *w;
 };
 
+// Optional epilogue of a filter run, executed by its last kernel (saves one-thread launches on dependent chains):
+// *slots_out = min(*other_n + n_out, slots_cap) when slots_out is set; *err_out = error code when one was raised.
+struct VoxTail {
+    int* err_out = nullptr;
+    int* slots_out = nullptr;
+    const int* other_n = nullptr;
+    int slots_cap = 0;
+};
+
 struct VoxelFilter {
     int cap = 0;
     RadixSort sorter;
@@ -34,12 +43,44 @@ struct VoxelFilter {
     // (computed on the device); max_bits bounds the passes the host enqueues (a multiple of 9 avoids waste).
     // n_bound: host-known upper bound of *d_n; clouds of <= 8192 points take a single-workgroup LDS path.
     // d_n_out receives the number of centroids; meta.p->error is set when the box needs more than max_bits.
-    int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out);
+    // bbox_done: the caller has already folded the cloud's bounding box into meta (vox_bbox_accumulate, e.g. while copying the
+    // cloud) - the reset and bounding-box launches are skipped, and the run leaves meta's box reset for the next one.
+    int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done = false,
+            const VoxTail* tail = nullptr);
+    int reset_box(hipStream_t s);
 };
 
 }  // namespace scal
 
 namespace scal {
+#ifdef __HIPCC__
+// Folds the bounding box of the caller's points into a VoxMeta (order-preserving uint images, atomic min / max), so that a kernel
+// which reads a cloud anyway (a gather) can stand in for k_vox_bbox (VoxelFilter::run with bbox_done).  Every thread of a
+// 256-thread block calls it; `have` = this thread holds a point.  One atomic pair per wave and axis.
+__device__ inline void vox_bbox_accumulate(VoxMeta* m, bool have, float x, float y, float z) {
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    if (have) {
+        const float v[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const unsigned u = __float_as_uint(v[a]);
+            lo[a] = hi[a] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
+            hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
+        }
+        if ((threadIdx.x & 63) == 0 && lo[a] != 0xffffffffu) {
+            atomicMin(&m->umin[a], lo[a]);
+            atomicMax(&m->umax[a], hi[a]);
+        }
+    }
+}
+#endif
 void launch_deinterleave(hipStream_t s, const float* aos, int n, SoA4 o);
 void launch_interleave(hipStream_t s, const int* d_n, int n_cap, CSoA4 in, float* aos);
 }  // namespace scal

@@ -89,7 +89,7 @@ class OdomStats(C.Structure):
 
 # every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names",
+    "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names", "scal_prof_timeline", "scal_prof_timeline_dump",
     "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_fetch",
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample", "scal_voxel_downsample_device",
@@ -238,6 +238,14 @@ def prof_enable(on, kernel=None):
 
 def prof_reset():
     lib().scal_prof_reset()
+
+
+def prof_timeline(on):
+    lib().scal_prof_timeline(1 if on else 0)
+
+
+def prof_timeline_dump(path):
+    lib().scal_prof_timeline_dump(path.encode())
 
 
 def prof_read_all():

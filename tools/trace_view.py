@@ -3,7 +3,8 @@
 duration and the gap to the previous kernel on the same queue."""
 import csv, glob, sys, collections
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/trace"
-f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+import os
+f = max(glob.glob(d + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
 rows = list(csv.DictReader(open(f)))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
