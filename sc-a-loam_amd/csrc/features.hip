@@ -22,6 +22,7 @@
 #include <mutex>
 #include "device_utils.hpp"
 #include "features_dev.hpp"
+#include "voxel_dev.hpp"
 #include <cmath>
 #include <climits>
 
@@ -102,6 +103,7 @@ __global__ void k_pre(const float* __restrict__ in, int n, int stride, KCfg c, F
         P->error = 0;
         P->n_tied = 0;
         P->n_kept = 0;
+        for (int a = 0; a < 3; ++a) P->box[a] = 0xffffffffu, P->box[3 + a] = 0u;
         if (s_last >= 0) {
             const size_t f = (size_t)s_first * stride, l = (size_t)s_last * stride;
             float startOri = neg_atan2f_cr(in[f + 1], in[f]);                                      // :143
@@ -247,11 +249,14 @@ __global__ void __launch_bounds__(256) k_scatter(const float* __restrict__ in, i
     }
 }
 
-__global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
+__global__ void __launch_bounds__(256) k_curv(FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
                                               const float* __restrict__ z, float* __restrict__ curv, int* __restrict__ label,
                                               unsigned char* __restrict__ gap) {
     const int n = P->n_kept;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (static_cast<int>(blockIdx.x * blockDim.x) >= n) return;  // uniform over the block
+    // bounding box of the ordered cloud on the way (the ScanContext keyframe filter starts from it instead of two launches)
+    vox_bbox_accumulate(P->box, P->box + 3, i < n, i < n ? x[i] : 0.f, i < n ? y[i] : 0.f, i < n ? z[i] : 0.f);
     if (i >= n) return;
     float c = 0.f;
     if (i >= 5 && i < n - 5) {  // :269-275, summed left to right exactly as written
@@ -683,7 +688,12 @@ struct scal_features {
     std::mutex ev_mu;  // consumers may register from different host threads  // seen once: record done_ev right behind every run, before later main-stream work
     int cap = 0, nb_cap = 0;
     DevBuf<float> d_in;
-    PinBuf<float> h_in;  // pinned staging of host scans: the upload is then an ordinary stream-ordered copy (see scal_features_run)
+    // pinned staging of host scans (two slots, each guarded by the event of the upload that last read it): the upload is an
+    // ordinary stream-ordered copy and the caller's buffer is free again when scal_features_run returns
+    PinBuf<float> h_in[2];
+    hipEvent_t up_ev[2] = {};
+    bool up_used[2] = {};
+    int up_next = 0;
     DevBuf<signed char> d_ring;
     DevBuf<float> d_ori;
     DevBuf<int> d_hist;
@@ -776,7 +786,8 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     int rc = SCAL_OK;
     auto A = [&](int r) { if (rc == SCAL_OK) rc = r; };
     A(c->d_in.alloc((size_t)cap * 8));  // up to 32-byte point stride
-    A(c->h_in.alloc((size_t)cap * 8));
+    A(c->h_in[0].alloc((size_t)cap * 8));
+    A(c->h_in[1].alloc((size_t)cap * 8));
     A(c->d_ring.alloc(cap));
     A(c->d_ori.alloc(cap));
     A(c->d_hist.alloc((size_t)64 * c->nb_cap));
@@ -793,11 +804,17 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     A(c->d_aos.alloc((size_t)cap * 4));
     A(c->d_P.alloc(1));
     A(c->h_P.alloc(1));
-    if (rc == SCAL_OK && hipMemset(c->d_P.p, 0, sizeof(FeatParams)) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
+    // Initialisation goes through the context's own stream.  hipMemset on the legacy null stream returns before the fill has
+    // run and is not ordered against a hipStreamNonBlocking stream: a fill landing after the first k_pre cleared
+    // FeatParams::empty again (the E_EMPTY that test_errors once missed).
+    if (rc == SCAL_OK && (hipMemsetAsync(c->d_P.p, 0, sizeof(FeatParams), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+        rc = SCAL_E_HIP;
+    for (int k = 0; k < 2 && rc == SCAL_OK; ++k)
+        if (hipEventCreateWithFlags(&c->up_ev[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -822,6 +839,8 @@ extern "C" void scal_features_destroy(scal_features_t* c) {
             (void)hipEventDestroy(c->reader_ev[i]);
         }
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
+    for (int k = 0; k < 2; ++k)
+        if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]);
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device);
@@ -956,11 +975,15 @@ extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     if (n > 0) {
-        // The caller's (usually pageable) buffer is staged through pinned memory.  Asynchronous copies straight from pageable
-        // memory are legal, but one run in ~50 of the test-suite saw stage A read stale device memory after a 1.2 KB upload.
-        SCAL_HIP(hipStreamSynchronize(c->stream));  // the staging buffer may still feed the previous upload
-        std::memcpy(c->h_in.p, xyz, (size_t)n * stride_bytes);
-        SCAL_HIP(hipMemcpyAsync(c->d_in.p, c->h_in.p, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+        // The caller's (usually pageable) buffer is staged through pinned memory, so the upload is an ordinary stream-ordered
+        // copy.  Two slots: the only wait is for the upload issued two calls ago, never for the work queued on the stream.
+        const int slot = c->up_next;
+        c->up_next ^= 1;
+        if (c->up_used[slot]) SCAL_HIP(hipEventSynchronize(c->up_ev[slot]));
+        std::memcpy(c->h_in[slot].p, xyz, (size_t)n * stride_bytes);
+        SCAL_HIP(hipMemcpyAsync(c->d_in.p, c->h_in[slot].p, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+        SCAL_HIP(hipEventRecord(c->up_ev[slot], c->stream));
+        c->up_used[slot] = true;
     }
     SCAL_TRY(launch_chain(c, c->d_in.p, n, stride_bytes / 4));
     if (out) return scal_features_fetch(c, out);

@@ -16,6 +16,7 @@ struct FeatParams {
     int n_sharp, n_less_sharp, n_flat, n_less_flat;
     int lf_ring_cnt[64];
     int lf_ring_off[65];
+    unsigned box[6];  // bounding box of the ordered cloud, order-preserving uint images: min xyz, max xyz (consumers: voxel filters)
 };
 
 struct FeatDeviceView {

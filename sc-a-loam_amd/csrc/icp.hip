@@ -434,12 +434,13 @@ extern "C" int scal_icp_create(const scal_icp_config* cfg, scal_icp_t** out) {
     A(c->h_sums.alloc(ICP_NSUM));
     A(c->grid.alloc(1)); A(c->mm.alloc(6)); A(c->count.alloc(ICP_NCELL)); A(c->start.alloc(ICP_NCELL + 4)); A(c->bsum.alloc(256));
     A(c->cell_of.alloc(cfg->max_target)); A(c->sorted.alloc(cfg->max_target)); A(c->un_list.alloc(cfg->max_source)); A(c->d_nun.alloc(2));
-    if (rc == SCAL_OK) {
+    if (rc == SCAL_OK && acquire_stream(cfg->device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
+    if (rc == SCAL_OK) {  // initialised on the context's own stream (the legacy null stream is not ordered against it)
         const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-        if (hipMemcpy(c->mm.p, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->d_nun.p, 0, 2 * sizeof(int)) != hipSuccess)
+        if (hipMemcpyAsync(c->mm.p, init, sizeof init, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->d_nun.p, 0, 2 * sizeof(int), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
             rc = SCAL_E_HIP;
     }
-    if (rc == SCAL_OK && acquire_stream(cfg->device, &c->stream) != SCAL_OK) rc = SCAL_E_HIP;
     if (rc != SCAL_OK) {
         delete c;
         return rc;

@@ -385,6 +385,15 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
     lm_compute_candidate(st);
 }
 
+// Hooks a caller can hang on the solve kernel so that work which must precede / follow it needs no launch of its own:
+//   Pre::operator()(first, stride, n)   every thread, before round 0: prepare the residual-block slots first, first + stride, ...
+//                                        (a thread only ever evaluates the slots it prepared itself, so no barrier is needed)
+//   Post::operator()(x, first, stride)  every thread, after the last round, with the final accepted point
+struct LMNoHook {
+    __device__ __forceinline__ void operator()(int, int, int) const {}
+    __device__ __forceinline__ void operator()(const double*, int, int, bool) const {}
+};
+
 // The whole <= 4-iteration solve in ONE launch.  A small grid (<= LM_GRID workgroups, all resident at once on 256 CUs)
 // walks the rounds together: every workgroup evaluates its tiles of residual blocks at the current point (round 0: the
 // accepted point, later: the candidate), publishes LM_NACC partial sums, meets the others at a grid barrier, then sums ALL
@@ -397,16 +406,20 @@ __device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phas
 // read it).  Partials are double buffered by round parity: a workgroup can be at most one round ahead of the slowest one.
 // Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
 // sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
-constexpr int LM_GRID = 32;
+constexpr int LM_GRID = 64;
 struct LMSync {
     unsigned arrivals;  // grows forever (wrap-around safe comparisons)
     unsigned epoch;     // arrivals consumed by all earlier solves
 };
 
+template <class Pre, class Post>
 static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
                                                          const int* __restrict__ d_enable, double* partials, LMSync* sync,
-                                                         const int* __restrict__ d_abort) {
-    if (d_abort && *d_abort) return;  // uniform over the grid (written by an earlier kernel): a stopped chain leaves the state alone
+                                                         const int* __restrict__ d_abort, Pre pre, Post post) {
+    if (d_abort && *d_abort) {  // uniform over the grid (written by an earlier kernel): a stopped chain leaves the state alone
+        post(st->x, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, true);
+        return;
+    }
     __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
     __shared__ double red[4][LM_NACC];
     __shared__ double tot[LM_NACC];
@@ -423,8 +436,11 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             st->log_iters[outer] = 0, st->log_success[outer] = 0, st->log_cost_init[outer] = 0, st->log_cost_final[outer] = 0;
             st->log_n_edge[outer] = 0, st->log_n_plane[outer] = 0;
         }
+        __syncthreads();
+        post(st->x, blockIdx.x * 256 + tid, G * 256, false);  // x is untouched: the prior pose stands
         return;
     }
+    pre(blockIdx.x * 256 + tid, G * 256, n);
     const unsigned epoch = sync->epoch;
     if (tid == 0) L = *st;  // only x carries over from the previous solve; lm_tail(phase 0) re-arms the rest
     __syncthreads();
@@ -526,6 +542,8 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         *st = L;
         sync->epoch = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(rounds);
     }
+    __syncthreads();  // block 0's hook may publish *st
+    post(L.x, blockIdx.x * 256 + tid, G * 256, false);
 }
 
 // Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
@@ -547,11 +565,12 @@ inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* 
 }
 
 // host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
+template <class Pre = LMNoHook, class Post = LMNoHook>
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
-                            int outer, const int* d_abort = nullptr) {
+                            int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post()) {
     int g = (f.cap + 255) / 256;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
-    SCAL_LAUNCH_PROF("k_lm_solve", k_lm_solve, dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort);
+    SCAL_LAUNCH_PROF("k_lm_solve", (k_lm_solve<Pre, Post>), dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
 }
 
 }  // namespace scal

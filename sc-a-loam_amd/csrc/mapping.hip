@@ -470,15 +470,20 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const Map
     }
 }
 
-__global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, const MapState* __restrict__ S, MapCounters* C, int outer,
-                                                 FactorSoA f) {
-    if (S->abort || !C->solve_on) return;
-    const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int valid = 0;
-    bool is_edge = false;
-    if (i < nc + ns && i < f.cap) {
-        is_edge = i < nc;
+// The neighbours of a residual-block slot become factor parameters: PCA of the five neighbours for an edge candidate (:594-622),
+// plane fit for a surf candidate (:651-687).  ~3k dependent f64 operations per slot.
+struct AssocFit {
+    CSoA4 cs, ss;
+    NNBuf nb;
+    const MapCounters* C;
+    FactorSoA f;
+    __device__ __forceinline__ void operator()(int first, int stride, int n_slots) const {
+        const int nc = C->n_corner_stack, ns = C->n_surf_stack;
+        for (int i = first; i < nc + ns && i < f.cap; i += stride) fit(i, nc);
+    }
+    __device__ __forceinline__ void fit(int i, int nc) const {
+        int valid = 0;
+        const bool is_edge = i < nc;
         const int j = is_edge ? i : i - nc;
         const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
         double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
@@ -531,6 +536,15 @@ __global__ void __launch_bounds__(64) k_assoc_fit(CSoA4 cs, CSoA4 ss, NNBuf nb, 
         f.pa[i] = pa[0], f.pa[f.cap + i] = pa[1], f.pa[2 * f.cap + i] = pa[2];
         f.pb[i] = pb[0], f.pb[f.cap + i] = pb[1], f.pb[2 * f.cap + i] = pb[2];
     }
+};
+
+// one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations, so it wants every lane busy with a different
+// point and many small workgroups spread over the machine; inside the solve kernel's 64 workgroups it ran slower)
+__global__ void __launch_bounds__(64) k_assoc_fit(AssocFit fit, const MapState* __restrict__ S) {
+    if (S->abort || !fit.C->solve_on) return;
+    const int nc = fit.C->n_corner_stack, ns = fit.C->n_surf_stack;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nc + ns && i < fit.f.cap) fit.fit(i, nc);
 }
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
@@ -830,12 +844,13 @@ __global__ void __launch_bounds__(512) k_merge_lookup(MergeArgs a, const MapStat
 
 // A merge that cannot be done (merge_fail, map pool full) stops the speculative chain here: nothing has been committed yet, the
 // host redoes this insertion with the full sort and replays the steps queued behind it.
-__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, MapCounters* C) {
+__device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S, MapCounters* C) {
     if (S->abort) return;
     if (C->merge_fail) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) S->abort = MAP_ABORT_MERGE;
+        if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&S->abort, static_cast<int>(MAP_ABORT_MERGE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+    if (static_cast<int>(blockIdx.x) >= MERGE_WRITE_GRID) return;  // registration blocks of the fused form
     __shared__ int s_base[MERGE_CHUNKS + 1];
     __shared__ unsigned long long s_samp[MERGE_MAX / 16];
     int b = blockIdx.x;
@@ -866,10 +881,10 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
     __syncthreads();
     const int total = s_base[MERGE_CHUNKS];
     if (n_old + total > a.cap) {  // uniform over the grid
-        if (b == 0 && part == 0 && threadIdx.x == 0) S->abort = MAP_ABORT_MERGE;
+        if (b == 0 && part == 0 && threadIdx.x == 0) __hip_atomic_store(&S->abort, static_cast<int>(MAP_ABORT_MERGE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (b == 0 && part == 0 && threadIdx.x == 0) C->n_map_new[cls] = n_old + total;
+    if (b == 0 && part == 0 && threadIdx.x == 0) __hip_atomic_store(&C->n_map_new[cls], n_old + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto pre_at = [&](int t) { return t < n_eff ? nw.pre[t] + s_base[t >> 9] : total; };
     if (part == 0) {
         for (int i = b * 256 + threadIdx.x; i < n_old; i += nblk * 256) {
@@ -925,6 +940,41 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
     out.cube[o] = nw.cube[static_cast<int>(nw.sorted[i] & (MERGE_MAX - 1))];
 }
 
+// What the host reads per step, in pinned memory: state + counters when the pose is ready (1) and after the insertion (2)
+struct MapResult {
+    LMState st;
+    MapCounters C1, C2;
+    MapState S1, S2;
+};
+
+// k_merge_write.  tail.fused = 0: the merge write alone.  tail.fused = 1 (speculative chain): the launch also carries the registration
+// of the full-resolution cloud (:845-849) as extra blocks - what k_transform_cloud does in a launch of its own on the general path.
+// (Committing the sizes from the last block to finish was tried as well: a ticket counter bumped by 2,300 workgroups costs more
+// than the 5 us launch of k_map_end it saves.)
+struct MergeTail {
+    int fused;
+    CSoA4 full;
+    const int* d_nfull;
+    int full_cap;
+    const LMState* st;
+    SoA4 full_out;
+};
+__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, MapCounters* C, MergeTail t) {
+    merge_write_body(a, S, C);
+    if (!t.fused) return;
+    if (static_cast<int>(blockIdx.x) >= MERGE_WRITE_GRID && !S->abort) {
+        const int i = (blockIdx.x - MERGE_WRITE_GRID) * 256 + threadIdx.x;
+        if (i < min(*t.d_nfull, t.full_cap)) {
+            double x7[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) x7[k] = t.st->x[k];
+            float sel[3];
+            associate_to_map(x7, t.full.x[i], t.full.y[i], t.full.z[i], sel);
+            t.full_out.x[i] = sel[0], t.full_out.y[i] = sel[1], t.full_out.z[i] = sel[2], t.full_out.w[i] = t.full.w[i];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st,
                                                          const MapState* __restrict__ S, SoA4 out) {
     if (S->abort) return;
@@ -964,7 +1014,7 @@ __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ le
             x = less_flat.x[i], y = less_flat.y[i], z = less_flat.z[i];
             surf_in.x[i] = x, surf_in.y[i] = y, surf_in.z[i] = z, surf_in.w[i] = less_flat.w[i];
         }
-        if (surf_box) vox_bbox_accumulate(surf_box, i < n, x, y, z);
+        if (surf_box) vox_bbox_accumulate(surf_box->umin, surf_box->umax, i < n, x, y, z);
     }
 }
 
@@ -1046,22 +1096,15 @@ __global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_wi
     for (int k = 0; k < 7; ++k) st->x[k] = x0[k];
 }
 
-// What the host reads per step, in pinned memory: state + counters when the pose is ready (1) and after the insertion (2)
-struct MapResult {
-    LMState st;
-    MapCounters C1, C2;
-    MapState S1, S2;
-};
-
 __device__ __forceinline__ void copy_words(void* dst, const void* src, int bytes) {
     const unsigned* s = static_cast<const unsigned*>(src);
     unsigned* d = static_cast<unsigned*>(dst);
     for (int i = threadIdx.x; i < bytes / 4; i += blockDim.x) d[i] = s[i];
 }
 
-// After the solve.  Block 0: transformUpdate (:149-153) on the device, then pose, statistics and state go to the host slot.
-// The other blocks (MERGE_NEW_BLOCKS per class) already prepare the insertion: the scan's stack points in the map frame
-// (:740 / :764), their cube and their packed sort key, once, for every consumer of the merge insert.
+// Epilogue of the second solve (lm_dev.hpp, Post hook), with the final pose in hand.  Block 0: transformUpdate (:149-153) on the
+// device, then pose, statistics and state go to the host slot.  All threads: the insertion is prepared - the scan's stack points
+// in the map frame (:740 / :764), their cube and their packed sort key, once, for every consumer of the merge insert.
 struct PoseDoneNew {
     CSoA4 stack[2];
     const int* d_ns[2];
@@ -1070,46 +1113,57 @@ struct PoseDoneNew {
     int* cube[2];
     unsigned long long* pkey[2];
 };
-__global__ void __launch_bounds__(256) k_map_pose_done(MapState* S, const LMState* st, MapCounters* C, MapResult* host, PoseDoneNew nw) {
-    if (blockIdx.x > 0) {
-        if (S->abort) return;
-        const int b = blockIdx.x - 1;
-        const int cls = b / MERGE_NEW_BLOCKS;
-        const int i = (b % MERGE_NEW_BLOCKS) * 256 + threadIdx.x;
-        if (i >= min(*nw.d_ns[cls], MERGE_MAX)) return;
-        const MapParams mp = S->mp;
-        double x7[7];
+struct MapPoseDone {
+    int active;  // the hook runs behind the second outer iteration only
+    MapState* S;
+    const LMState* st;
+    MapCounters* C;
+    MapResult* host;
+    PoseDoneNew nw;
+    __device__ __forceinline__ void operator()(const double* x, int first, int stride, bool aborted) const {
+        if (!active) return;
+        const bool stop = aborted || S->abort;
+        if (!stop) {
+            const MapParams mp = S->mp;
+            double x7[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-        float sel[3];
-        const CSoA4 stack = nw.stack[cls];
-        associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);
-        const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
-        const unsigned long long k = map_key(mp, nw.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
-        nw.x[cls][i] = sel[0], nw.y[cls][i] = sel[1], nw.z[cls][i] = sel[2], nw.w[cls][i] = stack.w[i], nw.cube[cls][i] = pc;
-        nw.pkey[cls][i] = k == ~0ull ? ~0ull : ((k << MERGE_IDX_BITS) | static_cast<unsigned long long>(i));
-        return;
+            for (int k = 0; k < 7; ++k) x7[k] = x[k];
+#pragma unroll
+            for (int cls = 0; cls < 2; ++cls) {
+                const int n_new = min(*nw.d_ns[cls], MERGE_MAX);
+                const CSoA4 stack = nw.stack[cls];
+                for (int i = first; i < n_new; i += stride) {
+                    float sel[3];
+                    associate_to_map(x7, stack.x[i], stack.y[i], stack.z[i], sel);
+                    const int pc = pack_cube(cube_abs(sel[0]), cube_abs(sel[1]), cube_abs(sel[2]));
+                    const unsigned long long k = map_key(mp, nw.inv_leaf[cls], sel[0], sel[1], sel[2], pc, C);
+                    nw.x[cls][i] = sel[0], nw.y[cls][i] = sel[1], nw.z[cls][i] = sel[2], nw.w[cls][i] = stack.w[i], nw.cube[cls][i] = pc;
+                    nw.pkey[cls][i] = k == ~0ull ? ~0ull : ((k << MERGE_IDX_BITS) | static_cast<unsigned long long>(i));
+                }
+            }
+        }
+        if (first >= 256) return;  // block 0 only from here on
+        if (first == 0 && !stop) {
+            // q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
+            const double* q_wodom = S->q_wodom;
+            const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
+            const double qi[4] = {-q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2};
+            double qn[4];
+            m_qmul(x, qi, qn);
+            double r2[3];
+            m_rot(qn, S->t_wodom, r2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) S->q_wmap_wodom[i] = qn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) S->t_wmap_wodom[i] = x[4 + i] - r2[i];
+        }
+        __syncthreads();
+        copy_words(&host->st, st, sizeof(LMState));
+        copy_words(&host->C1, C, sizeof(MapCounters));
+        copy_words(&host->S1, S, sizeof(MapState));
     }
-    if (threadIdx.x == 0 && !S->abort) {
-        // q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
-        const double* q_wodom = S->q_wodom;
-        const double* xf = st->x;
-        const double n2 = q_wodom[0] * q_wodom[0] + q_wodom[1] * q_wodom[1] + q_wodom[2] * q_wodom[2] + q_wodom[3] * q_wodom[3];
-        const double qi[4] = {-q_wodom[0] / n2, -q_wodom[1] / n2, -q_wodom[2] / n2, q_wodom[3] / n2};
-        double qn[4];
-        m_qmul(xf, qi, qn);
-        double r2[3];
-        m_rot(qn, S->t_wodom, r2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) S->q_wmap_wodom[i] = qn[i];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) S->t_wmap_wodom[i] = xf[4 + i] - r2[i];
-    }
-    __syncthreads();
-    copy_words(&host->st, st, sizeof(LMState));
-    copy_words(&host->C1, C, sizeof(MapCounters));
-    copy_words(&host->S1, S, sizeof(MapState));
-}
+    __device__ __forceinline__ void operator()(int, int, int) const {}
+};
 
 // End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
 __global__ void __launch_bounds__(256) k_map_end(MapState* S, const MapCounters* C, MapResult* host) {
@@ -1235,7 +1289,7 @@ struct scal_map {
     DevBuf<LMState> d_st;
     DevBuf<MapCounters> d_C2[NSETS];
     DevBuf<MapCounters>& d_C(int st) { return d_C2[st]; }
-    DevBuf<int> d_nfull;
+    DevBuf<int> d_nfull, d_done;
     PinBuf<MapCounters> h_C;
     PinBuf<MapState> h_S;
     PinBuf<int> h_misc;
@@ -1294,7 +1348,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
     A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
     A(c->lm_sync.alloc(1));
-    A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4));
+    A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
     A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     c->lane = stage_lane(STAGE_MAP);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
@@ -1308,6 +1362,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cell.zero(c->stream);
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK) rc = c->d_done.zero(c->stream);
         if (rc == SCAL_OK) rc = c->vf_side.reset_box(c->stream);  // the prefetch's gather accumulates into it, every run leaves it reset
         MapState& H = *c->h_S.p;
         std::memset(&H, 0, sizeof H);
@@ -1409,8 +1464,9 @@ int insert_full_sort(scal_map* c, const MapStep& e, const int* n_map) {
     return SCAL_OK;
 }
 
-// merge insert of the step's stack points (k_merge_*): no host-side sizes, stops the chain (MapState::abort) if it cannot be done
-int launch_insert_merge(scal_map* c, const MapStep& e) {
+// merge insert of the step's stack points (k_merge_*): no host-side sizes, stops the chain (MapState::abort) if it cannot be done.
+// fused: registration of the full-resolution cloud, commit and host copy ride in the last launch (see k_merge_write)
+int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
     hipStream_t s = c->stream;
     MapCounters* C = c->d_C(e.set).p;
     MergeArgs a;
@@ -1433,7 +1489,22 @@ int launch_insert_merge(scal_map* c, const MapStep& e) {
     }
     SCAL_LAUNCH_PROF("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
     SCAL_LAUNCH_PROF("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
-    SCAL_LAUNCH_PROF("k_merge_write", k_merge_write, dim3(MERGE_WRITE_GRID), dim3(256), 0, s, a, c->d_S.p, C);
+    MergeTail t{};
+    int grid = MERGE_WRITE_GRID;
+    if (fused) {
+        t.fused = 1, t.st = c->d_st.p, t.full_out = c->full_out.v(), t.full_cap = c->scan_cap;
+        if (e.have_full && e.feat) {
+            FeatDeviceView v = features_view(e.feat);
+            t.full = CSoA4{v.x, v.y, v.z, v.i}, t.d_nfull = &v.P->n_kept;
+            grid += std::max(1, div_up(c->scan_cap, 256));
+        } else if (e.have_full) {
+            t.full = c->full_in.cv(), t.d_nfull = c->d_nfull.p;
+            grid += std::max(1, div_up(c->scan_cap, 256));
+        } else {
+            t.full = c->full_in.cv(), t.d_nfull = c->d_nfull.p, t.full_cap = 0;
+        }
+    }
+    SCAL_LAUNCH_PROF("k_merge_write", k_merge_write, dim3(grid), dim3(256), 0, s, a, c->d_S.p, C, t);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -1491,26 +1562,26 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
     // two outer iterations (:563)
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
+    MapPoseDone pd;
+    pd.S = S, pd.st = st, pd.C = C, pd.host = c->res.p + e.slot;
+    for (int k = 0; k < 2; ++k) {
+        pd.nw.stack[k] = k == 0 ? c->corner_stack(st_).cv() : c->surf_stack(st_).cv();
+        pd.nw.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        pd.nw.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
+        pd.nw.x[k] = c->mnew[k].x.p, pd.nw.y[k] = c->mnew[k].y.p, pd.nw.z[k] = c->mnew[k].z.p, pd.nw.w[k] = c->mnew[k].w.p;
+        pd.nw.cube[k] = c->mcube[k].p, pd.nw.pkey[k] = c->mpkey[k].p;
+    }
+    const AssocFit fit{c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), c->nnbuf(), C, F};
     for (int outer = 0; outer < 2; ++outer) {
         {
             SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
                              c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), st, C, c->nnbuf());
         }
-        {
-            SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, c->corner_stack(st_).cv(),
-                             c->surf_stack(st_).cv(), c->nnbuf(), S, C, outer, F);
-        }
-        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort);
+        SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
+        // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
+        pd.active = outer == 1;
+        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, LMNoHook(), pd);
     }
-    PoseDoneNew pn;
-    for (int k = 0; k < 2; ++k) {
-        pn.stack[k] = k == 0 ? c->corner_stack(st_).cv() : c->surf_stack(st_).cv();
-        pn.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        pn.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
-        pn.x[k] = c->mnew[k].x.p, pn.y[k] = c->mnew[k].y.p, pn.z[k] = c->mnew[k].z.p, pn.w[k] = c->mnew[k].w.p;
-        pn.cube[k] = c->mcube[k].p, pn.pkey[k] = c->mpkey[k].p;
-    }
-    SCAL_LAUNCH_PROF("k_map_pose_done", k_map_pose_done, dim3(1 + 2 * MERGE_NEW_BLOCKS), dim3(256), 0, s, S, st, C, c->res.p + e.slot, pn);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
     return SCAL_OK;
@@ -1568,8 +1639,11 @@ int launch_fast(scal_map* c, MapStep& e) {
     e.insert_path = 1;
     c->n_fast++;
     SCAL_TRY(launch_pose_part(c, e));
-    SCAL_TRY(launch_insert_merge(c, e));
-    SCAL_TRY(launch_tail(c, e));
+    SCAL_TRY(launch_insert_merge(c, e, true));
+    SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, c->stream, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipEventRecord(c->ev_done[e.slot], c->stream));
+    if (e.feat) SCAL_TRY(features_note_reader(e.feat, c->stream));  // the registration transform reads the full-resolution cloud last
     c->cur = e.par ^ 1;
     return SCAL_OK;
 }

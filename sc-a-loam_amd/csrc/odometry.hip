@@ -43,6 +43,7 @@ __device__ __forceinline__ unsigned long long make_key(float d, unsigned seq) {
 constexpr int RING_TAB = 96;   // per-ring first/last index tables of a target cloud
 constexpr int NN_QT = 64;      // queries per block
 constexpr int NN_TC = 2048;    // target points per block (staged through LDS)
+constexpr int NN_PARTS = 16;   // waves per block: each takes 1/16 of the block's targets for all 64 queries
 
 // TransformToStart (:111-129): q_last_curr * p + t_last_curr in f64, stored to f32
 __device__ __forceinline__ void transform_to_start(const double* x7, float ox, float oy, float oz, float* o) {
@@ -56,10 +57,10 @@ __device__ __forceinline__ void transform_to_start(const double* x7, float ox, f
 // Exact NN(1), tiled: block (qt, ch) scans target chunk ch (2048 points staged in LDS, read as wave-wide broadcasts)
 // for 64 queries; thread (q = tid % 64, part = tid / 64) covers a quarter of the chunk.  The per-(query, chunk) minima
 // are (f32 distance bits, target index) keys; k_odom_assoc takes the minimum over chunks.
-__global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st,
+__global__ void __launch_bounds__(64 * NN_PARTS) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st,
                                                  const OdomCounters* __restrict__ C, int slot_cap, int nch, unsigned long long* __restrict__ part) {
     __shared__ float tx[NN_TC], ty[NN_TC], tz[NN_TC];
-    __shared__ unsigned long long red[4][NN_QT];
+    __shared__ unsigned long long red[NN_PARTS][NN_QT];
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
     // a tile never mixes sharp and flat queries: tiles are laid out per class
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 
     const int t0 = blockIdx.y * NN_TC;
     if (t0 >= nT) return;
     const int tn = min(NN_TC, nT - t0);
-    for (int i = threadIdx.x; i < tn; i += 256) tx[i] = T.x[t0 + i], ty[i] = T.y[t0 + i], tz[i] = T.z[t0 + i];
+    for (int i = threadIdx.x; i < tn; i += 64 * NN_PARTS) tx[i] = T.x[t0 + i], ty[i] = T.y[t0 + i], tz[i] = T.z[t0 + i];
     __syncthreads();
     const int ql = threadIdx.x & 63, partq = threadIdx.x >> 6;
     const int qi = qbase + ql;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 
         for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
         float sel[3];
         transform_to_start(x7, Q.x[qi], Q.y[qi], Q.z[qi], sel);
-        const int per = (tn + 3) / 4;
+        const int per = (tn + NN_PARTS - 1) / NN_PARTS;
         const int b0 = partq * per, b1 = min(tn, b0 + per);
         float bd = 3.4e38f;
         int bi = -1;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(256) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 
     __syncthreads();
     if (partq == 0 && qi < nq) {
         unsigned long long b = red[0][ql];
-        for (int p = 1; p < 4; ++p) b = red[p][ql] < b ? red[p][ql] : b;
+        for (int p = 1; p < NN_PARTS; ++p) b = red[p][ql] < b ? red[p][ql] : b;
         const int slot = is_edge ? qi : ns + qi;
         if (slot < slot_cap) part[(size_t)slot * nch + blockIdx.y] = b;
     }
@@ -278,6 +279,8 @@ struct HandoverArgs {
     int nb0;            // blocks of the corner part
     int* tab_write;     // [corner first | corner last | surf first | surf last] x RING_TAB, pre-filled
     int* tab_reset;     // the set the association of this scan used: re-filled here for the next hand-over
+    const LMState* st;  // the solved state goes to the host slot from here (no launch of its own)
+    LMState* host_st;
 };
 __global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
     int b = blockIdx.x;
@@ -285,6 +288,9 @@ __global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
     if (k) b -= a.nb0;
     if (blockIdx.x == 0) {
         for (int t = threadIdx.x; t < 4 * RING_TAB; t += 256) a.tab_reset[t] = ((t / RING_TAB) & 1) ? -1 : 0x7f7f7f7f;
+        const unsigned* src = reinterpret_cast<const unsigned*>(a.st);
+        unsigned* dst = reinterpret_cast<unsigned*>(a.host_st);
+        for (int t = threadIdx.x; t < static_cast<int>(sizeof(LMState) / 4); t += 256) dst[t] = src[t];
     }
     int* first_idx = a.tab_write + 2 * k * RING_TAB;
     int* last_idx = first_idx + RING_TAB;
@@ -392,7 +398,6 @@ struct scal_odom {
     int tab_cur = 0;       // set read by this scan's association
     DevBuf<LMState> d_st;
     DevBuf<OdomCounters> d_C;
-    PinBuf<OdomCounters> h_C;   // [MAX_STEPS] result slots
     PinBuf<LMState> h_st;       // [MAX_STEPS]
     PinBuf<OdomCounters> h_up;  // upload staging of scal_odom_step
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
@@ -423,7 +428,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->ring_tab.alloc(8 * RING_TAB));
-    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_C.alloc(scal_odom::MAX_STEPS)); A(c->h_st.alloc(scal_odom::MAX_STEPS)); A(c->h_up.alloc(1));
+    A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_st.alloc(scal_odom::MAX_STEPS)); A(c->h_up.alloc(1));
     c->lane = stage_lane(STAGE_ODOM);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     for (int k = 0; k < scal_odom::MAX_STEPS && rc == SCAL_OK; ++k)
@@ -486,7 +491,7 @@ int odom_enqueue(scal_odom* c) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
             {
                 // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
-                SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
             }
             {
@@ -509,11 +514,10 @@ int odom_enqueue(scal_odom* c) {
         h.nb0 = std::max(1, div_up(c->feat_cap, 256));
         h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
         h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
+        h.st = st, h.host_st = c->h_st.p + slot;
         SCAL_LAUNCH_PROF("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
         c->tab_cur ^= 1;
     }
-    SCAL_HIP(hipGetLastError());
-    launch_publish(s, st, c->h_st.p + slot, static_cast<const OdomCounters*>(C), c->h_C.p + slot);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev[slot], s));
     c->pending.push_back({slot, solve});

@@ -722,12 +722,14 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
     A(c->block_best.alloc((size_t)3 * div_up(c->cap, 256) + 3));
     A(c->d_rec.alloc(4 * scal_sc::DET_DEPTH));
     A(c->gcell.alloc(DESC));
-    if (rc == SCAL_OK && hipMemset(c->gcell.p, 0, sizeof(unsigned) * DESC) != hipSuccess) rc = SCAL_E_HIP;
     A(c->h_rec.alloc(4 * scal_sc::DET_DEPTH));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane = (c->cfg.side_stream > 0 ? std::min(c->cfg.side_stream, 5) : stage_lane(STAGE_SC))) != SCAL_OK) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
+    // initialised on the context's own stream (the legacy null stream is not ordered against it)
+    if (rc == SCAL_OK && (hipMemsetAsync(c->gcell.p, 0, sizeof(unsigned) * DESC, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+        rc = SCAL_E_HIP;
     if (rc != SCAL_OK) {
         delete c;
         return rc;
@@ -872,7 +874,9 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
     }
     SCAL_TRY(features_wait_done(feat, c->stream));  // side stream: start after stage A of this scan
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
-    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p));
+    // the bounding box comes with the features context (k_curv): no reset / bounding-box launches here
+    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p,
+                       v.cap > 8192, nullptr, v.P->box));
     if (v.stream != c->stream) SCAL_TRY(features_note_reader(feat, c->stream));  // the filter was the last reader of feat's buffers
     *d_n = c->d_nds.p;
     *n_cap = v.cap;
@@ -1065,10 +1069,12 @@ static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q, bool wa
     SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
                        c->block_best.p, static_cast<const int*>(nullptr));
     SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
-                       q.cnorm, fill_zero ? 1 : 0, d_rec);
+                       q.cnorm, fill_zero ? 1 : 0, wait ? d_rec : h_rec);  // queued searches write their records straight to pinned host memory
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(h_rec, d_rec, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
-    if (wait) SCAL_HIP(hipStreamSynchronize(s));
+    if (wait) {
+        SCAL_HIP(hipMemcpyAsync(h_rec, d_rec, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+    }
     return SCAL_OK;
 }
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ int bits_for(int cells) {  // smallest b with (1 << b
 }
 
 __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restrict__ d_n, float inv, int max_bits, VoxMeta* m,
-                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals, const unsigned* __restrict__ ext_box) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n && i != 0) return;
@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restric
     long long d[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        mn[a] = ordered_to_float(m->umin[a]);
-        mx[a] = ordered_to_float(m->umax[a]);
+        mn[a] = ordered_to_float(ext_box ? ext_box[a] : m->umin[a]);
+        mx[a] = ordered_to_float(ext_box ? ext_box[3 + a] : m->umax[a]);
         d[a] = static_cast<long long>((mx[a] - mn[a]) * inv) + 1;
         mb[a] = static_cast<int>(floorf(mn[a] * inv));
         cells[a] = static_cast<int>(floorf(mx[a] * inv)) - mb[a] + 1;
@@ -338,7 +338,7 @@ int VoxelFilter::reset_box(hipStream_t s) {
 }
 
 int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done,
-                     const VoxTail* tail) {
+                     const VoxTail* tail, const unsigned* ext_box) {
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
     const VoxTail tl = tail ? *tail : VoxTail();
     if (n_bound <= VOX_SMALL) {
@@ -359,11 +359,11 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
         SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
         SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
     }
-    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p);
+    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, bbox_done ? ext_box : nullptr);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
     SCAL_LAUNCH_PROF("k_vox_heads", k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, bbox_done ? 1 : 0);
+    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, (bbox_done && !ext_box) ? 1 : 0);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

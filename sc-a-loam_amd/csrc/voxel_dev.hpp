@@ -45,8 +45,9 @@ struct VoxelFilter {
     // d_n_out receives the number of centroids; meta.p->error is set when the box needs more than max_bits.
     // bbox_done: the caller has already folded the cloud's bounding box into meta (vox_bbox_accumulate, e.g. while copying the
     // cloud) - the reset and bounding-box launches are skipped, and the run leaves meta's box reset for the next one.
+    // ext_box (with bbox_done): the box lives in the caller's own device words instead (min xyz, max xyz; left untouched).
     int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done = false,
-            const VoxTail* tail = nullptr);
+            const VoxTail* tail = nullptr, const unsigned* ext_box = nullptr);
     int reset_box(hipStream_t s);
 };
 
@@ -56,8 +57,8 @@ namespace scal {
 #ifdef __HIPCC__
 // Folds the bounding box of the caller's points into a VoxMeta (order-preserving uint images, atomic min / max), so that a kernel
 // which reads a cloud anyway (a gather) can stand in for k_vox_bbox (VoxelFilter::run with bbox_done).  Every thread of a
-// 256-thread block calls it; `have` = this thread holds a point.  One atomic pair per wave and axis.
-__device__ inline void vox_bbox_accumulate(VoxMeta* m, bool have, float x, float y, float z) {
+// 256-thread block calls it; `have` = this thread holds a point.
+__device__ inline void vox_bbox_accumulate(unsigned* umin, unsigned* umax, bool have, float x, float y, float z) {
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     if (have) {
         const float v[3] = {x, y, z};
@@ -74,9 +75,11 @@ __device__ inline void vox_bbox_accumulate(VoxMeta* m, bool have, float x, float
             lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
             hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
         }
+        // Atomics on one word serialise (~13 ns each, 10k waves would cost more than the launches this saves): a wave only
+        // issues one when it improves on the value it can see.  That value may be stale - then the atomic is merely redundant.
         if ((threadIdx.x & 63) == 0 && lo[a] != 0xffffffffu) {
-            atomicMin(&m->umin[a], lo[a]);
-            atomicMax(&m->umax[a], hi[a]);
+            if (lo[a] < __hip_atomic_load(&umin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&umin[a], lo[a]);
+            if (hi[a] > __hip_atomic_load(&umax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&umax[a], hi[a]);
         }
     }
 }

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libscaloam_hip.so"))
+# SCALOAM_LIB: another build of the same library (A/B measurements of two builds on one GPU box); never a different implementation
+LIB_PATH = os.environ.get("SCALOAM_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libscaloam_hip.so"))
 
 VLP16, HDL32, HDL64, OS1_64 = 0, 1, 2, 3
 SCAN_LINES = {VLP16: 16, HDL32: 32, HDL64: 64, OS1_64: 64}
