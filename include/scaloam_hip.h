@@ -96,6 +96,10 @@ int scal_features_create(const scal_features_config* cfg, scal_features_t** ctx)
 void scal_features_destroy(scal_features_t* ctx);
 /* host input: xyz at xyz + i*stride_bytes (PointCloud2 layout). Synchronous. */
 int scal_features_run(scal_features_t* ctx, const void* xyz, int n, int stride_bytes, scal_features_out* out);
+/* host input, asynchronous: the scan is copied into pinned staging (the caller's buffer is free on return), uploaded and
+ * processed on the context's stream; results stay on the GPU as with scal_features_run_device (the PointCloud2 callback of
+ * scanRegistration.cpp:116 when the later stages consume the device-resident results) */
+int scal_features_enqueue_host(scal_features_t* ctx, const void* xyz, int n, int stride_bytes);
 /* device input (float*, stride in floats), asynchronous on the context's stream; results stay on the GPU
  * for scal_odom_step_features / scal_map_step_features / scal_sc_insert_features. */
 int scal_features_run_device(scal_features_t* ctx, const float* d_xyz, int n, int stride_floats);

@@ -103,7 +103,6 @@ __global__ void k_pre(const float* __restrict__ in, int n, int stride, KCfg c, F
         P->error = 0;
         P->n_tied = 0;
         P->n_kept = 0;
-        for (int a = 0; a < 3; ++a) P->box[a] = 0xffffffffu, P->box[3 + a] = 0u;
         if (s_last >= 0) {
             const size_t f = (size_t)s_first * stride, l = (size_t)s_last * stride;
             float startOri = neg_atan2f_cr(in[f + 1], in[f]);                                      // :143
@@ -249,14 +248,14 @@ __global__ void __launch_bounds__(256) k_scatter(const float* __restrict__ in, i
     }
 }
 
-__global__ void __launch_bounds__(256) k_curv(FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
+__global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
                                               const float* __restrict__ z, float* __restrict__ curv, int* __restrict__ label,
-                                              unsigned char* __restrict__ gap) {
+                                              unsigned char* __restrict__ gap, unsigned* __restrict__ box_parts) {
     const int n = P->n_kept;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (static_cast<int>(blockIdx.x * blockDim.x) >= n) return;  // uniform over the block
-    // bounding box of the ordered cloud on the way (the ScanContext keyframe filter starts from it instead of two launches)
-    vox_bbox_accumulate(P->box, P->box + 3, i < n, i < n ? x[i] : 0.f, i < n ? y[i] : 0.f, i < n ? z[i] : 0.f);
+    // bounding box of the ordered cloud on the way, one part per block (the ScanContext keyframe filter starts from the parts
+    // instead of two launches of its own)
+    vox_bbox_block_store(box_parts, blockIdx.x, i < n, i < n ? x[i] : 0.f, i < n ? y[i] : 0.f, i < n ? z[i] : 0.f);
     if (i >= n) return;
     float c = 0.f;
     if (i >= 5 && i < n - 5) {  // :269-275, summed left to right exactly as written
@@ -709,6 +708,8 @@ struct scal_features {
     DevBuf<float> f_sharp, f_less, f_flat;  // xyzi of the picked points
     DevBuf<float> d_aos;  // AoS staging for fetch
     DevBuf<FeatParams> d_P;
+    DevBuf<unsigned> d_boxparts;  // [ceil(cap / 256)][6]
+    int n_box_parts = 0;
     PinBuf<FeatParams> h_P;
     bool ran = false;
     int last_n = 0;
@@ -721,6 +722,7 @@ FeatDeviceView features_view(scal_features* c) {
     v.x = c->ox.p, v.y = c->oy.p, v.z = c->oz.p, v.i = c->oi.p;
     v.lfx = c->lx.p, v.lfy = c->ly.p, v.lfz = c->lz.p, v.lfi = c->li.p;
     v.sharp_xyzi = c->f_sharp.p, v.less_xyzi = c->f_less.p, v.flat_xyzi = c->f_flat.p;
+    v.box_parts = c->d_boxparts.p, v.n_box_parts = c->n_box_parts;
     v.cap = c->cap;
     v.stream = c->stream;
     v.device = c->cfg.device;
@@ -803,6 +805,7 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     A(c->f_sharp.alloc(ns * 6 * 2 * 4)); A(c->f_less.alloc(ns * 6 * 20 * 4)); A(c->f_flat.alloc(ns * 6 * 4 * 4));
     A(c->d_aos.alloc((size_t)cap * 4));
     A(c->d_P.alloc(1));
+    A(c->d_boxparts.alloc((size_t)6 * (div_up(cap, 256) + 1)));
     A(c->h_P.alloc(1));
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream) != SCAL_OK) {
         set_error("hipStreamCreate failed");
@@ -871,7 +874,8 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     SCAL_LAUNCH_PROF("k_scatter", k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
                        c->oz.p, c->oi.p, c->d_src.p);
     const int nb256 = max(1, div_up(n, 256));
-    SCAL_LAUNCH_PROF("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p);
+    SCAL_LAUNCH_PROF("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p, c->d_boxparts.p);
+    c->n_box_parts = nb256;
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
     {
         SCAL_LAUNCH_PROF("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
@@ -964,7 +968,7 @@ extern "C" int scal_features_fetch(scal_features_t* c, scal_features_out* o) {
     return SCAL_OK;
 }
 
-extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int stride_bytes, scal_features_out* out) {
+static int features_run_host(scal_features_t* c, const void* xyz, int n, int stride_bytes, scal_features_out* out, bool no_wait) {
     if (!c || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || (stride_bytes % 4) != 0 || stride_bytes > 32) {
         set_error("scal_features_run: bad argument (stride_bytes must be a multiple of 4 in [12, 32])");
         return SCAL_E_ARG;
@@ -986,6 +990,15 @@ extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int
         c->up_used[slot] = true;
     }
     SCAL_TRY(launch_chain(c, c->d_in.p, n, stride_bytes / 4));
+    if (no_wait) return SCAL_OK;
     if (out) return scal_features_fetch(c, out);
     return scal_features_sync(c);
+}
+
+extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int stride_bytes, scal_features_out* out) {
+    return features_run_host(c, xyz, n, stride_bytes, out, false);
+}
+
+extern "C" int scal_features_enqueue_host(scal_features_t* c, const void* xyz, int n, int stride_bytes) {
+    return features_run_host(c, xyz, n, stride_bytes, nullptr, true);
 }

@@ -16,7 +16,6 @@ struct FeatParams {
     int n_sharp, n_less_sharp, n_flat, n_less_flat;
     int lf_ring_cnt[64];
     int lf_ring_off[65];
-    unsigned box[6];  // bounding box of the ordered cloud, order-preserving uint images: min xyz, max xyz (consumers: voxel filters)
 };
 
 struct FeatDeviceView {
@@ -24,6 +23,8 @@ struct FeatDeviceView {
     const float *x, *y, *z, *i;          // ordered cloud, SoA, P->n_kept points
     const float *lfx, *lfy, *lfz, *lfi;  // lessFlat cloud, SoA, P->n_less_flat points
     const float *sharp_xyzi, *less_xyzi, *flat_xyzi;  // picked points, AoS xyzi
+    const unsigned* box_parts;           // per-block bounding boxes of the ordered cloud (vox_bbox_block_store), n_box_parts blocks
+    int n_box_parts;
     int cap;
     hipStream_t stream;
     int device;

@@ -567,10 +567,10 @@ inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* 
 // host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
 template <class Pre = LMNoHook, class Post = LMNoHook>
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
-                            int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post()) {
+                            int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {
     int g = (f.cap + 255) / 256;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
-    SCAL_LAUNCH_PROF("k_lm_solve", (k_lm_solve<Pre, Post>), dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
+    SCAL_LAUNCH_PROF(prof_name, (k_lm_solve<Pre, Post>), dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
 }
 
 }  // namespace scal

@@ -990,10 +990,10 @@ __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __
 
 // Start of a device-resident step in ONE launch: clears the per-scan counters and copies the lessSharp cloud (xyzi records)
 // and the lessFlat cloud (SoA) of a features context into corner_in / surf_in.  Blocks [0,nbc) corner, the rest surf.
-// surf_box != null: the bounding box of the surf cloud is folded into that VoxMeta on the way (stands in for k_vox_bbox).
+// surf_parts != null: every surf block stores the bounding box of its points there (stands in for k_vox_bbox, see VoxelFilter::run).
 __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ less_aos, const int* __restrict__ d_n_less, CSoA4 less_flat,
                                                     const int* __restrict__ d_n_less_flat, SoA4 corner_in, SoA4 surf_in, MapCounters* C, int cap,
-                                                    int nbc, VoxMeta* surf_box) {
+                                                    int nbc, unsigned* surf_parts) {
     const bool corner = static_cast<int>(blockIdx.x) < nbc;
     const int b = corner ? blockIdx.x : blockIdx.x - nbc;
     const int n = min(corner ? *d_n_less : *d_n_less_flat, cap);
@@ -1008,13 +1008,12 @@ __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ le
         const float4 p = reinterpret_cast<const float4*>(less_aos)[i];
         corner_in.x[i] = p.x, corner_in.y[i] = p.y, corner_in.z[i] = p.z, corner_in.w[i] = p.w;
     } else {
-        if (b * 256 >= n) return;  // uniform over the block
         float x = 0.f, y = 0.f, z = 0.f;
         if (i < n) {
             x = less_flat.x[i], y = less_flat.y[i], z = less_flat.z[i];
             surf_in.x[i] = x, surf_in.y[i] = y, surf_in.z[i] = z, surf_in.w[i] = less_flat.w[i];
         }
-        if (surf_box) vox_bbox_accumulate(surf_box->umin, surf_box->umax, i < n, x, y, z);
+        if (surf_parts) vox_bbox_block_store(surf_parts, b, i < n, x, y, z);
     }
 }
 
@@ -1288,6 +1287,7 @@ struct scal_map {
     NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
     DevBuf<LMState> d_st;
     DevBuf<MapCounters> d_C2[NSETS];
+    DevBuf<unsigned> surf_parts[NSETS];  // per-block bounding boxes of surf_in (written by the prefetch's gather)
     DevBuf<MapCounters>& d_C(int st) { return d_C2[st]; }
     DevBuf<int> d_nfull, d_done;
     PinBuf<MapCounters> h_C;
@@ -1324,6 +1324,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     for (int k = 0; k < scal_map::NSETS; ++k) {
         A(c->corner_in2[k].alloc(sc)); A(c->surf_in2[k].alloc(sc)); A(c->corner_stack2[k].alloc(sc)); A(c->surf_stack2[k].alloc(sc));
         A(c->d_C2[k].alloc(1));
+        A(c->surf_parts[k].alloc((size_t)6 * (div_up(c->scan_cap, 256) + 1)));
     }
     A(c->full_in.alloc(sc)); A(c->full_out.alloc(sc));
     A(c->vf.init(c->scan_cap));
@@ -1363,7 +1364,6 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK) rc = c->d_done.zero(c->stream);
-        if (rc == SCAL_OK) rc = c->vf_side.reset_box(c->stream);  // the prefetch's gather accumulates into it, every run leaves it reset
         MapState& H = *c->h_S.p;
         std::memset(&H, 0, sizeof H);
         H.q_wmap_wodom[3] = 1.0;
@@ -1414,15 +1414,16 @@ int enqueue_corner_filter(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_cor
     VoxTail tc;
     tc.err_out = &C->error;
     const int bits_c = c->cfg.line_res >= 0.35f ? 30 : 40;
-    return vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, bits_c, c->corner_stack(st).v(), &C->n_corner_stack, false, &tc);
+    return vf.run(s, c->corner_in(st).cv(), &C->n_corner_in, n_corner_bound, c->cfg.line_res, bits_c, c->corner_stack(st).v(), &C->n_corner_stack, &tc);
 }
 int enqueue_surf_filter(scal_map* c, VoxelFilter& vf, hipStream_t s, int n_surf_bound, int st, bool surf_box_done) {
     MapCounters* C = c->d_C(st).p;
     VoxTail ts;
     ts.err_out = &C->error;
     const int bits_s = c->cfg.plane_res >= 0.35f ? 30 : 40;
-    const bool box = surf_box_done && n_surf_bound > 8192;
-    return vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, bits_s, c->surf_stack(st).v(), &C->n_surf_stack, box, &ts);
+    const bool box = surf_box_done && n_surf_bound > 8192;  // the gather stored per-block boxes of the surf cloud
+    return vf.run(s, c->surf_in(st).cv(), &C->n_surf_in, n_surf_bound, c->cfg.plane_res, bits_s, c->surf_stack(st).v(), &C->n_surf_stack, &ts,
+                  box ? c->surf_parts[st].p : nullptr, box ? std::max(1, div_up(n_surf_bound, 256)) : 0);
 }
 int enqueue_stack_filters(scal_map* c, VoxelFilter& vfc, VoxelFilter& vfs, hipStream_t s, int n_corner_bound, int n_surf_bound, int st,
                           bool surf_box_done) {
@@ -1548,7 +1549,7 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
             const int nbc = std::max(1, div_up(e.n_corner_bound, 256));
             SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
                                CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st_).v(), c->surf_in(st_).v(), C, c->scan_cap, nbc,
-                               static_cast<VoxMeta*>(nullptr));
+                               static_cast<unsigned*>(nullptr));
         }
     }
     if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
@@ -1580,7 +1581,7 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
         SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
         // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
         pd.active = outer == 1;
-        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, LMNoHook(), pd);
+        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, LMNoHook(), pd, "k_lm_solve_map");
     }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
@@ -1933,10 +1934,10 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     // slow every stream down on this GPU, and stage A's stream has room.)
     hipStream_t sa = v.stream;
     const int nbc = std::max(1, div_up(ls_cap, 256));
-    c->pre_a_used[nset] = ls_cap <= 8192;  // else the corner cloud takes the radix path on the side stream and owns vf_side's box first
+    c->pre_a_used[nset] = ls_cap <= 8192;  // else the corner cloud takes the radix path on the side stream
     SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, sa, v.less_xyzi, &v.P->n_less_sharp,
                      CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc,
-                     c->pre_a_used[nset] ? c->vf_side.meta.p : static_cast<VoxMeta*>(nullptr));
+                     c->surf_parts[nset].p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_gather[nset], sa));
     if (c->pre_a_used[nset]) {
@@ -1945,7 +1946,7 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     }
     SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_gather[nset], 0));
     if (!c->pre_a_used[nset]) SCAL_TRY(enqueue_corner_filter(c, c->vf_side, c->side, ls_cap, nset));
-    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, c->pre_a_used[nset]));
+    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, true));
     SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
     c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
     c->n_pf++;

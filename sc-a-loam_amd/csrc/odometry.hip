@@ -499,7 +499,7 @@ int odom_enqueue(scal_odom* c) {
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
             }
             {
-                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, c->lm_sync.p, outer);
+                                launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, c->lm_sync.p, outer, nullptr, LMNoHook(), LMNoHook(), "k_lm_solve_odom");
             }
         }
     }

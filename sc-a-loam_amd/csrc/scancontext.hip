@@ -874,9 +874,9 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
     }
     SCAL_TRY(features_wait_done(feat, c->stream));  // side stream: start after stage A of this scan
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
-    // the bounding box comes with the features context (k_curv): no reset / bounding-box launches here
+    // the bounding box comes with the features context (per-block parts from k_curv): no reset / bounding-box launches here
     SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p,
-                       v.cap > 8192, nullptr, v.P->box));
+                       nullptr, v.box_parts, v.n_box_parts));
     if (v.stream != c->stream) SCAL_TRY(features_note_reader(feat, c->stream));  // the filter was the last reader of feat's buffers
     *d_n = c->d_nds.p;
     *n_cap = v.cap;

@@ -57,17 +57,41 @@ __device__ __forceinline__ int bits_for(int cells) {  // smallest b with (1 << b
 }
 
 __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restrict__ d_n, float inv, int max_bits, VoxMeta* m,
-                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals, const unsigned* __restrict__ ext_box) {
+                                                  unsigned long long* __restrict__ keys, int* __restrict__ vals, const unsigned* __restrict__ ext_parts, int n_parts) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (static_cast<int>(blockIdx.x * blockDim.x) >= n && blockIdx.x != 0) return;  // uniform over the block
+    __shared__ unsigned s_box[6];
+    if (ext_parts) {  // the box arrives as per-block parts: every block reduces them (L2-resident, a few KB)
+        __shared__ unsigned s_w[4][6];
+        unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+        for (int b = threadIdx.x; b < n_parts; b += 256)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) lo[a] = min(lo[a], ext_parts[b * 6 + a]), hi[a] = max(hi[a], ext_parts[b * 6 + 3 + a]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
+                hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
+            }
+            if (lane_id() == 0) s_w[wave_id()][a] = lo[a], s_w[wave_id()][3 + a] = hi[a];
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) s_box[threadIdx.x] = min(min(s_w[0][threadIdx.x], s_w[1][threadIdx.x]), min(s_w[2][threadIdx.x], s_w[3][threadIdx.x]));
+        else if (threadIdx.x < 6) s_box[threadIdx.x] = max(max(s_w[0][threadIdx.x], s_w[1][threadIdx.x]), max(s_w[2][threadIdx.x], s_w[3][threadIdx.x]));
+    } else if (threadIdx.x < 6) {
+        s_box[threadIdx.x] = threadIdx.x < 3 ? m->umin[threadIdx.x] : m->umax[threadIdx.x - 3];
+    }
+    __syncthreads();
     if (i >= n && i != 0) return;
     float mn[3], mx[3];
     int mb[3], cells[3];
     long long d[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        mn[a] = ordered_to_float(ext_box ? ext_box[a] : m->umin[a]);
-        mx[a] = ordered_to_float(ext_box ? ext_box[3 + a] : m->umax[a]);
+        mn[a] = ordered_to_float(s_box[a]);
+        mx[a] = ordered_to_float(s_box[3 + a]);
         d[a] = static_cast<long long>((mx[a] - mn[a]) * inv) + 1;
         mb[a] = static_cast<int>(floorf(mn[a] * inv));
         cells[a] = static_cast<int>(floorf(mx[a] * inv)) - mb[a] + 1;
@@ -331,14 +355,8 @@ int VoxelFilter::init(int capacity) {
     return SCAL_OK;
 }
 
-int VoxelFilter::reset_box(hipStream_t s) {
-    SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
-    SCAL_HIP(hipGetLastError());
-    return SCAL_OK;
-}
-
-int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done,
-                     const VoxTail* tail, const unsigned* ext_box) {
+int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, const VoxTail* tail,
+                     const unsigned* ext_parts, int n_parts) {
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
     const VoxTail tl = tail ? *tail : VoxTail();
     if (n_bound <= VOX_SMALL) {
@@ -355,15 +373,15 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
         return SCAL_OK;
     }
     const int nb = max(1, div_up(min(cap, n_bound), 256));
-    if (!bbox_done) {
+    if (!ext_parts) {
         SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
         SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
     }
-    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, bbox_done ? ext_box : nullptr);
+    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
     SCAL_LAUNCH_PROF("k_vox_heads", k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, (bbox_done && !ext_box) ? 1 : 0);
+    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, 0);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

@@ -43,22 +43,22 @@ struct VoxelFilter {
     // (computed on the device); max_bits bounds the passes the host enqueues (a multiple of 9 avoids waste).
     // n_bound: host-known upper bound of *d_n; clouds of <= 8192 points take a single-workgroup LDS path.
     // d_n_out receives the number of centroids; meta.p->error is set when the box needs more than max_bits.
-    // bbox_done: the caller has already folded the cloud's bounding box into meta (vox_bbox_accumulate, e.g. while copying the
-    // cloud) - the reset and bounding-box launches are skipped, and the run leaves meta's box reset for the next one.
-    // ext_box (with bbox_done): the box lives in the caller's own device words instead (min xyz, max xyz; left untouched).
-    int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, bool bbox_done = false,
-            const VoxTail* tail = nullptr, const unsigned* ext_box = nullptr);
-    int reset_box(hipStream_t s);
+    // ext_parts / n_parts: per-block boxes of the cloud written by an earlier kernel (vox_bbox_block_store): the reset and
+    // bounding-box launches are skipped, the key kernel reduces the parts itself.
+    int run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float leaf, int max_bits, SoA4 out, int* d_n_out, const VoxTail* tail = nullptr,
+            const unsigned* ext_parts = nullptr, int n_parts = 0);
 };
 
 }  // namespace scal
 
 namespace scal {
 #ifdef __HIPCC__
-// Folds the bounding box of the caller's points into a VoxMeta (order-preserving uint images, atomic min / max), so that a kernel
-// which reads a cloud anyway (a gather) can stand in for k_vox_bbox (VoxelFilter::run with bbox_done).  Every thread of a
-// 256-thread block calls it; `have` = this thread holds a point.
-__device__ inline void vox_bbox_accumulate(unsigned* umin, unsigned* umax, bool have, float x, float y, float z) {
+// Bounding box without a launch of its own and without contended atomics: a kernel that reads a cloud anyway (a gather, the
+// curvature pass) lets every 256-thread block store the box of ITS points (order-preserving uint images: min xyz, max xyz) in
+// parts[block][6]; the filter's key kernel reduces the parts (VoxelFilter::run with ext_parts).  Every thread of the block calls
+// it, also in blocks without points (they store the identity); `have` = this thread holds a point.
+__device__ inline void vox_bbox_block_store(unsigned* parts, int block, bool have, float x, float y, float z) {
+    __shared__ unsigned s_box[4][6];
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     if (have) {
         const float v[3] = {x, y, z};
@@ -75,13 +75,13 @@ __device__ inline void vox_bbox_accumulate(unsigned* umin, unsigned* umax, bool 
             lo[a] = min(lo[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(lo[a]), o, 64)));
             hi[a] = max(hi[a], static_cast<unsigned>(__shfl_xor(static_cast<int>(hi[a]), o, 64)));
         }
-        // Atomics on one word serialise (~13 ns each, 10k waves would cost more than the launches this saves): a wave only
-        // issues one when it improves on the value it can see.  That value may be stale - then the atomic is merely redundant.
-        if ((threadIdx.x & 63) == 0 && lo[a] != 0xffffffffu) {
-            if (lo[a] < __hip_atomic_load(&umin[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&umin[a], lo[a]);
-            if (hi[a] > __hip_atomic_load(&umax[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&umax[a], hi[a]);
-        }
+        if ((threadIdx.x & 63) == 0) s_box[threadIdx.x >> 6][a] = lo[a], s_box[threadIdx.x >> 6][3 + a] = hi[a];
     }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        parts[block * 6 + threadIdx.x] = min(min(s_box[0][threadIdx.x], s_box[1][threadIdx.x]), min(s_box[2][threadIdx.x], s_box[3][threadIdx.x]));
+    else if (threadIdx.x < 6)
+        parts[block * 6 + threadIdx.x] = max(max(s_box[0][threadIdx.x], s_box[1][threadIdx.x]), max(s_box[2][threadIdx.x], s_box[3][threadIdx.x]));
 }
 #endif
 void launch_deinterleave(hipStream_t s, const float* aos, int n, SoA4 o);

@@ -91,7 +91,7 @@ class OdomStats(C.Structure):
 # every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names", "scal_prof_timeline", "scal_prof_timeline_dump",
-    "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_fetch",
+    "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_enqueue_host", "scal_features_fetch",
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample", "scal_voxel_downsample_device",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
@@ -124,6 +124,7 @@ def lib():
     L.scal_features_destroy.restype = None
     L.scal_features_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeaturesOut)]
     L.scal_features_run_device.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.scal_features_enqueue_host.argtypes = [vp, vp, C.c_int, C.c_int]
     L.scal_features_fetch.argtypes = [vp, C.POINTER(FeaturesOut)]
     L.scal_features_sync.argtypes = [vp]
     L.scal_voxel_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
@@ -309,6 +310,12 @@ class ScanRegistration:
         stride = xyz.strides[0] if xyz.shape[0] > 0 else 4 * xyz.shape[1]
         _check(lib().scal_features_run(self.h, xyz.ctypes.data, xyz.shape[0], stride, C.byref(o)))
         return self._pack(o)
+
+    def enqueue_host(self, xyz):
+        """asynchronous laserCloudHandler: pinned staging + upload + stage A on the context's stream, results stay on the GPU"""
+        xyz = _f32(xyz)
+        stride = xyz.strides[0] if xyz.shape[0] > 0 else 4 * xyz.shape[1]
+        _check(lib().scal_features_enqueue_host(self.h, xyz.ctypes.data, xyz.shape[0], stride))
 
     def run_device(self, d_ptr, n, stride_floats):
         _check(lib().scal_features_run_device(self.h, d_ptr, n, stride_floats))
