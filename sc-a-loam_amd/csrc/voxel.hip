@@ -13,15 +13,9 @@
 
 namespace scal {
 
-__global__ void k_vox_reset(VoxMeta* m) {
-    if (threadIdx.x < 3) {
-        m->umin[threadIdx.x] = 0xffffffffu;
-        m->umax[threadIdx.x] = 0u;
-    }
-    if (threadIdx.x == 0) m->error = 0, m->n_out = 0, m->guard = 0;
-}
-
-__global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restrict__ d_n, VoxMeta* m) {
+// bounding box as per-block parts (order-preserving uint images: min xyz, max xyz); k_vox_keys reduces them.  No atomics: 768
+// atomic min/max on six words of one cache line cost more than the rest of this kernel.
+__global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restrict__ d_n, unsigned* __restrict__ parts) {
     __shared__ unsigned s_lo[3][4], s_hi[3][4];
     const int n = *d_n;
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -41,12 +35,10 @@ __global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restric
         if (lane_id() == 0) s_lo[a][wave_id()] = lo[a], s_hi[a][wave_id()] = hi[a];
     }
     __syncthreads();
-    if (threadIdx.x < 3) {  // one atomic pair per block and axis
+    if (threadIdx.x < 3) {
         const int a = threadIdx.x;
-        const unsigned l = min(min(s_lo[a][0], s_lo[a][1]), min(s_lo[a][2], s_lo[a][3]));
-        const unsigned h = max(max(s_hi[a][0], s_hi[a][1]), max(s_hi[a][2], s_hi[a][3]));
-        if (l != 0xffffffffu) atomicMin(&m->umin[a], l);
-        if (h != 0u) atomicMax(&m->umax[a], h);
+        parts[blockIdx.x * 6 + a] = min(min(s_lo[a][0], s_lo[a][1]), min(s_lo[a][2], s_lo[a][3]));
+        parts[blockIdx.x * 6 + 3 + a] = max(max(s_hi[a][0], s_hi[a][1]), max(s_hi[a][2], s_hi[a][3]));
     }
 }
 
@@ -62,7 +54,7 @@ __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restric
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (static_cast<int>(blockIdx.x * blockDim.x) >= n && blockIdx.x != 0) return;  // uniform over the block
     __shared__ unsigned s_box[6];
-    if (ext_parts) {  // the box arrives as per-block parts: every block reduces them (L2-resident, a few KB)
+    {   // the box arrives as per-block parts: every block reduces them (L2-resident, a few KB)
         __shared__ unsigned s_w[4][6];
         unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
         for (int b = threadIdx.x; b < n_parts; b += 256)
@@ -80,8 +72,6 @@ __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restric
         __syncthreads();
         if (threadIdx.x < 3) s_box[threadIdx.x] = min(min(s_w[0][threadIdx.x], s_w[1][threadIdx.x]), min(s_w[2][threadIdx.x], s_w[3][threadIdx.x]));
         else if (threadIdx.x < 6) s_box[threadIdx.x] = max(max(s_w[0][threadIdx.x], s_w[1][threadIdx.x]), max(s_w[2][threadIdx.x], s_w[3][threadIdx.x]));
-    } else if (threadIdx.x < 6) {
-        s_box[threadIdx.x] = threadIdx.x < 3 ? m->umin[threadIdx.x] : m->umax[threadIdx.x - 3];
     }
     __syncthreads();
     if (i >= n && i != 0) return;
@@ -145,15 +135,13 @@ __global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __
 // The block's output offset is the sum of the earlier blocks' head counts (k_vox_heads), summed here instead of in a scan
 // launch of its own; the last block publishes the total, runs the optional epilogue and leaves the bounding box reset.
 __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockcnt, CSoA4 in, SoA4 out,
-                                                    int* __restrict__ d_n_out, VoxMeta* m, VoxTail tail, int reset_box) {
+                                                    int* __restrict__ d_n_out, VoxMeta* m, VoxTail tail) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         *d_n_out = 0;
         if (tail.slots_out) *tail.slots_out = min(*tail.other_n, tail.slots_cap);
         if (tail.err_out && m->error) *tail.err_out = m->error;
-        if (reset_box)
-            for (int a = 0; a < 3; ++a) m->umin[a] = 0xffffffffu, m->umax[a] = 0u;
     }
     if (static_cast<int>(blockIdx.x) >= nb) return;
     constexpr int SPAN = 512;
@@ -186,8 +174,6 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
         *d_n_out = n_out;
         if (tail.slots_out) *tail.slots_out = min(*tail.other_n + n_out, tail.slots_cap);
         if (tail.err_out && m->error) *tail.err_out = m->error;
-        if (reset_box)
-            for (int a = 0; a < 3; ++a) m->umin[a] = 0xffffffffu, m->umax[a] = 0u;
     }
     if (!head) return;
     const unsigned long long k = skey[threadIdx.x];
@@ -352,6 +338,7 @@ int VoxelFilter::init(int capacity) {
     SCAL_TRY(vals.alloc(cap));
     SCAL_TRY(blockcnt.alloc(div_up(cap, 256) + 1));
     SCAL_TRY(meta.alloc(1));
+    SCAL_TRY(box_parts.alloc(6 * 128));
     return SCAL_OK;
 }
 
@@ -374,14 +361,15 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
     }
     const int nb = max(1, div_up(min(cap, n_bound), 256));
     if (!ext_parts) {
-        SCAL_LAUNCH_PROF("k_vox_reset", k_vox_reset, dim3(1), dim3(64), 0, s, meta.p);
-        SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(min(nb, 128)), dim3(256), 0, s, in, d_n, meta.p);
+        n_parts = min(nb, 128);
+        ext_parts = box_parts.p;
+        SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
     }
     SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
     SCAL_LAUNCH_PROF("k_vox_heads", k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl, 0);
+    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

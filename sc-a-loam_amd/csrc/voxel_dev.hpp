@@ -6,7 +6,6 @@
 namespace scal {
 
 struct VoxMeta {
-    unsigned umin[3], umax[3];  // order-preserving uint images of the bounding box
     int error;                  // SCAL_E_CAPACITY when an axis needs more cells than the key layout holds
     int n_out;
     int guard;                  // PCL's "leaf size is too small" guard fired: output = input
@@ -37,6 +36,7 @@ struct VoxelFilter {
     DevBuf<int> vals;
     DevBuf<int> blockcnt;
     DevBuf<VoxMeta> meta;
+    DevBuf<unsigned> box_parts;  // [128][6] per-block bounding boxes (k_vox_bbox)
 
     int init(int capacity);
     // out must hold `cap` points.  The key packs the three voxel coordinates as tightly as the bounding box allows
