@@ -63,3 +63,28 @@ def test_scd_and_kitti_bin(tmp_path):
     a = rng.normal(size=(1000, 4)).astype(np.float32)
     F.write_kitti_bin(p, a)
     assert np.array_equal(F.read_kitti_bin(p), a)
+
+
+def test_keyframe_gate_and_g2o(tmp_path):
+    """Host glue of the pose-graph node (scaloam/pgo.py): the keyframe gate of laserPosegraphOptimization.cpp:598-617 and the g2o
+    text of :147-216.  The reference ships no pose-graph file, so the text format is pinned by its std::to_string construction only."""
+    from scaloam.pgo import KeyframeGate, write_g2o, read_g2o, g2o_vertex, quat_from_rpy, rpy_from_quat
+    g = KeyframeGate(meter_gap=1.0, deg_gap=10.0)
+    q0 = np.array([0.0, 0.0, 0.0, 1.0])
+    assert g(q0, np.zeros(3))                      # accumulators start at 1e6: the first pose is a keyframe
+    assert not g(q0, np.array([0.4, 0.0, 0.0]))
+    assert not g(q0, np.array([0.8, 0.0, 0.0]))
+    assert g(q0, np.array([1.3, 0.0, 0.0]))        # 0.4 + 0.4 + 0.5 > 1.0, accumulators reset
+    assert not g(q0, np.array([1.4, 0.0, 0.0]))
+    yaw = np.deg2rad(11.0)
+    assert g(np.array([0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)]), np.array([1.4, 0.0, 0.0]))  # rotation alone passes 10 deg
+    r, p, y = rpy_from_quat(quat_from_rpy(0.1, -0.2, 0.3))
+    assert abs(r - 0.1) < 1e-12 and abs(p + 0.2) < 1e-12 and abs(y - 0.3) < 1e-12
+    assert g2o_vertex(3, (1.0, 2.5, -0.25), (0.0, 0.0, 0.0, 1.0)) == "VERTEX_SE3:QUAT 3 1.000000 2.500000 -0.250000 0.000000 0.000000 0.000000 1.000000"
+    poses = [(0, 0, 0, 0, 0, 0), (1.0, 0.5, 0.0, 0.0, 0.0, 0.2)]
+    edges = [(0, 1, (1.0, 0.5, 0.0), quat_from_rpy(0, 0, 0.2))]
+    f = tmp_path / "singlesession_posegraph.g2o"
+    write_g2o(str(f), poses, edges)
+    V, E = read_g2o(str(f))
+    assert len(V) == 2 and len(E) == 1 and E[0][:2] == (0, 1)
+    assert np.abs(V[1][0] - [1.0, 0.5, 0.0]).max() < 1e-6 and np.abs(V[1][1] - quat_from_rpy(0, 0, 0.2)).max() < 1e-6
