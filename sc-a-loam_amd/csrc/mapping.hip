@@ -523,7 +523,10 @@ struct AssocFit {
 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     if (fabs(nv[0] * px[k] + nv[1] * py[k] + nv[2] * pz[k] + d) > 0.2) ok = false;  // :673-676
-                if (ok && nrm == nrm) {
+                // No finiteness test, as in the reference: a degenerate fit (n = 0 -> nrm = 0, d = inf, n/0 = NaN) passes the
+                // 0.2 m test because NaN comparisons are false (:673-676), the NaN block reaches the solver, every step of the
+                // solve is then invalid and the pose stays as it was (Ceres: "Residual and Jacobian evaluation failed").
+                if (ok) {
                     valid = 1;
                     pa[0] = nv[0], pa[1] = nv[1], pa[2] = nv[2];
                     pb[0] = d;

@@ -181,3 +181,71 @@ def test_queued_steps_equal_general_path(S, hdl64_stream, plane_res):
         assert ca[3] >= n - 4 and cb[3] >= n - 4, (ca, cb)
     for m in (a, b, g):
         m.close()
+
+
+def test_long_stream_parity_device_pipeline(O, S, hdl64_stream):
+    """50 scans of the BASELINE config #2 sequence (seed 205) through the device-resident pipeline A -> B -> C (features context handed
+    from stage to stage, stage C on its speculative chain) against the oracle chain.  Long enough for the trajectory (1 m per scan)
+    to change the centre cube of the map window in-stream, so the merge insert, its full-sort fallback and a real window change
+    (chain stopped on the device, step redone on the general path) all meet the oracle.  Poses within 1e-6, residual-block
+    counts and LM iterations equal at every scan, the final maps hold the same points."""
+    n = 50
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
+    od = S.LaserOdometry(max_points=200000)
+    gm = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=3000000)
+    oo, om = O.Odometry(), O.Mapper(0.4, 0.8, voxel_order=1, knn_mode=0)
+    worst, paths = 0.0, []
+    for k in range(n):
+        xyz = hdl64_stream(k)
+        reg.laserCloudHandler(xyz)
+        qlc, tlc, qw, tw, _ = od.step_features(reg)
+        qg, tg, sg = gm.process_features(reg, qw, tw)
+        f = O.features(xyz, O.HDL64, 5.0)
+        c = f["cloud"]
+        a = oo.step(c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
+        qo, to, so, _ = om.step(c[f["less_sharp"]], f["less_flat"], c, a[2], a[3])
+        assert sg.solved == so.solved and list(sg.n_edge) == list(so.n_edge) and list(sg.n_plane) == list(so.n_plane), (k, list(sg.n_plane), list(so.n_plane))
+        assert list(sg.lm_iters) == list(so.lm_iters) and list(sg.lm_success) == list(so.lm_success), k
+        assert sg.n_corner_map == so.n_corner_map and sg.n_surf_map == so.n_surf_map, k
+        d = max(np.abs(qg - qo).max(), np.abs(tg - to).max())
+        worst = max(worst, d)
+        assert d <= 1e-6, (k, d)
+        paths.append(sg.insert_path)
+    cnt = gm.path_counters()
+    print("worst pose difference over 50 scans:", worst, "insert paths:", paths, "path counters:", cnt)
+    assert cnt[2] >= 1, cnt            # the centre cube changed at least once: a speculative step was redone on the general path
+    assert sum(paths) >= n - 6, paths   # everything else went through the merge insert
+    for which in (0, 1):
+        mo, mg = _sorted_rows(om.export(which)), _sorted_rows(gm.export(which))
+        assert mo.shape == mg.shape, (which, mo.shape, mg.shape)
+        assert (mo != mg).any(axis=1).sum() <= max(3, mo.shape[0] // 5000), which
+    for x in (reg, od, gm):
+        x.close()
+
+
+def test_degenerate_plane_fit_follows_the_reference(O, S):
+    """laserMapping.cpp:664-687 with five neighbours whose sum is zero: the least-squares normal of A n = -1 is n = 0, so d = 1/0 and
+    n/|n| = NaN; `fabs(NaN) > 0.2` is false, the block counts as valid and goes to the solver with NaN parameters.  Every LM step is
+    then invalid and the pose comes back unchanged (Ceres would stop with "Residual and Jacobian evaluation failed").  The HIP path
+    must take the same road as the oracle: same block counts, same (prior) pose."""
+    rng = np.random.default_rng(3)
+    star = np.array([[0.85, 0, 0], [-0.85, 0, 0], [0, 0.85, 0], [0, -0.85, 0], [0, 0, 0]], np.float32)   # sum = 0, 0.85 m apart (> the 0.8 m leaf)
+    gx, gy = np.meshgrid(np.arange(8) * 1.7 + 12.0, np.arange(8) * 1.7 - 6.0)
+    ground = np.stack([gx.ravel(), gy.ravel(), np.full(64, -1.7)], 1).astype(np.float32)                # 64 well separated surf points, far from the star
+    surf = np.concatenate([star, ground])
+    surf = np.concatenate([surf, np.zeros((surf.shape[0], 1), np.float32)], 1)
+    corner = np.stack([np.full(14, 20.0), np.arange(14) * 0.9 - 6.0, np.arange(14) * 0.45], 1).astype(np.float32)
+    corner = np.concatenate([corner, np.zeros((14, 1), np.float32)], 1)
+    q, t = np.array([0.0, 0.0, 0.0, 1.0]), np.zeros(3)
+    om, gm = O.Mapper(0.4, 0.8), S.LaserMapping(0.4, 0.8, max_scan_points=10000, max_map_points=100000)
+    for m in (om, gm):     # first scan: map too small, inserted with the prior pose
+        m.step(corner, surf, None, q, t) if m is om else m.process(corner, surf, None, q, t)
+    # second scan: one surf point at the centre of the star (its five neighbours are the star), a few on the ground patch
+    surf2 = np.concatenate([np.array([[0.02, -0.01, 0.0, 0.0]], np.float32), surf[5:25] + np.array([0.05, 0.02, 0.0, 0.0], np.float32)])
+    qo, to, so, _ = om.step(corner, surf2, None, q, t)
+    qg, tg, sg, _ = gm.process(corner, surf2, None, q, t)
+    assert so.solved == 1 and sg.solved == 1
+    assert list(sg.n_plane) == list(so.n_plane) and list(sg.n_edge) == list(so.n_edge), (list(sg.n_plane), list(so.n_plane))
+    assert list(sg.lm_iters) == list(so.lm_iters) and list(sg.lm_success) == list(so.lm_success) == [0, 0]
+    assert np.array_equal(qg, qo) and np.array_equal(tg, to) and np.array_equal(qg, q) and np.array_equal(tg, t)
+    gm.close()

@@ -418,8 +418,10 @@ def test_new_entry_points_reject_bad_arguments(S):
 
 def test_loop_icp_matches_oracle(O, S, golden):
     """Loop-closure verification ICP (SURVEY 8f-2): the HIP path against the oracle's restatement of pcl::IterativeClosestPoint
-    on real keyframes downsampled at 0.4 m as doICPVirtualRelative prepares them.  Nearest neighbours are exact on both sides;
-    the f64 correspondence sums are added in a different order, so transforms agree to ~1e-6, not bit for bit."""
+    on real keyframes downsampled at 0.4 m as doICPVirtualRelative prepares them.  Nearest neighbours are exact on both sides and
+    the increment is stored as the f32 Matrix4f PCL keeps, which absorbs the different order of the f64 correspondence sums: on the
+    real keyframe pair every one of the 99 iterates equals the oracle's bit for bit (tools/diag_icp_iterates.py), so the bar here
+    is 1e-9, not the 2e-3 an earlier version of this test allowed."""
     vg = S.VoxelGrid()
     icp = S.LoopICP(max_source=100000, max_target=400000)
     a = vg.filter(golden("KAIST03_000000.npy"), 0.4)
@@ -433,20 +435,20 @@ def test_loop_icp_matches_oracle(O, S, golden):
     Ti = np.eye(4)
     Ti[:3, :3], Ti[:3, 3] = R.T, -R.T @ t
     assert rg["converged"] and ro["converged"] and rg["state"] == ro["state"]
-    assert np.abs(rg["T"] - Ti).max() <= 1e-5 and np.abs(rg["T"] - ro["T"]).max() <= 1e-5
-    assert rg["fitness"] <= 1e-9 and abs(rg["iterations"] - ro["iterations"]) <= 1
+    assert np.abs(rg["T"] - Ti).max() <= 1e-5 and np.abs(rg["T"] - ro["T"]).max() <= 1e-9
+    assert rg["fitness"] <= 1e-9 and rg["iterations"] == ro["iterations"]
     # (2) two different keyframes of the sample session (what the verification really sees: partial overlap)
     b = vg.filter(golden("KAIST03_000007.npy"), 0.4)
     tgt = np.concatenate([a, vg.filter(golden("KAIST03_000020.npy"), 0.4)])
     rg, ro = icp.align(b, tgt), O.icp_align(b, tgt)
-    assert rg["converged"] == ro["converged"]
-    assert np.abs(rg["T"] - ro["T"]).max() <= 2e-3, (rg["T"], ro["T"])
-    assert abs(rg["fitness"] - ro["fitness"]) <= 1e-3 * max(1.0, ro["fitness"]), (rg["fitness"], ro["fitness"])
+    assert rg["converged"] == ro["converged"] and rg["iterations"] == ro["iterations"] and rg["state"] == ro["state"]
+    assert np.abs(rg["T"] - ro["T"]).max() <= 1e-9, (rg["T"], ro["T"])
+    assert abs(rg["fitness"] - ro["fitness"]) <= 1e-9 * max(1.0, ro["fitness"]), (rg["fitness"], ro["fitness"])
     # (3) iteration cap, too few points, empty clouds
     capped = S.LoopICP(max_source=100000, max_target=400000, max_iterations=2)
     rc, rco = capped.align(b, tgt), O.icp_align(b, tgt, max_iter=2)
     assert rc["iterations"] == 2 and rc["state"] == 1 and rc["converged"] and rco["state"] == 1
-    assert np.abs(rc["T"] - rco["T"]).max() <= 1e-5
+    assert np.abs(rc["T"] - rco["T"]).max() <= 1e-9
     r2 = icp.align(b[:2], tgt)
     assert not r2["converged"] and r2["state"] == 5
     r0 = icp.align(np.zeros((0, 4), np.float32), tgt)
@@ -494,10 +496,11 @@ def test_loop_icp_cell_grid_equals_dense_sweep(S, golden):
         x.close()
 
 
-def test_sc_5k_database_8_shards(S):
+def test_sc_5k_database_8_shards(O, S):
     """BASELINE config #4 shape: a 5000-keyframe database sharded 8 ways (keyframe i on shard i % 8), batched insert + query per
-    step exactly as bench.py --gpus 8 issues them, against ONE context holding the whole database (the path validated against
-    the oracle above).  Every 25th step is compared: loop id, best candidate and its distance."""
+    step exactly as bench.py --gpus 8 issues them, against ONE context holding the whole database AND against the oracle's
+    detectLoopClosureID fed the same 5000 descriptors (same tree period, same exclusion of the newest 30).  Every 25th step is
+    compared: loop id, best candidate and its distance."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
@@ -507,6 +510,8 @@ def test_sc_5k_database_8_shards(S):
     rng = np.random.default_rng(17)
     base = rng.uniform(-2.0, 18.0, (64, 20, 60)) * (rng.uniform(size=(64, 20, 60)) < 0.5)
     single = S.SCManager(dist_thres=0.3, max_keyframes=5100)
+    osc = O.SCManager(dist_thres=0.3)
+    orefs_all = []
     shards = [S.SCManager(dist_thres=0.3, max_keyframes=700, n_shards=G, shard=s) for s in range(G)]
     d_q, d_out = ctypes.c_void_p(), ctypes.c_void_p()
     assert hip.hipMalloc(ctypes.byref(d_q), G * 1200 * 8) == 0 and hip.hipMalloc(ctypes.byref(d_out), G * 3 * 24) == 0
@@ -525,17 +530,18 @@ def test_sc_5k_database_8_shards(S):
         if st == 0:
             batch_hist = []
         batch_hist.extend(batch)
-        refs, limits = [], []
+        refs, orefs, limits = [], [], []
         check = st % 25 == 24
         for d in batch:
             single.saveScancontextAndKeys(d)
+            osc.saveScancontextAndKeys(d)
             n_global += 1
-            if check:
+            if check or n_global >= 31:  # (also between the checked steps: keeps the tree period in step with the reference sequence)
                 refs.append(single.detectLoopClosureID())
-            elif n_global >= 31:  # keep the single context's tree period in step with the reference sequence
-                refs.append(single.detectLoopClosureID())
+                orefs.append(osc.detectLoopClosureID())
             else:
                 refs.append(None)
+                orefs.append(None)
             if n_global >= 31:
                 if counter % 30 == 0:
                     size_at_rebuild = n_global
@@ -558,6 +564,8 @@ def test_sc_5k_database_8_shards(S):
                 got = S.merge_candidates(cands, 0.3)
                 assert got["loop_id"] == refs[q]["loop_id"] and got["nn_idx"] == refs[q]["nn_idx"], (st, q)
                 assert abs(got["min_dist"] - refs[q]["min_dist"]) <= 1e-12, (st, q)
+                assert got["loop_id"] == orefs[q]["loop_id"] and got["nn_idx"] == orefs[q]["nn_idx"], (st, q, "oracle")
+                assert abs(got["min_dist"] - orefs[q]["min_dist"]) <= 1e-12, (st, q, "oracle")
                 hits += got["loop_id"] >= 0
                 checked += 1
     assert single.size() == 5000 and sum(sh.size() for sh in shards) == 5000 * G  # every shard counts every global insert
