@@ -1,25 +1,36 @@
+# HBM traffic per dispatch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, kernel trace only) of the serial
+# schedule of bench.py, aggregated per kernel -> gpurun_out/pmc_summary.json (copy to profiles/ after checking)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+CFG="--steps 20 --warmup 5 --reps 1 --h2d 0 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0"
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0 > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py $CFG > $R/gpurun_out/pmc_fetch.log 2>&1
 echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0 > $R/gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py $CFG > $R/gpurun_out/pmc_write.log 2>&1
 echo write rc=$?
-ls $R/gpurun_out/pmc_fetch/* | head; 
-# keep only the per-kernel aggregates (the raw counter CSVs are large)
-python3 - <<'PY'
-import csv, glob, json, os, collections
+python3 - <<PY
+import csv, glob, json, os, collections, re
 R=os.environ['GRAFT_REPO_ROOT']
-out={}
+def short(n):
+    m = re.search(r'(k_[a-z0-9_]+)', n)
+    s = m.group(1) if m else n
+    if s == 'k_lm_solve':
+        s = 'k_lm_solve_map' if 'MapPoseDone' in n else 'k_lm_solve_odom'
+    return s
+agg={}
 for tag in ('fetch','write'):
-    fs=glob.glob(f'{R}/gpurun_out/pmc_{tag}/*/*counter_collection.csv')
-    agg=collections.defaultdict(lambda:[0.0,0])
-    for f in fs:
+    a=collections.defaultdict(lambda:[0.0,0])
+    for f in glob.glob(f'{R}/gpurun_out/pmc_{tag}/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
-            agg[r['Kernel_Name']][0]+=float(r['Counter_Value']); agg[r['Kernel_Name']][1]+=1
-    out[tag]={k:{'sum':v[0],'dispatches':v[1]} for k,v in agg.items()}
+            a[short(r['Kernel_Name'])][0]+=float(r['Counter_Value']); a[short(r['Kernel_Name'])][1]+=1
+    agg[tag]=a
+out={'config':'python3 bench.py $CFG (serial schedule, one stream), FETCH_SIZE / WRITE_SIZE in KB per dispatch as rocprofv3 reports them; '
+     'FETCH_SIZE raw (the guide\\'s x2 correction applies to 16-B-per-lane streaming reads; these kernels read 4-8 B per lane)','kernels':{}}
+for k in sorted(set(agg['fetch'])|set(agg['write'])):
+    f,w=agg['fetch'].get(k,[0,0]),agg['write'].get(k,[0,0])
+    out['kernels'][k]={'dispatches':max(f[1],w[1]),'fetch_kb_per_dispatch':f[0]/max(1,f[1]),'write_kb_per_dispatch':w[0]/max(1,w[1])}
 json.dump(out, open(f'{R}/gpurun_out/pmc_summary.json','w'), indent=1)
-print({k:len(v) for k,v in out.items()})
+print(len(out['kernels']),'kernels')
 PY
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
