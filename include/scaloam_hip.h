@@ -273,6 +273,30 @@ int scal_map_get_path_counters(scal_map_t* ctx, int* out4);
  * only noticed by collect / finish, so that steps really get queued behind it (test switch for the replay path) */
 int scal_map_set_poll(scal_map_t* ctx, int enable);
 
+/* ---- Ceres-adapter mode of stage C: the host keeps ceres::Problem / ceres::Solve exactly as
+ * laserMapping.cpp:563-728 builds them; the device does what surrounds the solve and evaluates the residual blocks in batches.
+ *   scal_map_adapter_begin   :310-560  transformAssociateToMap, window shift, submap (cell grids), stack downsample; returns the prior pose
+ *   per outer iteration (:563):
+ *     scal_map_associate     :578-688  kNN + PCA / plane fit at the caller's current pose -> residual blocks, in the order the reference adds
+ *                                      them (corner stack points, then surf stack points); n_residuals = 3 per edge block + 1 per plane block
+ *     scal_map_get_blocks              the blocks as records (to construct the reference's own LidarEdgeFactor / LidarPlaneNormFactor objects), or
+ *     scal_map_eval_blocks             residuals [n_residuals] and ambient Jacobians [n_residuals][7] (qx qy qz qw tx ty tz, row-major) of all
+ *                                      blocks at x7, without loss function or local parameterisation (Ceres applies its HuberLoss(0.1) and
+ *                                      EigenQuaternionParameterization itself): what a ceres::EvaluationCallback + thin per-block CostFunction serves from
+ *   scal_map_adapter_finish  :735-802, :845-849  transformUpdate with the solved pose, map insertion + re-filter, registration
+ * kind: 0 LidarEdgeFactor(curr_point = cp, last_point_a = pa, last_point_b = pb, s = 1), 2 LidarPlaneNormFactor(curr_point = cp,
+ * plane_unit_norm = pa, negative_OA_dot_norm = pb[0]); (1 = LidarPlaneFactor(cp, j = pa, unit normal = pb) in the odometry's blocks). */
+typedef struct {
+    int kind, pad;
+    double cp[3], pa[3], pb[3];
+} scal_block;
+int scal_map_adapter_begin(scal_map_t* ctx, const float* corner_last, int n_corner, const float* surf_last, int n_surf, const float* full_res,
+                           int n_full, const double* q_wodom, const double* t_wodom, double* q_w_curr, double* t_w_curr);
+int scal_map_associate(scal_map_t* ctx, const double* q_w_curr, const double* t_w_curr, int* n_blocks, int* n_residuals);
+int scal_map_get_blocks(scal_map_t* ctx, scal_block* out, int cap); /* returns the number of records written */
+int scal_map_eval_blocks(scal_map_t* ctx, const double* x7, int want_jac, double* residuals, double* jacobians);
+int scal_map_adapter_finish(scal_map_t* ctx, const double* q_w_curr, const double* t_w_curr, float* registered, scal_map_stats* stats);
+
 /* ------------------------------------------------------------------ stage B: scan-to-scan odometry
  * Replaces the main loop body of src/laserOdometry.cpp:267-291, :299-506, :554-568. */
 typedef struct {

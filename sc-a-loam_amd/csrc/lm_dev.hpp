@@ -173,6 +173,129 @@ __device__ __forceinline__ void factor_accumulate(int kind, const double* cp, co
     }
 }
 
+// Plain residual and Jacobian of one block with respect to the AMBIENT parameters (qx qy qz qw tx ty tz), as the reference's
+// ceres::AutoDiffCostFunction<F, kRes, 4, 3> hands them to Ceres (lidarFactor.hpp:48-50, :96-98, :130-132): no loss function,
+// no local parameterisation - in the Ceres-adapter mode Ceres applies both itself.  Returns the number of residual rows (3 / 1).
+__device__ __forceinline__ int factor_residual_jacobian(int kind, const double* cp, const double* pa, const double* pb, const double* x, double* r,
+                                                        double (*J)[7]) {
+    const double qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+    double lp[3];
+    quat_rotate(x, cp[0], cp[1], cp[2], lp);
+    lp[0] += x[4], lp[1] += x[5], lp[2] += x[6];
+    const double c0 = cp[0], c1 = cp[1], c2 = cp[2];
+    const double ucx = qy * c2 - qz * c1, ucy = qz * c0 - qx * c2, ucz = qx * c1 - qy * c0;
+    const double udc = qx * c0 + qy * c1 + qz * c2;
+    double A[3][7];  // d lp / d (qx qy qz qw tx ty tz)
+    A[0][0] = 0, A[0][1] = 2 * qw * c2, A[0][2] = -2 * qw * c1;
+    A[1][0] = -2 * qw * c2, A[1][1] = 0, A[1][2] = 2 * qw * c0;
+    A[2][0] = 2 * qw * c1, A[2][1] = -2 * qw * c0, A[2][2] = 0;
+    A[0][1] += 2 * ucz, A[0][2] += -2 * ucy;
+    A[1][0] += -2 * ucz, A[1][2] += 2 * ucx;
+    A[2][0] += 2 * ucy, A[2][1] += -2 * ucx;
+    const double cpv[3] = {c0, c1, c2}, uv[3] = {qx, qy, qz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[a][b] += -2 * cpv[a] * uv[b] + (a == b ? 2 * udc : 0.0);
+    A[0][3] = 2 * ucx, A[1][3] = 2 * ucy, A[2][3] = 2 * ucz;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) A[a][4 + b] = a == b ? 1.0 : 0.0;
+    if (kind == 0) {  // r = (lp-a) x (lp-b) / |a-b| ; dr/dlp = [b-a]x / |a-b|
+        const double ax = lp[0] - pa[0], ay = lp[1] - pa[1], az = lp[2] - pa[2];
+        const double bx = lp[0] - pb[0], by = lp[1] - pb[1], bz = lp[2] - pb[2];
+        const double dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+        const double den = sqrt(dx * dx + dy * dy + dz * dz);
+        r[0] = (ay * bz - az * by) / den, r[1] = (az * bx - ax * bz) / den, r[2] = (ax * by - ay * bx) / den;
+        const double ex = -dx / den, ey = -dy / den, ez = -dz / den;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            J[0][c] = -ez * A[1][c] + ey * A[2][c];
+            J[1][c] = ez * A[0][c] - ex * A[2][c];
+            J[2][c] = -ey * A[0][c] + ex * A[1][c];
+        }
+        return 3;
+    }
+    double nx, ny, nz;
+    if (kind == 1) {  // (lp - j) . n
+        nx = pb[0], ny = pb[1], nz = pb[2];
+        r[0] = (lp[0] - pa[0]) * nx + (lp[1] - pa[1]) * ny + (lp[2] - pa[2]) * nz;
+    } else {  // n . lp + d
+        nx = pa[0], ny = pa[1], nz = pa[2];
+        r[0] = (nx * lp[0] + ny * lp[1] + nz * lp[2]) + pb[0];
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) J[0][c] = nx * A[0][c] + ny * A[1][c] + nz * A[2][c];
+    return 1;
+}
+
+// ---- Ceres-adapter mode: the live blocks of a FactorSoA, compacted, and their batched evaluation
+struct BlockList {
+    int* live;      // [cap] slot of the i-th live block
+    int* row_off;   // [cap + 1] first residual row of the i-th live block
+    int* counts;    // [0] live blocks, [1] residual rows
+};
+// one workgroup: stable compaction of the valid slots (slot order = the order the reference adds its residual blocks in)
+static __global__ void __launch_bounds__(1024) k_blocks_compact(FactorSoA f, const int* __restrict__ d_nslots, BlockList bl) {
+    __shared__ int s_scan[17];
+    __shared__ int s_run[2];
+    const int n = min(*d_nslots, f.cap);
+    if (threadIdx.x == 0) s_run[0] = 0, s_run[1] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n && f.valid[i]) ? 1 : 0;
+        const int rows = v ? (f.kind[i] == 0 ? 3 : 1) : 0;
+        int tot_v, tot_r;
+        const int pv = block_exclusive_scan(v, s_scan, &tot_v);
+        const int pr = block_exclusive_scan(rows, s_scan, &tot_r);
+        if (v) {
+            bl.live[s_run[0] + pv] = i;
+            bl.row_off[s_run[0] + pv] = s_run[1] + pr;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run[0] += tot_v, s_run[1] += tot_r;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        bl.row_off[s_run[0]] = s_run[1];
+        bl.counts[0] = s_run[0], bl.counts[1] = s_run[1];
+    }
+}
+// one thread per live block: residual rows (and, if wanted, their 7 ambient Jacobian columns, row-major) at the pose x7
+static __global__ void __launch_bounds__(256) k_blocks_eval(FactorSoA f, BlockList bl, const double* __restrict__ x7, int want_jac,
+                                                           double* __restrict__ residuals, double* __restrict__ jac) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bl.counts[0]) return;
+    const int i = bl.live[b];
+    double x[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) x[k] = x7[k];
+    const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
+    const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
+    const double pb[3] = {f.pb[i], f.pb[f.cap + i], f.pb[2 * f.cap + i]};
+    double r[3], J[3][7];
+    const int rows = factor_residual_jacobian(f.kind[i], cp, pa, pb, x, r, J);
+    const int r0 = bl.row_off[b];
+    for (int q = 0; q < rows; ++q) {
+        residuals[r0 + q] = r[q];
+        if (want_jac)
+#pragma unroll
+            for (int c = 0; c < 7; ++c) jac[static_cast<size_t>(r0 + q) * 7 + c] = J[q][c];
+    }
+}
+// blocks as records for the host (struct scal_block of the C-ABI: int kind, int pad, double cp[3], pa[3], pb[3] = 80 bytes)
+static __global__ void __launch_bounds__(256) k_blocks_export(FactorSoA f, BlockList bl, double* __restrict__ out10) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= bl.counts[0]) return;
+    const int i = bl.live[b];
+    double* o = out10 + static_cast<size_t>(b) * 10;
+    reinterpret_cast<int*>(o)[0] = f.kind[i], reinterpret_cast<int*>(o)[1] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o[1 + a] = f.cp[a * f.cap + i], o[4 + a] = f.pa[a * f.cap + i], o[7 + a] = f.pb[a * f.cap + i];
+}
+
 constexpr int LM_NACC = 30;  // cost, g[6], upper H[21], number of live edge blocks, number of live plane blocks
 
 // which = 0: evaluate at st->x (iteration zero), 1: at st->cand

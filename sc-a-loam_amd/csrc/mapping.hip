@@ -1167,6 +1167,11 @@ struct MapPoseDone {
     __device__ __forceinline__ void operator()(int, int, int) const {}
 };
 
+// the same work as a launch of its own (Ceres-adapter mode: the caller's solver produced the pose)
+__global__ void __launch_bounds__(256) k_map_pose_done(MapPoseDone pd) {
+    pd(pd.st->x, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, false);
+}
+
 // End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
 __global__ void __launch_bounds__(256) k_map_end(MapState* S, const MapCounters* C, MapResult* host) {
     if (threadIdx.x == 0 && !S->abort) S->n_map[0] = C->n_map_new[0], S->n_map[1] = C->n_map_new[1];
@@ -1250,6 +1255,13 @@ struct scal_map {
     hipEvent_t ev_pose[NSLOTS] = {}, ev_done[NSLOTS] = {};
     int next_slot = 0;
     PinBuf<MapResult> res;
+    // Ceres-adapter mode (scal_map_adapter_begin ... _finish): the step whose solve the caller drives
+    bool adapter_active = false;
+    MapStep adapter_step;
+    DevBuf<int> bl_live, bl_rowoff, bl_counts;
+    DevBuf<double> d_x7, d_res, d_jac, d_blocks;
+    PinBuf<int> h_counts;
+    BlockList block_list() { return BlockList{bl_live.p, bl_rowoff.p, bl_counts.p}; }
     int n_fast = 0, n_general = 0, n_recover_pose = 0, n_recover_insert = 0;  // scal_map_get_path_counters
     bool poll_on_enqueue = true;  // scal_map_set_poll
     int cur = 0;                // parity of the map buffers once every queued step has been inserted
@@ -1353,6 +1365,8 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
     A(c->lm_sync.alloc(1));
     A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
+    A(c->bl_live.alloc(sc)); A(c->bl_rowoff.alloc(sc + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->d_x7.alloc(8));
+    A(c->d_res.alloc(3 * sc)); A(c->d_jac.alloc(21 * sc)); A(c->d_blocks.alloc(10 * sc));
     A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     c->lane = stage_lane(STAGE_MAP);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
@@ -1534,9 +1548,24 @@ int launch_tail(scal_map* c, const MapStep& e) {
     return SCAL_OK;
 }
 
+MapPoseDone make_pose_done(scal_map* c, const MapStep& e) {
+    MapCounters* C = c->d_C(e.set).p;
+    MapPoseDone pd;
+    pd.active = 1;
+    pd.S = c->d_S.p, pd.st = c->d_st.p, pd.C = C, pd.host = c->res.p + e.slot;
+    for (int k = 0; k < 2; ++k) {
+        pd.nw.stack[k] = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
+        pd.nw.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
+        pd.nw.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
+        pd.nw.x[k] = c->mnew[k].x.p, pd.nw.y[k] = c->mnew[k].y.p, pd.nw.z[k] = c->mnew[k].z.p, pd.nw.w[k] = c->mnew[k].w.p;
+        pd.nw.cube[k] = c->mcube[k].p, pd.nw.pkey[k] = c->mpkey[k].p;
+    }
+    return pd;
+}
+
 // Everything of a step up to the pose: inputs (unless prefetched), k_map_begin, cell grids, 2 x (association + solve), transformUpdate.
 // ev_pose fires when pose and statistics have reached the host slot.
-int launch_pose_part(scal_map* c, const MapStep& e) {
+int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     hipStream_t s = c->stream;
     const int st_ = e.set;
     MapCounters* C = c->d_C(st_).p;
@@ -1563,18 +1592,14 @@ int launch_pose_part(scal_map* c, const MapStep& e) {
     SCAL_LAUNCH_PROF("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
     SCAL_LAUNCH_PROF("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
     SCAL_LAUNCH_PROF("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
+    if (prepare_only) {  // Ceres-adapter mode: the caller drives association and solve (scal_map_associate / scal_map_eval_blocks)
+        SCAL_HIP(hipGetLastError());
+        return SCAL_OK;
+    }
     // two outer iterations (:563)
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
-    MapPoseDone pd;
-    pd.S = S, pd.st = st, pd.C = C, pd.host = c->res.p + e.slot;
-    for (int k = 0; k < 2; ++k) {
-        pd.nw.stack[k] = k == 0 ? c->corner_stack(st_).cv() : c->surf_stack(st_).cv();
-        pd.nw.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        pd.nw.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
-        pd.nw.x[k] = c->mnew[k].x.p, pd.nw.y[k] = c->mnew[k].y.p, pd.nw.z[k] = c->mnew[k].z.p, pd.nw.w[k] = c->mnew[k].w.p;
-        pd.nw.cube[k] = c->mcube[k].p, pd.nw.pkey[k] = c->mpkey[k].p;
-    }
+    MapPoseDone pd = make_pose_done(c, e);
     const AssocFit fit{c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), c->nnbuf(), C, F};
     for (int outer = 0; outer < 2; ++outer) {
         {
@@ -1596,6 +1621,7 @@ int report_device_error(scal_map* c, int err) {
     return err;
 }
 
+int general_insert(scal_map* c, MapStep& e);
 // General path, synchronous: the window may move, the insertion falls back to the full sort.  All earlier steps have finished.
 int run_general(scal_map* c, MapStep& e) {
     hipStream_t s = c->stream;
@@ -1604,6 +1630,12 @@ int run_general(scal_map* c, MapStep& e) {
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    return general_insert(c, e);
+}
+
+// second half of the general path: the pose stands (slot S1 / C1 published), insertion + registration + commit, synchronous
+int general_insert(scal_map* c, MapStep& e) {
+    hipStream_t s = c->stream;
     const MapResult& R = c->res.p[e.slot];
     if (R.C1.error) return report_device_error(c, R.C1.error);
     const int n_map[2] = {R.S1.n_map[0], R.S1.n_map[1]};
@@ -2075,5 +2107,199 @@ extern "C" int scal_map_get_path_counters(scal_map_t* c, int* out4) {
 extern "C" int scal_map_set_poll(scal_map_t* c, int enable) {
     if (!c) return SCAL_E_ARG;
     c->poll_on_enqueue = enable != 0;
+    return SCAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Ceres-adapter mode
+// The host keeps ceres::Problem / ceres::Solve (laserMapping.cpp:566-573, :713-721); the device does everything around it.
+static int upload_step_inputs(scal_map* c, MapStep& e, const float* corner_last, int n_corner, const float* surf_last, int n_surf, const float* full_res,
+                              int n_full) {
+    hipStream_t s = c->stream;
+    MapCounters z;
+    std::memset(&z, 0, sizeof z);
+    z.n_corner_in = n_corner, z.n_surf_in = n_surf;
+    *c->h_C.p = z;
+    SCAL_HIP(hipMemcpyAsync(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
+    c->h_misc.p[0] = n_full;
+    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
+    auto up = [&](const float* src, int n, SoAStore& dst) -> int {
+        if (n > 0) {
+            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            launch_deinterleave(s, c->aos.p, n, dst.v());
+            SCAL_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next upload
+        }
+        return SCAL_OK;
+    };
+    SCAL_TRY(up(corner_last, n_corner, c->corner_in(e.set)));
+    SCAL_TRY(up(surf_last, n_surf, c->surf_in(e.set)));
+    if (n_full > 0) SCAL_TRY(up(full_res, n_full, c->full_in));
+    e.have_full = n_full > 0, e.n_corner_bound = n_corner, e.n_surf_bound = n_surf;
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_adapter_begin(scal_map_t* c, const float* corner_last, int n_corner, const float* surf_last, int n_surf, const float* full_res,
+                                      int n_full, const double* q_wodom, const double* t_wodom, double* q_w_curr, double* t_w_curr) {
+    if (!c || !q_wodom || !t_wodom || !q_w_curr || !t_w_curr || n_corner < 0 || n_surf < 0 || n_full < 0 || (n_corner > 0 && !corner_last) ||
+        (n_surf > 0 && !surf_last)) {
+        set_error("scal_map_adapter_begin: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_corner > c->scan_cap || n_surf > c->scan_cap || n_full > c->scan_cap) {
+        set_error("scal_map_adapter_begin: input cloud larger than max_scan_points (%d)", c->scan_cap);
+        return SCAL_E_TOO_MANY;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(map_finish(c));
+    if (!c->steps.empty() || c->adapter_active) {
+        set_error("scal_map_adapter_begin: a step is still open");
+        return SCAL_E_STATE;
+    }
+    MapStep e;
+    SCAL_TRY(new_step(c, &e));
+    {
+        std::lock_guard<std::mutex> lk(c->pf_mu);
+        c->n_pf = 0;
+        e.set = c->alloc_set();
+    }
+    SCAL_TRY(upload_step_inputs(c, e, corner_last, n_corner, surf_last, n_surf, (full_res && n_full > 0) ? full_res : nullptr, full_res ? n_full : 0));
+    for (int i = 0; i < 4; ++i) e.pose.q_wodom[i] = q_wodom[i];
+    for (int i = 0; i < 3; ++i) e.pose.t_wodom[i] = t_wodom[i];
+    e.fast = false, e.par = c->cur;
+    c->n_general++;
+    SCAL_TRY(launch_pose_part(c, e, true));  // stack filters, transformAssociateToMap + window, cell grids
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->h_S.p, c->d_S.p, sizeof(MapState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(c->res.p + e.slot, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));  // MapResult::st is its first member
+    SCAL_HIP(hipStreamSynchronize(s));
+    const double* x = c->res.p[e.slot].st.x;
+    for (int i = 0; i < 4; ++i) q_w_curr[i] = x[i];
+    for (int i = 0; i < 3; ++i) t_w_curr[i] = x[4 + i];
+    c->adapter_step = e;
+    c->adapter_active = true;
+    return SCAL_OK;
+}
+
+static int adapter_set_pose(scal_map* c, const double* q, const double* t) {
+    double* h = reinterpret_cast<double*>(c->h_S.p);  // pinned scratch (MapState is larger than 7 doubles)
+    for (int i = 0; i < 4; ++i) h[i] = q[i];
+    for (int i = 0; i < 3; ++i) h[4 + i] = t[i];
+    SCAL_HIP(hipMemcpyAsync(c->d_st.p->x, h, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_associate(scal_map_t* c, const double* q_w_curr, const double* t_w_curr, int* n_blocks, int* n_residuals) {
+    if (!c || !q_w_curr || !t_w_curr || !n_blocks || !n_residuals) {
+        set_error("scal_map_associate: null argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_map_associate: no scal_map_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const MapStep& e = c->adapter_step;
+    MapCounters* C = c->d_C(e.set).p;
+    SCAL_TRY(adapter_set_pose(c, q_w_curr, t_w_curr));
+    SCAL_HIP(hipStreamSynchronize(s));  // the pinned scratch is reused
+    FactorSoA F = c->factors();
+    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
+    SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
+                     c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), c->d_st.p, C, c->nnbuf());
+    const AssocFit fit{c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->nnbuf(), C, F};
+    SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, c->d_S.p);
+    SCAL_LAUNCH_PROF("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    if (!c->h_C.p->solve_on) c->h_counts.p[0] = c->h_counts.p[1] = 0;  // map too small (:555): no residual blocks, the caller skips the solve
+    *n_blocks = c->h_counts.p[0], *n_residuals = c->h_counts.p[1];
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_get_blocks(scal_map_t* c, scal_block* out, int cap) {
+    if (!c || (!out && cap > 0) || cap < 0) {
+        set_error("scal_map_get_blocks: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_map_get_blocks: no scal_map_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    static_assert(sizeof(scal_block) == 80, "scal_block layout");
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int n = std::min(cap, c->h_counts.p[0]);
+    if (n <= 0) return 0;
+    hipStream_t s = c->stream;
+    SCAL_LAUNCH_PROF("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
+    SCAL_HIP(hipMemcpyAsync(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return n;
+}
+
+extern "C" int scal_map_eval_blocks(scal_map_t* c, const double* x7, int want_jac, double* residuals, double* jacobians) {
+    if (!c || !x7 || !residuals || (want_jac && !jacobians)) {
+        set_error("scal_map_eval_blocks: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_map_eval_blocks: no scal_map_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int nb = c->h_counts.p[0], nr = c->h_counts.p[1];
+    if (nb == 0) return SCAL_OK;
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipMemcpyAsync(c->d_x7.p, x7, sizeof(double) * 7, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH_PROF("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
+                     c->d_res.p, c->d_jac.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
+    if (want_jac) SCAL_HIP(hipMemcpyAsync(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, const double* t_w_curr, float* registered, scal_map_stats* stats) {
+    if (!c || !q_w_curr || !t_w_curr) {
+        set_error("scal_map_adapter_finish: null argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_map_adapter_finish: no scal_map_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    MapStep& e = c->adapter_step;
+    c->adapter_active = false;
+    SCAL_TRY(adapter_set_pose(c, q_w_curr, t_w_curr));
+    // transformUpdate (:735), host copy, insertion keys: what the second solve's launch does on the all-device path
+    SCAL_LAUNCH_PROF("k_map_pose_done", k_map_pose_done, dim3(64), dim3(256), 0, s, make_pose_done(c, e));
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
+    SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    SCAL_TRY(general_insert(c, e));
+    const MapResult& R = c->res.p[e.slot];
+    for (int i = 0; i < 4; ++i) c->q_wmap_wodom[i] = R.S1.q_wmap_wodom[i];
+    for (int i = 0; i < 3; ++i) c->t_wmap_wodom[i] = R.S1.t_wmap_wodom[i];
+    c->have_mp = true;
+    for (int k = 0; k < 2; ++k) c->map[k].n = R.S2.n_map[k];
+    c->last_insert_path = e.insert_path;
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->n_corner_stack = R.C1.n_corner_stack, stats->n_surf_stack = R.C1.n_surf_stack;
+        stats->n_corner_map = R.C1.n_valid[0], stats->n_surf_map = R.C1.n_valid[1];
+        stats->solved = R.C1.solve_on;
+        stats->n_map_corner_total = c->map[0].n, stats->n_map_surf_total = c->map[1].n;
+        stats->insert_path = e.insert_path;
+    }
+    if (e.have_full && registered) {
+        const int n_full = c->h_misc.p[0];
+        launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
+        SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+    }
     return SCAL_OK;
 }

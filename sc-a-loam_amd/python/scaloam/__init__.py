@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
     "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_align_device", "scal_icp_set_search",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
@@ -171,6 +171,11 @@ def lib():
     L.scal_map_get_wmap_wodom.argtypes = [vp, _f64p, _f64p]
     L.scal_map_set_merge_insert.argtypes = [vp, C.c_int]
     L.scal_map_get_path_counters.argtypes = [vp, C.POINTER(C.c_int)]
+    L.scal_map_adapter_begin.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p, _f64p]
+    L.scal_map_associate.argtypes = [vp, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.scal_map_get_blocks.argtypes = [vp, vp, C.c_int]
+    L.scal_map_eval_blocks.argtypes = [vp, _f64p, C.c_int, _f64p, _f64p]
+    L.scal_map_adapter_finish.argtypes = [vp, _f64p, _f64p, _f32p, C.POINTER(MapStats)]
     L.scal_map_set_poll.argtypes = [vp, C.c_int]
     L.scal_map_prefetch_features.argtypes = [vp, vp]
     L.scal_map_enqueue_features.argtypes = [vp, vp, _f64p, _f64p]
@@ -539,6 +544,48 @@ class LaserMapping:
 
     def prefetch_features(self, feat):
         _check(lib().scal_map_prefetch_features(self.h, feat.h))
+
+    # ---- Ceres-adapter mode (the caller owns the solver): begin -> per outer iteration associate / blocks / eval -> finish
+    def adapter_begin(self, corner_last, surf_last, full_res, q_wodom, t_wodom):
+        c = _f32(corner_last).reshape(-1, 4)
+        s = _f32(surf_last).reshape(-1, 4)
+        f = _f32(full_res).reshape(-1, 4) if full_res is not None else None
+        self._adapter_full = f
+        q, t = np.zeros(4), np.zeros(3)
+        _check(lib().scal_map_adapter_begin(self.h, _p(c, _f32p), c.shape[0], _p(s, _f32p), s.shape[0], _p(f, _f32p), 0 if f is None else f.shape[0],
+                                            _p(_f64(q_wodom), _f64p), _p(_f64(t_wodom), _f64p), _p(q, _f64p), _p(t, _f64p)))
+        return q, t
+
+    def associate(self, q_w_curr, t_w_curr):
+        nb, nr = C.c_int(0), C.c_int(0)
+        _check(lib().scal_map_associate(self.h, _p(_f64(q_w_curr), _f64p), _p(_f64(t_w_curr), _f64p), C.byref(nb), C.byref(nr)))
+        self._adapter_n = (nb.value, nr.value)
+        return nb.value, nr.value
+
+    def blocks(self):
+        """(kind [n], cp [n][3], pa [n][3], pb [n][3]) of the residual blocks of the last associate()"""
+        nb = self._adapter_n[0]
+        raw = np.zeros((max(nb, 1), 10), np.float64)
+        n = lib().scal_map_get_blocks(self.h, raw.ctypes.data, nb)
+        if n < 0:
+            _check(n)
+        raw = raw[:n]
+        kind = raw[:, 0].copy().view(np.int32)[::2].copy()
+        return kind, raw[:, 1:4].copy(), raw[:, 4:7].copy(), raw[:, 7:10].copy()
+
+    def eval_blocks(self, x7, want_jac=True):
+        nb, nr = self._adapter_n
+        r = np.zeros(max(nr, 1))
+        J = np.zeros((max(nr, 1), 7))
+        _check(lib().scal_map_eval_blocks(self.h, _p(_f64(x7), _f64p), 1 if want_jac else 0, _p(r, _f64p), _p(J, _f64p)))
+        return r[:nr], (J[:nr] if want_jac else None)
+
+    def adapter_finish(self, q_w_curr, t_w_curr, want_registered=False):
+        f = self._adapter_full
+        reg = np.zeros_like(f) if (want_registered and f is not None) else None
+        st = MapStats()
+        _check(lib().scal_map_adapter_finish(self.h, _p(_f64(q_w_curr), _f64p), _p(_f64(t_w_curr), _f64p), _p(reg, _f32p), C.byref(st)))
+        return st, reg
 
     def path_counters(self):
         """(queued speculatively, general path, redone after a moved window, insertion redone with the full sort)"""

@@ -249,3 +249,51 @@ def test_degenerate_plane_fit_follows_the_reference(O, S):
     assert list(sg.lm_iters) == list(so.lm_iters) and list(sg.lm_success) == list(so.lm_success) == [0, 0]
     assert np.array_equal(qg, qo) and np.array_equal(tg, to) and np.array_equal(qg, q) and np.array_equal(tg, t)
     gm.close()
+
+
+def test_ceres_adapter_mode(O, S, stage_ab):
+    """SURVEY.md section 8b's adapter cut: the HOST owns the solver, the device prepares the scan (scal_map_adapter_begin), associates at
+    the solver's current pose (scal_map_associate), hands out the residual blocks (scal_map_get_blocks) or evaluates all of them in
+    one batch (scal_map_eval_blocks: residuals + ambient Jacobians, the interface of the reference's AutoDiffCostFunctions,
+    lidarFactor.hpp:12-138), and inserts the scan at the solved pose (scal_map_adapter_finish).
+      (1) every block's residual and 3x7 / 1x7 Jacobian equals the oracle's autodiff (Jets) evaluation of the same functor;
+      (2) with the oracle's restatement of ceres::Solve as the host solver the poses equal the all-device path's."""
+    a = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)   # all-device
+    b = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)   # adapter mode
+    checked = 0
+    for k, fr in enumerate(stage_ab[:6]):
+        qa, ta, sa, _ = a.process(fr["corner"], fr["surf"], fr["full"], fr["q"], fr["t"])
+        q, t = b.adapter_begin(fr["corner"], fr["surf"], fr["full"], fr["q"], fr["t"])
+        for outer in range(2):  # :563
+            nb, nr = b.associate(q, t)
+            if nb == 0:   # map too small (:555): no solve
+                continue
+            kind, cp, pa, pb = b.blocks()
+            assert nb == sa.n_edge[outer] + sa.n_plane[outer] and nr == 3 * sa.n_edge[outer] + sa.n_plane[outer], (k, outer)
+            assert (kind == 0).sum() == sa.n_edge[outer] and (kind == 2).sum() == sa.n_plane[outer]
+            x7 = np.concatenate([q, t])
+            r, J = b.eval_blocks(x7)
+            row = 0
+            for i in list(range(0, nb, max(1, nb // 150)))[:150]:   # a sample of the blocks against the autodiff oracle
+                row = int(3 * (kind[:i] == 0).sum() + (kind[:i] != 0).sum())
+                ro, Jo = O.factor_eval(int(kind[i]), cp[i], np.concatenate([pa[i], pb[i]]), x7)
+                n_r = 3 if kind[i] == 0 else 1
+                assert np.abs(r[row:row + n_r] - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max()), (k, outer, i)
+                assert np.abs(J[row:row + n_r] - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max()), (k, outer, i)
+                checked += 1
+            x, iters, trace, term = O.ceres_solve(kind, cp, pa, pb, x7)   # the host's solver (oracle restatement of ceres::Solve)
+            q, t = x[:4].copy(), x[4:].copy()
+        sb, _ = b.adapter_finish(q, t)
+        assert max(np.abs(q - qa).max(), np.abs(t - ta).max()) <= 1e-9, (k, np.abs(q - qa).max(), np.abs(t - ta).max())
+        assert sb.n_map_corner_total == sa.n_map_corner_total and sb.n_map_surf_total == sa.n_map_surf_total, k
+        qwa, twa = a.wmap_wodom()
+        qwb, twb = b.wmap_wodom()
+        assert np.abs(qwa - qwb).max() <= 1e-9 and np.abs(twa - twb).max() <= 1e-9
+    assert checked > 500
+    for which in (0, 1):
+        ma, mb = _sorted_rows(a.export(which)), _sorted_rows(b.export(which))
+        assert ma.shape == mb.shape and (ma != mb).any(axis=1).sum() <= 3
+    with pytest.raises(S.ScalError) as e:
+        b.associate(q, t)   # no open step
+    assert e.value.code == S.E_STATE
+    a.close(), b.close()
