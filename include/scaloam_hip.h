@@ -323,6 +323,19 @@ int scal_odom_enqueue_features(scal_odom_t* ctx, scal_features_t* feat);
 int scal_odom_collect(scal_odom_t* ctx, double* q_last_curr, double* t_last_curr, double* q_w_curr, double* t_w_curr,
                       scal_odom_stats* stats);
 
+/* Ceres-adapter mode of stage B (laserOdometry.cpp:278-501 with the host's own ceres::Problem / ceres::Solve), the counterpart of
+ * scal_map_adapter_*: begin uploads the four clouds and returns the initial guess (para_q / para_t persist across scans, :97-101)
+ * and whether this frame is solved at all (the first one is not, :267-271); per outer iteration scal_odom_associate runs the
+ * correspondence search of :299-483 at the solver's current increment, scal_odom_get_blocks / scal_odom_eval_blocks are as for
+ * stage C (kind 0 LidarEdgeFactor, kind 1 LidarPlaneFactor given as (j, unit normal)); finish integrates the pose (:504-505) and
+ * hands the clouds over (:554-568). */
+int scal_odom_adapter_begin(scal_odom_t* ctx, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat,
+                            int n_flat, const float* less_flat, int n_less_flat, double* q_last_curr, double* t_last_curr, int* need_solve);
+int scal_odom_associate(scal_odom_t* ctx, const double* q_last_curr, const double* t_last_curr, int* n_blocks, int* n_residuals);
+int scal_odom_get_blocks(scal_odom_t* ctx, scal_block* out, int cap);
+int scal_odom_eval_blocks(scal_odom_t* ctx, const double* x7, int want_jac, double* residuals, double* jacobians);
+int scal_odom_adapter_finish(scal_odom_t* ctx, const double* q_last_curr, const double* t_last_curr, double* q_w_curr, double* t_w_curr);
+
 /* ------------------------------------------------------------------ offline dense map merge
  * Replaces the loop body of utils/python/makeMergedMap.py:83-133: keyframe cloud x SE(3) pose -> global frame (f64), removal of
  * points whose LOCAL range is <= near_thres (:109-116, 2 m in the script), concatenation in keyframe order, f32 xyzi out

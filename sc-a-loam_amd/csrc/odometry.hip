@@ -400,6 +400,14 @@ struct scal_odom {
     DevBuf<OdomCounters> d_C;
     PinBuf<LMState> h_st;       // [MAX_STEPS]
     PinBuf<OdomCounters> h_up;  // upload staging of scal_odom_step
+    // Ceres-adapter mode (scal_odom_adapter_begin ... _finish)
+    bool adapter_active = false, adapter_solve = false;
+    DevBuf<int> bl_live, bl_rowoff, bl_counts;
+    DevBuf<double> d_x7, d_res, d_jac, d_blocks;
+    PinBuf<int> h_counts;
+    PinBuf<double> h_x7;
+    int outer_next = 0;
+    BlockList block_list() { return BlockList{bl_live.p, bl_rowoff.p, bl_counts.p}; }
     FactorSoA factors() { return FactorSoA{fvalid.p, fkind.p, fcp.p, fpa.p, fpb.p, slot_cap}; }
 };
 
@@ -428,6 +436,8 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
     A(c->ring_tab.alloc(8 * RING_TAB));
+    A(c->bl_live.alloc(c->slot_cap)); A(c->bl_rowoff.alloc(c->slot_cap + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->h_x7.alloc(8));
+    A(c->d_x7.alloc(8)); A(c->d_res.alloc(3 * (size_t)c->slot_cap)); A(c->d_jac.alloc(21 * (size_t)c->slot_cap)); A(c->d_blocks.alloc(10 * (size_t)c->slot_cap));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_st.alloc(scal_odom::MAX_STEPS)); A(c->h_up.alloc(1));
     c->lane = stage_lane(STAGE_ODOM);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
@@ -477,6 +487,7 @@ void o_rot(const double* q, const double* v, double* o) {
     o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
 }
 
+int launch_handover(scal_odom* c, int slot);
 // inputs already in sharp / flat / less_sharp / less_flat with counts in d_C
 int odom_enqueue(scal_odom* c) {
     hipStream_t s = c->stream;
@@ -503,7 +514,17 @@ int odom_enqueue(scal_odom* c) {
             }
         }
     }
-    // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets
+    SCAL_TRY(launch_handover(c, slot));
+    SCAL_HIP(hipEventRecord(c->ev[slot], s));
+    c->pending.push_back({slot, solve});
+    return SCAL_OK;
+}
+
+// hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets; the state goes to the host slot
+int launch_handover(scal_odom* c, int slot) {
+    hipStream_t s = c->stream;
+    OdomCounters* C = c->d_C.p;
+    LMState* st = c->d_st.p;
     {
         HandoverArgs h;
         h.in[0] = c->less_sharp.cv(), h.in[1] = c->less_flat.cv();
@@ -519,8 +540,6 @@ int odom_enqueue(scal_odom* c) {
         c->tab_cur ^= 1;
     }
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev[slot], s));
-    c->pending.push_back({slot, solve});
     return SCAL_OK;
 }
 
@@ -568,24 +587,8 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
 
 }  // namespace
 
-extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat,
-                              int n_flat, const float* less_flat, int n_less_flat, double* q_lc, double* t_lc, double* q_w, double* t_w,
-                              scal_odom_stats* stats) {
-    if (!c || !q_lc || !t_lc || !q_w || !t_w || n_sharp < 0 || n_less_sharp < 0 || n_flat < 0 || n_less_flat < 0 || (n_sharp && !sharp) ||
-        (n_less_sharp && !less_sharp) || (n_flat && !flat) || (n_less_flat && !less_flat)) {
-        set_error("scal_odom_step: bad argument");
-        return SCAL_E_ARG;
-    }
-    if (n_sharp + n_flat > c->slot_cap || n_sharp > c->slot_cap || n_flat > c->slot_cap || n_less_sharp > c->feat_cap || n_less_flat > c->cap) {
-        set_error("scal_odom_step: cloud larger than the context capacity (sharp+flat <= %d, lessSharp <= %d, lessFlat <= %d)", c->slot_cap,
-                  c->feat_cap, c->cap);
-        return SCAL_E_TOO_MANY;
-    }
-    SCAL_HIP(hipSetDevice(c->cfg.device));
-    if (!c->pending.empty()) {
-        set_error("scal_odom_step: a queued step has not been collected");
-        return SCAL_E_STATE;
-    }
+static int odom_upload(scal_odom* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat, int n_flat,
+                       const float* less_flat, int n_less_flat) {
     hipStream_t s = c->stream;
     SCAL_HIP(hipStreamSynchronize(s));  // the upload staging may still feed the previous call's copy
     OdomCounters& H = *c->h_up.p;
@@ -608,6 +611,28 @@ extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, c
     SCAL_TRY(up(flat, n_flat, c->flat));
     SCAL_TRY(up(less_sharp, n_less_sharp, c->less_sharp));
     SCAL_TRY(up(less_flat, n_less_flat, c->less_flat));
+    return SCAL_OK;
+}
+
+extern "C" int scal_odom_step(scal_odom_t* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat,
+                              int n_flat, const float* less_flat, int n_less_flat, double* q_lc, double* t_lc, double* q_w, double* t_w,
+                              scal_odom_stats* stats) {
+    if (!c || !q_lc || !t_lc || !q_w || !t_w || n_sharp < 0 || n_less_sharp < 0 || n_flat < 0 || n_less_flat < 0 || (n_sharp && !sharp) ||
+        (n_less_sharp && !less_sharp) || (n_flat && !flat) || (n_less_flat && !less_flat)) {
+        set_error("scal_odom_step: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_sharp + n_flat > c->slot_cap || n_sharp > c->slot_cap || n_flat > c->slot_cap || n_less_sharp > c->feat_cap || n_less_flat > c->cap) {
+        set_error("scal_odom_step: cloud larger than the context capacity (sharp+flat <= %d, lessSharp <= %d, lessFlat <= %d)", c->slot_cap,
+                  c->feat_cap, c->cap);
+        return SCAL_E_TOO_MANY;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (!c->pending.empty()) {
+        set_error("scal_odom_step: a queued step has not been collected");
+        return SCAL_E_STATE;
+    }
+    SCAL_TRY(odom_upload(c, sharp, n_sharp, less_sharp, n_less_sharp, flat, n_flat, less_flat, n_less_flat));
     SCAL_TRY(odom_enqueue(c));
     return odom_collect(c, q_lc, t_lc, q_w, t_w, stats);
 }
@@ -658,4 +683,139 @@ extern "C" int scal_odom_step_features(scal_odom_t* c, scal_features_t* feat, do
     }
     SCAL_TRY(scal_odom_enqueue_features(c, feat));
     return odom_collect(c, q_lc, t_lc, q_w, t_w, stats);
+}
+
+// ------------------------------------------------------------------------------------------------ Ceres-adapter mode
+// laserOdometry.cpp:278-501 with the host's own ceres::Problem / ceres::Solve: the device associates at the solver's current
+// q_last_curr / t_last_curr and evaluates the residual blocks in batches.
+extern "C" int scal_odom_adapter_begin(scal_odom_t* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat,
+                                       int n_flat, const float* less_flat, int n_less_flat, double* q_last_curr, double* t_last_curr, int* need_solve) {
+    if (!c || !q_last_curr || !t_last_curr || !need_solve || n_sharp < 0 || n_less_sharp < 0 || n_flat < 0 || n_less_flat < 0 || (n_sharp && !sharp) ||
+        (n_less_sharp && !less_sharp) || (n_flat && !flat) || (n_less_flat && !less_flat)) {
+        set_error("scal_odom_adapter_begin: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n_sharp + n_flat > c->slot_cap || n_less_sharp > c->feat_cap || n_less_flat > c->cap) {
+        set_error("scal_odom_adapter_begin: cloud larger than the context capacity");
+        return SCAL_E_TOO_MANY;
+    }
+    if (!c->pending.empty() || c->adapter_active) {
+        set_error("scal_odom_adapter_begin: a step is still open");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_TRY(odom_upload(c, sharp, n_sharp, less_sharp, n_less_sharp, flat, n_flat, less_flat, n_less_flat));
+    SCAL_HIP(hipMemcpyAsync(c->h_st.p, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 4; ++i) q_last_curr[i] = c->h_st.p->x[i];   // para_q / para_t persist across scans (:97-101)
+    for (int i = 0; i < 3; ++i) t_last_curr[i] = c->h_st.p->x[4 + i];
+    c->adapter_solve = c->systemInited;  // first frame: no optimisation (:267-271)
+    c->systemInited = true;
+    *need_solve = c->adapter_solve ? 1 : 0;
+    c->adapter_active = true;
+    c->outer_next = 0;
+    return SCAL_OK;
+}
+
+static int odom_set_pose(scal_odom* c, const double* q, const double* t) {
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; ++i) c->h_x7.p[i] = q[i];
+    for (int i = 0; i < 3; ++i) c->h_x7.p[4 + i] = t[i];
+    SCAL_HIP(hipMemcpyAsync(c->d_st.p->x, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
+    return SCAL_OK;
+}
+
+extern "C" int scal_odom_associate(scal_odom_t* c, const double* q_last_curr, const double* t_last_curr, int* n_blocks, int* n_residuals) {
+    if (!c || !q_last_curr || !t_last_curr || !n_blocks || !n_residuals) {
+        set_error("scal_odom_associate: null argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active || !c->adapter_solve) {
+        set_error("scal_odom_associate: no open step that needs a solve");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    OdomCounters* C = c->d_C.p;
+    LMState* st = c->d_st.p;
+    FactorSoA F = c->factors();
+    SCAL_TRY(odom_set_pose(c, q_last_curr, t_last_curr));
+    SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
+                     c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
+    SCAL_LAUNCH_PROF("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
+                     c->surf_last.cv(), st, C, std::min(c->outer_next, 1), F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
+    c->outer_next++;
+    SCAL_LAUNCH_PROF("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    *n_blocks = c->h_counts.p[0], *n_residuals = c->h_counts.p[1];
+    return SCAL_OK;
+}
+
+extern "C" int scal_odom_get_blocks(scal_odom_t* c, scal_block* out, int cap) {
+    if (!c || (!out && cap > 0) || cap < 0) {
+        set_error("scal_odom_get_blocks: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_odom_get_blocks: no scal_odom_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int n = std::min(cap, c->h_counts.p[0]);
+    if (n <= 0) return 0;
+    hipStream_t s = c->stream;
+    SCAL_LAUNCH_PROF("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
+    SCAL_HIP(hipMemcpyAsync(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return n;
+}
+
+extern "C" int scal_odom_eval_blocks(scal_odom_t* c, const double* x7, int want_jac, double* residuals, double* jacobians) {
+    if (!c || !x7 || !residuals || (want_jac && !jacobians)) {
+        set_error("scal_odom_eval_blocks: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_odom_eval_blocks: no scal_odom_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    const int nb = c->h_counts.p[0], nr = c->h_counts.p[1];
+    if (nb == 0) return SCAL_OK;
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < 7; ++i) c->h_x7.p[i] = x7[i];
+    SCAL_HIP(hipMemcpyAsync(c->d_x7.p, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH_PROF("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
+                     c->d_res.p, c->d_jac.p);
+    SCAL_HIP(hipGetLastError());
+    SCAL_HIP(hipMemcpyAsync(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
+    if (want_jac) SCAL_HIP(hipMemcpyAsync(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
+extern "C" int scal_odom_adapter_finish(scal_odom_t* c, const double* q_last_curr, const double* t_last_curr, double* q_w_curr, double* t_w_curr) {
+    if (!c || !q_last_curr || !t_last_curr || !q_w_curr || !t_w_curr) {
+        set_error("scal_odom_adapter_finish: null argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->adapter_active) {
+        set_error("scal_odom_adapter_finish: no scal_odom_adapter_begin");
+        return SCAL_E_STATE;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    c->adapter_active = false;
+    SCAL_TRY(odom_set_pose(c, q_last_curr, t_last_curr));  // para_q / para_t of the next scan's initial guess
+    const int slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % scal_odom::MAX_STEPS;
+    SCAL_TRY(launch_handover(c, slot));
+    SCAL_HIP(hipEventRecord(c->ev[slot], c->stream));
+    c->pending.push_back({slot, c->adapter_solve});
+    double q_lc[4], t_lc[3];
+    return odom_collect(c, q_lc, t_lc, q_w_curr, t_w_curr, nullptr);  // pose integration (:504-505)
 }

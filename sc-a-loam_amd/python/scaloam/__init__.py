@@ -98,7 +98,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_odom_adapter_begin", "scal_odom_associate", "scal_odom_get_blocks", "scal_odom_eval_blocks", "scal_odom_adapter_finish", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
     "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_align_device", "scal_icp_set_search",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
@@ -176,6 +176,11 @@ def lib():
     L.scal_map_get_blocks.argtypes = [vp, vp, C.c_int]
     L.scal_map_eval_blocks.argtypes = [vp, _f64p, C.c_int, _f64p, _f64p]
     L.scal_map_adapter_finish.argtypes = [vp, _f64p, _f64p, _f32p, C.POINTER(MapStats)]
+    L.scal_odom_adapter_begin.argtypes = [vp, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, C.POINTER(C.c_int)]
+    L.scal_odom_associate.argtypes = [vp, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.scal_odom_get_blocks.argtypes = [vp, vp, C.c_int]
+    L.scal_odom_eval_blocks.argtypes = [vp, _f64p, C.c_int, _f64p, _f64p]
+    L.scal_odom_adapter_finish.argtypes = [vp, _f64p, _f64p, _f64p, _f64p]
     L.scal_map_set_poll.argtypes = [vp, C.c_int]
     L.scal_map_prefetch_features.argtypes = [vp, vp]
     L.scal_map_enqueue_features.argtypes = [vp, vp, _f64p, _f64p]
@@ -636,6 +641,40 @@ class LaserOdometry:
         st = OdomStats()
         _check(lib().scal_odom_collect(self.h, _p(qlc, _f64p), _p(tlc, _f64p), _p(qw, _f64p), _p(tw, _f64p), C.byref(st)))
         return qlc, tlc, qw, tw, st
+
+    # ---- Ceres-adapter mode (the caller owns the solver)
+    def adapter_begin(self, sharp, less_sharp, flat, less_flat):
+        a = [_f32(x).reshape(-1, 4) for x in (sharp, less_sharp, flat, less_flat)]
+        q, t, need = np.zeros(4), np.zeros(3), C.c_int(0)
+        _check(lib().scal_odom_adapter_begin(self.h, _p(a[0], _f32p), a[0].shape[0], _p(a[1], _f32p), a[1].shape[0], _p(a[2], _f32p), a[2].shape[0],
+                                             _p(a[3], _f32p), a[3].shape[0], _p(q, _f64p), _p(t, _f64p), C.byref(need)))
+        return q, t, bool(need.value)
+
+    def associate(self, q_lc, t_lc):
+        nb, nr = C.c_int(0), C.c_int(0)
+        _check(lib().scal_odom_associate(self.h, _p(_f64(q_lc), _f64p), _p(_f64(t_lc), _f64p), C.byref(nb), C.byref(nr)))
+        self._adapter_n = (nb.value, nr.value)
+        return nb.value, nr.value
+
+    def blocks(self):
+        nb = self._adapter_n[0]
+        raw = np.zeros((max(nb, 1), 10), np.float64)
+        n = lib().scal_odom_get_blocks(self.h, raw.ctypes.data, nb)
+        if n < 0:
+            _check(n)
+        raw = raw[:n]
+        return raw[:, 0].copy().view(np.int32)[::2].copy(), raw[:, 1:4].copy(), raw[:, 4:7].copy(), raw[:, 7:10].copy()
+
+    def eval_blocks(self, x7, want_jac=True):
+        nb, nr = self._adapter_n
+        r, J = np.zeros(max(nr, 1)), np.zeros((max(nr, 1), 7))
+        _check(lib().scal_odom_eval_blocks(self.h, _p(_f64(x7), _f64p), 1 if want_jac else 0, _p(r, _f64p), _p(J, _f64p)))
+        return r[:nr], (J[:nr] if want_jac else None)
+
+    def adapter_finish(self, q_lc, t_lc):
+        qw, tw = np.zeros(4), np.zeros(3)
+        _check(lib().scal_odom_adapter_finish(self.h, _p(_f64(q_lc), _f64p), _p(_f64(t_lc), _f64p), _p(qw, _f64p), _p(tw, _f64p)))
+        return qw, tw
 
     def step_features(self, feat):
         qlc, tlc, qw, tw = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)

@@ -376,3 +376,39 @@ def test_async_entry_points_reject_misuse(S, hdl64_stream):
     assert ms2.insert_path in (0, 1)
     for x in (reg, od, mp, sc):
         x.close()
+
+
+def test_odometry_ceres_adapter_mode(O, S, hdl64_stream):
+    """Stage B with the solver on the host (scal_odom_adapter_*): blocks and their batched residual / Jacobian evaluation against the
+    oracle's autodiff, and - with the oracle's restatement of ceres::Solve as the host solver - the same poses as the all-device step."""
+    a, b = S.LaserOdometry(max_points=200000), S.LaserOdometry(max_points=200000)
+    checked = 0
+    for k in range(5):
+        f = O.features(hdl64_stream(k), O.HDL64, 5.0)
+        c = f["cloud"]
+        clouds = (c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
+        qlc_a, tlc_a, qw_a, tw_a, st_a = a.step(*clouds)
+        q, t, need = b.adapter_begin(*clouds)
+        assert need == (k > 0)
+        if need:
+            for outer in range(2):   # laserOdometry.cpp:278
+                nb, nr = b.associate(q, t)
+                assert nb == st_a.n_edge[outer] + st_a.n_plane[outer], (k, outer, nb)
+                kind, cp, pa, pb = b.blocks()
+                assert (kind == 0).sum() == st_a.n_edge[outer] and (kind == 1).sum() == st_a.n_plane[outer]
+                x7 = np.concatenate([q, t])
+                r, J = b.eval_blocks(x7)
+                for i in range(0, nb, max(1, nb // 60)):
+                    row = int(3 * (kind[:i] == 0).sum() + (kind[:i] != 0).sum())
+                    ro, Jo = O.factor_eval(int(kind[i]), cp[i], np.concatenate([pa[i], pb[i]]), x7)
+                    n_r = 3 if kind[i] == 0 else 1
+                    assert np.abs(r[row:row + n_r] - ro).max() <= 1e-9 * max(1.0, np.abs(ro).max())
+                    assert np.abs(J[row:row + n_r] - Jo).max() <= 1e-9 * max(1.0, np.abs(Jo).max())
+                    checked += 1
+                x, _, _, _ = O.ceres_solve(kind, cp, pa, pb, x7)
+                q, t = x[:4].copy(), x[4:].copy()
+        qw_b, tw_b = b.adapter_finish(q, t)
+        assert max(np.abs(qw_a - qw_b).max(), np.abs(tw_a - tw_b).max()) <= 1e-9, k
+        assert max(np.abs(qlc_a - q).max(), np.abs(tlc_a - t).max()) <= 1e-9, k
+    assert checked > 200
+    a.close(), b.close()
