@@ -248,14 +248,21 @@ def main():
         host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
         return r
 
+    sc_ext = torch.cuda.ExternalStream(sc.stream_ptr()) if (world > 1 and a.backend == "nccl") else None
+
     def sc_sharded(k, queued=False):
-        """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records)"""
+        """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records).  Under RCCL the
+        collectives (torch's stream) and the shard's kernels (the library's stream, scal_sc_stream) are ordered against each other
+        on the device; the host only waits for the final records.  The gloo rehearsal stages through the host and synchronises."""
         if queued:
             sc_build.wait_descriptor()  # the oldest queued descriptor (scan k); younger builds keep running
         else:
             sc.make_features(reg, d_q[k % 2].data_ptr())
         all_gather(all_q, d_q[k % 2])
-        torch.cuda.current_stream().synchronize()
+        if sc_ext is not None:
+            sc_ext.wait_stream(torch.cuda.current_stream())
+        else:
+            torch.cuda.current_stream().synchronize()
         sc.insert_descriptors_device(all_q.data_ptr(), world)  # global insertion order: rank 0..N-1 of this step, one launch
         sc_state["n_global"] += world
         # detectLoopClosureID's tree period (Scancontext.cpp:353-365), one query per rank in global order
@@ -266,9 +273,12 @@ def main():
             sc_state["counter"] += 1
             limits.append(sc_state["size_at_rebuild"])
         sc.shard_query_batch_device(all_q.data_ptr(), limits, d_rec.data_ptr())  # every query against its own tree size
-        sc.sync()
+        if sc_ext is not None:
+            torch.cuda.current_stream().wait_stream(sc_ext)
+        else:
+            sc.sync()
         all_gather(all_rec, d_rec)
-        rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query
+        rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query (the one host wait)
         cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
         return S.merge_candidates(cands, 0.4)
 

@@ -58,6 +58,23 @@ int scal_prof_names(char* buf, int cap);
 int scal_prof_timeline(int on);
 int scal_prof_timeline_dump(const char* path);
 
+/* ------------------------------------------------------------------ ordering against the caller's own streams
+ * Every `_device` entry point reads (and writes) the caller's device memory on the CONTEXT'S stream, which is not ordered against
+ * any stream of the caller: device inputs must be complete before the call, unless the caller orders the context's stream behind
+ * its producer itself.  These accessors return that stream (a hipStream_t) for exactly that: hipStreamWaitEvent(ctx_stream, ev)
+ * in front of the call, hipEventRecord(ev, ctx_stream) behind it (torch: torch.cuda.ExternalStream(ptr).wait_stream(...)).
+ * Typical producer: an RCCL collective on the caller's stream (sharded map filter, sharded ScanContext exchange). */
+typedef struct scal_features scal_features_t;
+typedef struct scal_voxel scal_voxel_t;
+typedef struct scal_sc scal_sc_t;
+typedef struct scal_map scal_map_t;
+typedef struct scal_odom scal_odom_t;
+void* scal_features_stream(scal_features_t* ctx);
+void* scal_voxel_stream(scal_voxel_t* ctx);
+void* scal_sc_stream(scal_sc_t* ctx);
+void* scal_map_stream(scal_map_t* ctx);
+void* scal_odom_stream(scal_odom_t* ctx);
+
 /* ------------------------------------------------------------------ stage A: feature extraction
  * Replaces laserCloudHandler, src/scanRegistration.cpp:134-421 (NaN/range filter, ring id + relative
  * time, ring-major reorder, curvature, per-(ring,sixth) sort + greedy sharp/lessSharp/flat picks,
@@ -115,7 +132,8 @@ int scal_voxel_create(int max_points, int device, scal_voxel_t** ctx);
 void scal_voxel_destroy(scal_voxel_t* ctx);
 int scal_voxel_downsample(scal_voxel_t* ctx, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out);
 /* the same with the cloud and the output (room for n records; may not overlap the input) in device memory, e.g. between
- * scal_mapmerge_device_points and scal_icp_align_device: loopFindNearKeyframesCloud's VoxelGrid, :491-492; waits, *n_out on the host */
+ * scal_mapmerge_device_points and scal_icp_align_device: loopFindNearKeyframesCloud's VoxelGrid, :491-492; waits, *n_out on the host.
+ * The input must be complete (or scal_voxel_stream ordered behind its producer) before the call. */
 int scal_voxel_downsample_device(scal_voxel_t* ctx, const float* d_xyzi, int n, float leaf, float* d_out_xyzi, int* n_out);
 
 /* ------------------------------------------------------------------ stage D: ScanContext

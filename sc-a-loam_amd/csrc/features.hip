@@ -1002,3 +1002,5 @@ extern "C" int scal_features_run(scal_features_t* c, const void* xyz, int n, int
 extern "C" int scal_features_enqueue_host(scal_features_t* c, const void* xyz, int n, int stride_bytes) {
     return features_run_host(c, xyz, n, stride_bytes, nullptr, true);
 }
+
+extern "C" void* scal_features_stream(scal_features_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

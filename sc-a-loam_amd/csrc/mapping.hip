@@ -2303,3 +2303,5 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
     }
     return SCAL_OK;
 }
+
+extern "C" void* scal_map_stream(scal_map_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

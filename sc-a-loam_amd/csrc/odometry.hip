@@ -819,3 +819,5 @@ extern "C" int scal_odom_adapter_finish(scal_odom_t* c, const double* q_last_cur
     double q_lc[4], t_lc[3];
     return odom_collect(c, q_lc, t_lc, q_w_curr, t_w_curr, nullptr);  // pose integration (:504-505)
 }
+
+extern "C" void* scal_odom_stream(scal_odom_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

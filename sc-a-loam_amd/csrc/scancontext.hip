@@ -1333,3 +1333,5 @@ extern "C" int scal_sc_distance_matrix_device(scal_sc_t* c, int q0, int q1, int 
     SCAL_HIP(hipSetDevice(c->cfg.device));
     return enqueue_matrix(c, q0, q1, d0, d1, mode, d_dist, d_shift, c->stream);
 }
+
+extern "C" void* scal_sc_stream(scal_sc_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

@@ -492,3 +492,5 @@ extern "C" int scal_voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, 
 extern "C" int scal_voxel_downsample_device(scal_voxel_t* c, const float* d_xyzi, int n, float leaf, float* d_out_xyzi, int* n_out) {
     return voxel_downsample(c, d_xyzi, n, leaf, d_out_xyzi, n_out, true);
 }
+
+extern "C" void* scal_voxel_stream(scal_voxel_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

@@ -91,7 +91,7 @@ class OdomStats(C.Structure):
 # every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names", "scal_prof_timeline", "scal_prof_timeline_dump",
-    "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_enqueue_host", "scal_features_fetch",
+    "scal_features_create", "scal_features_destroy", "scal_features_run", "scal_features_run_device", "scal_features_enqueue_host", "scal_features_stream", "scal_voxel_stream", "scal_sc_stream", "scal_map_stream", "scal_odom_stream", "scal_features_fetch",
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample", "scal_voxel_downsample_device",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
@@ -125,6 +125,9 @@ def lib():
     L.scal_features_run.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(FeaturesOut)]
     L.scal_features_run_device.argtypes = [vp, vp, C.c_int, C.c_int]
     L.scal_features_enqueue_host.argtypes = [vp, vp, C.c_int, C.c_int]
+    for fn in ("scal_features_stream", "scal_voxel_stream", "scal_sc_stream", "scal_map_stream", "scal_odom_stream"):
+        getattr(L, fn).restype = C.c_void_p
+        getattr(L, fn).argtypes = [vp]
     L.scal_features_fetch.argtypes = [vp, C.POINTER(FeaturesOut)]
     L.scal_features_sync.argtypes = [vp]
     L.scal_voxel_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
@@ -360,6 +363,10 @@ class VoxelGrid:
         _check(lib().scal_voxel_downsample(self.h, _p(xyzi, _f32p), xyzi.shape[0], C.c_float(leaf), _p(out, _f32p), C.byref(n)))
         return out[:n.value].copy()
 
+    def stream_ptr(self):
+        """the context's hipStream_t (to order it against the caller's streams, e.g. torch.cuda.ExternalStream(ptr))"""
+        return lib().scal_voxel_stream(self.h)
+
     def filter_device(self, d_in_ptr, n, leaf, d_out_ptr):
         """16-byte xyzi records in device memory in, centroids to d_out_ptr (room for n records); returns their number."""
         m = C.c_int(0)
@@ -406,6 +413,10 @@ class SCManager:
         k = np.zeros(20, np.float32)
         _check(lib().scal_sc_get_descriptor(self.h, idx, _p(d, _f64p), _p(k, _f32p)))
         return d.reshape(60, 20).T.copy(), k
+
+    def stream_ptr(self):
+        """the context's hipStream_t (to order it against the caller's streams, e.g. torch.cuda.ExternalStream(ptr))"""
+        return lib().scal_sc_stream(self.h)
 
     def insert_features(self, feat):
         """keyframe cloud of a ScanRegistration context -> VoxelGrid(0.4) -> makeAndSaveScancontextAndKeys, all on the GPU"""

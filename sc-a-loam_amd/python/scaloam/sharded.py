@@ -93,7 +93,12 @@ def gpu_voxel_filter(device):
             vg = state["vg"] = VoxelGrid(max_points=n + 1024, device=device)
             state["cap"] = n + 1024
         out = torch.empty_like(recv)
-        m = vg.filter_device(recv.data_ptr(), n, leaf, out.data_ptr())
+        # The filter runs on the library's own stream: order it behind whatever produced `recv` (under nccl the all-to-all has
+        # only been ENQUEUED on torch's stream when it returns) and torch's stream behind the filter, on the device.
+        ext = torch.cuda.ExternalStream(vg.stream_ptr(), device=recv.device)
+        ext.wait_stream(torch.cuda.current_stream(recv.device))
+        m = vg.filter_device(recv.data_ptr(), n, leaf, out.data_ptr())   # waits for its own stream before returning
+        torch.cuda.current_stream(recv.device).wait_stream(ext)
         return out[:m].cpu().numpy()
 
     return run

@@ -592,3 +592,24 @@ def test_voxel_large_cloud(O, S):
     assert guard == 0 and g.shape == o.shape
     assert np.array_equal(_bits(g), _bits(o))
     vg.close()
+
+
+def test_device_input_behind_a_producer_stream(S, golden):
+    """`_device` entry points read the caller's memory on the context's own stream (include/scaloam_hip.h "ordering against the
+    caller's own streams").  The sharded map filter orders that stream behind the producer of its input on the device
+    (scal_voxel_stream + torch ExternalStream): here the input is written by a copy that sits behind a ~20 ms busy-wait on a torch
+    side stream - as an RCCL all-to-all would still be in flight when torch returns - and the result must equal the filter of the
+    finished data."""
+    torch = pytest.importorskip("torch")
+    from scaloam.sharded import gpu_voxel_filter
+    src = torch.from_numpy(np.ascontiguousarray(np.concatenate([golden("Seosan01_000000.npy"), golden("Seosan01_000011.npy")]), np.float32)).cuda()
+    run = gpu_voxel_filter(0)
+    want = run(src, 0.4)                      # producer long finished
+    side = torch.cuda.Stream()
+    recv = torch.zeros_like(src)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(40_000_000)         # the "collective" is still running when the host moves on
+        recv.copy_(src, non_blocking=True)
+        got = run(recv, 0.4)                  # must wait for the copy on the device, not read the zeros
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
