@@ -530,6 +530,8 @@ struct LMNoHook {
 // Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
 // sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
 constexpr int LM_GRID = 64;
+// poll budget of the grid barrier (per translation unit; scal_*_debug_set_lm_polls lowers it to force the give-up path in tests)
+static __device__ int g_lm_poll_budget = 1 << 22;
 struct LMSync {
     unsigned arrivals;  // grows forever (wrap-around safe comparisons)
     unsigned epoch;     // arrivals consumed by all earlier solves
@@ -616,7 +618,8 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             __hip_atomic_fetch_add(&sync->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // data already written through
             const unsigned target = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(round + 1);
             int ok = 0;
-            for (int poll = 0; poll < (1 << 22); ++poll) {
+            const int budget = g_lm_poll_budget;
+            for (int poll = 0; poll < budget; ++poll) {
                 const unsigned cur = __hip_atomic_load(&sync->arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (static_cast<int>(cur - target) >= 0) {
                     ok = 1;
@@ -688,6 +691,27 @@ inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* 
 }
 
 // host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
+// The grid barrier needs all (<= LM_GRID) workgroups of a solve resident at once.  A plain launch does not promise that, a
+// cooperative launch would - but cooperative launches of different streams take turns on this runtime, and stage B's and stage
+// C's solves must overlap.  So the contexts check at creation that the device can hold LM_GRID such workgroups many times over
+// (one per CU suffices: 256 CUs against 64), and the barrier gives up after a bounded number of polls (termination 5) instead of
+// hanging if something else ever occupied the machine.
+template <class Pre, class Post>
+inline int lm_check_residency(int device) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCAL_E_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), 256, 0) != hipSuccess) return SCAL_E_HIP;
+    if (per_cu * prop.multiProcessorCount < 4 * LM_GRID) {
+        set_error("device %d cannot keep %d LM workgroups resident (%d per CU x %d CUs)", device, LM_GRID, per_cu, prop.multiProcessorCount);
+        return SCAL_E_NO_DEVICE;
+    }
+    return SCAL_OK;
+}
+inline int lm_set_poll_budget(int polls) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_lm_poll_budget), &polls, sizeof(int)) == hipSuccess ? SCAL_OK : SCAL_E_HIP;
+}
+
 template <class Pre = LMNoHook, class Post = LMNoHook>
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
                             int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {

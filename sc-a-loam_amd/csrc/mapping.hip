@@ -1369,6 +1369,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->d_res.alloc(3 * sc)); A(c->d_jac.alloc(21 * sc)); A(c->d_blocks.alloc(10 * sc));
     A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     c->lane = stage_lane(STAGE_MAP);
+    if (rc == SCAL_OK) rc = lm_check_residency<LMNoHook, MapPoseDone>(c->cfg.device);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     for (int k = 0; k < scal_map::NSLOTS && rc == SCAL_OK; ++k) {
         if (hipEventCreateWithFlags(&c->ev_pose[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
@@ -2305,3 +2306,10 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
 }
 
 extern "C" void* scal_map_stream(scal_map_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+extern "C" int scal_map_debug_set_lm_polls(scal_map_t* c, int polls) {
+    if (!c || polls < 0) return SCAL_E_ARG;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_HIP(hipStreamSynchronize(c->stream));
+    return lm_set_poll_budget(polls);
+}

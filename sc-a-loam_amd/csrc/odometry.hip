@@ -440,6 +440,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->d_x7.alloc(8)); A(c->d_res.alloc(3 * (size_t)c->slot_cap)); A(c->d_jac.alloc(21 * (size_t)c->slot_cap)); A(c->d_blocks.alloc(10 * (size_t)c->slot_cap));
     A(c->d_st.alloc(1)); A(c->d_C.alloc(1)); A(c->h_st.alloc(scal_odom::MAX_STEPS)); A(c->h_up.alloc(1));
     c->lane = stage_lane(STAGE_ODOM);
+    if (rc == SCAL_OK) rc = lm_check_residency<LMNoHook, LMNoHook>(c->cfg.device);
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     for (int k = 0; k < scal_odom::MAX_STEPS && rc == SCAL_OK; ++k)
         if (hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;

@@ -297,3 +297,26 @@ def test_ceres_adapter_mode(O, S, stage_ab):
         b.associate(q, t)   # no open step
     assert e.value.code == S.E_STATE
     a.close(), b.close()
+
+
+def test_lm_barrier_gives_up_cleanly(S, stage_ab):
+    """The LM solve's grid barrier is a bounded wait: when a round's arrivals do not show up within the poll budget every workgroup
+    leaves with termination 5, the step reports SCAL_E_HIP, and the context keeps working.  The budget is lowered to zero here to
+    force that path (it cannot be provoked otherwise without another process hogging the GPU)."""
+    gm = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    ref = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
+    for fr in stage_ab[:3]:
+        gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+        ref.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+    gm.debug_set_lm_polls(0)
+    fr = stage_ab[3]
+    with pytest.raises(S.ScalError) as e:
+        gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+    assert e.value.code == S.E_HIP and "abandoned" in str(e.value)
+    gm.debug_set_lm_polls(1 << 22)
+    gm.finish()
+    q, t, st, _ = gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])   # the same scan again: solves normally
+    assert st.solved == 1 and st.lm_iters[0] >= 1
+    q2, t2, st2, _ = ref.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+    assert max(np.abs(q - q2).max(), np.abs(t - t2).max()) <= 5e-2   # (the abandoned step inserted the scan at its prior pose)
+    gm.close(), ref.close()
