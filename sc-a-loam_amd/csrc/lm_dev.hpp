@@ -44,12 +44,24 @@ struct LMState {
     double log_cost_init[2], log_cost_final[2];
 };
 
+// The part of LMState the trust-region state machine works on, without the per-outer-iteration log arrays (those are indexed
+// with a run-time value, which would push a private copy into scratch memory): the serial step runs on a register copy of this.
+struct LMCore {
+    double x[7], cand[7];
+    double x_cost, mcc, radius, decrease_factor, x_norm;
+    double H[21], g[6], scale[6];
+    int iteration, done, successful, started, enabled, termination;
+    double cost_init, cost_final;
+};
+
 __device__ __forceinline__ void quat_plus(const double* x, const double* delta, double* o) {
     // EigenQuaternionParameterization::Plus: [sin|d| d/|d|, cos|d|] (x) q, no half angle
     const double nd = sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
     if (nd > 0.0) {
-        const double s = sin(nd) / nd;
-        const double ax = s * delta[0], ay = s * delta[1], az = s * delta[2], aw = cos(nd);
+        double sn, cs;
+        sincos(nd, &sn, &cs);  // one range reduction for both
+        const double s = sn / nd;
+        const double ax = s * delta[0], ay = s * delta[1], az = s * delta[2], aw = cs;
         const double bx = x[0], by = x[1], bz = x[2], bw = x[3];
         o[0] = aw * bx + ax * bw + ay * bz - az * by;
         o[1] = aw * by + ay * bw + az * bx - ax * bz;
@@ -376,7 +388,8 @@ __device__ __forceinline__ bool chol_solve6(const double* Hs, const double* d2, 
 }
 
 // LevenbergMarquardtStrategy::ComputeStep + TrustRegionMinimizer::ComputeTrustRegionStep; loops over invalid steps
-__device__ __forceinline__ void lm_compute_candidate(LMState* st) {
+template <class State>
+__device__ __forceinline__ void lm_compute_candidate(State* st) {
     const int max_num_iterations = 4;
     while (!st->done) {
         if (st->iteration >= max_num_iterations) {
@@ -426,7 +439,8 @@ __device__ __forceinline__ void lm_compute_candidate(LMState* st) {
 }
 
 // Trust-region bookkeeping after one evaluation (TrustRegionMinimizer: IterationZero / candidate evaluation).
-__device__ __forceinline__ void lm_tail(LMState* st, const double* tot, int phase) {
+template <class State>
+__device__ __forceinline__ void lm_tail(State* st, const double* tot, int phase) {
     const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8, min_relative_decrease = 1e-3;
     // max-norm of x - Plus(x, -g), only ever compared with gradient_tolerance.  The translation part of that difference is g_t
     // itself (up to the rounding of x - (x - g), far below the tolerance's scale), so when one of its components already exceeds
@@ -530,6 +544,9 @@ struct LMNoHook {
 // Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
 // sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
 constexpr int LM_GRID = 64;
+constexpr int LM_THREADS = 256;   // (512-thread workgroups, i.e. half the arrivals and partial sums per round, measured slower: 64 vs 58 us)
+constexpr int LM_WAVES = LM_THREADS / 64;
+constexpr int LM_LDS_BYTES = LM_WAVES * LM_NACC * 65 * 8;
 // poll budget of the grid barrier (per translation unit; scal_*_debug_set_lm_polls lowers it to force the give-up path in tests)
 static __device__ int g_lm_poll_budget = 1 << 22;
 struct LMSync {
@@ -538,15 +555,16 @@ struct LMSync {
 };
 
 template <class Pre, class Post>
-static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
+static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
                                                          const int* __restrict__ d_enable, double* partials, LMSync* sync,
                                                          const int* __restrict__ d_abort, Pre pre, Post post) {
     if (d_abort && *d_abort) {  // uniform over the grid (written by an earlier kernel): a stopped chain leaves the state alone
-        post(st->x, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, true);
+        post(st->x, blockIdx.x * LM_THREADS + threadIdx.x, gridDim.x * LM_THREADS, true);
         return;
     }
-    __shared__ double xch[4][LM_NACC][65];  // per-wave transpose buffer (row stride 65: conflict-free column sums)
-    __shared__ double red[4][LM_NACC];
+    extern __shared__ __align__(16) unsigned char lm_lds[];  // per-wave transpose buffers (row stride 65: conflict-free column sums)
+    double (*xch)[LM_NACC][65] = reinterpret_cast<double (*)[LM_NACC][65]>(lm_lds);
+    __shared__ double red[LM_WAVES][LM_NACC];
     __shared__ double tot[LM_NACC];
     __shared__ LMState L;
     __shared__ int s_ok;
@@ -562,10 +580,10 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             st->log_n_edge[outer] = 0, st->log_n_plane[outer] = 0;
         }
         __syncthreads();
-        post(st->x, blockIdx.x * 256 + tid, G * 256, false);  // x is untouched: the prior pose stands
+        post(st->x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, false);  // x is untouched: the prior pose stands
         return;
     }
-    pre(blockIdx.x * 256 + tid, G * 256, n);
+    pre(blockIdx.x * LM_THREADS + tid, G * LM_THREADS, n);
     const unsigned epoch = sync->epoch;
     if (tid == 0) L = *st;  // only x carries over from the previous solve; lm_tail(phase 0) re-arms the rest
     __syncthreads();
@@ -581,7 +599,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         double acc[LM_NACC];
 #pragma unroll
         for (int k = 0; k < LM_NACC; ++k) acc[k] = 0.0;
-        for (int i = blockIdx.x * 256 + tid; i < n; i += G * 256) {
+        for (int i = blockIdx.x * LM_THREADS + tid; i < n; i += G * LM_THREADS) {
             if (f.valid[i]) {
                 const double cp[3] = {f.cp[i], f.cp[f.cap + i], f.cp[2 * f.cap + i]};
                 const double pa[3] = {f.pa[i], f.pa[f.cap + i], f.pa[2 * f.cap + i]};
@@ -609,8 +627,12 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         }
         __syncthreads();
         double* mine = partials + (static_cast<size_t>(round & 1) * LM_GRID + blockIdx.x) * LM_NACC;
-        if (tid < LM_NACC)
-            __hip_atomic_store(&mine[tid], ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            double wsum = red[0][tid < LM_NACC ? tid : 0];
+#pragma unroll
+            for (int w2 = 1; w2 < LM_WAVES; ++w2) wsum += red[w2][tid < LM_NACC ? tid : 0];  // fixed wave order
+            if (tid < LM_NACC) __hip_atomic_store(&mine[tid], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 2);
@@ -640,7 +662,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
             double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
             const double* all = partials + static_cast<size_t>(round & 1) * LM_GRID * LM_NACC;
             const int k = tid & 31, g = tid >> 5;
-            if (k < LM_NACC) {
+            if (k < LM_NACC && g < 8) {
                 double sacc = 0.0;
                 for (int b = g; b < G; b += 8) sacc += __hip_atomic_load(&all[b * LM_NACC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 gsum[0][k][g] = sacc;
@@ -655,9 +677,33 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 4);
-        if (tid == 0) {  // the serial tail works on the LDS copy of the state (a private copy would live in scratch)
+        if (tid == 0) {
+            // The serial step runs on a register copy of the state (LMCore: no run-time indexed arrays, so it does not go to
+            // scratch) and of the totals: on the LDS copy every field access was a dependent ~100-cycle round trip.
             if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
-            lm_tail(&L, tot, phase);
+            LMCore R;
+            double t[LM_NACC];
+#pragma unroll
+            for (int k = 0; k < LM_NACC; ++k) t[k] = tot[k];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) R.x[k] = L.x[k], R.cand[k] = L.cand[k];
+            R.x_cost = L.x_cost, R.mcc = L.mcc, R.radius = L.radius, R.decrease_factor = L.decrease_factor, R.x_norm = L.x_norm;
+#pragma unroll
+            for (int k = 0; k < 21; ++k) R.H[k] = L.H[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) R.g[k] = L.g[k], R.scale[k] = L.scale[k];
+            R.iteration = L.iteration, R.done = L.done, R.successful = L.successful, R.started = L.started, R.enabled = L.enabled;
+            R.termination = L.termination, R.cost_init = L.cost_init, R.cost_final = L.cost_final;
+            lm_tail(&R, t, phase);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) L.x[k] = R.x[k], L.cand[k] = R.cand[k];
+            L.x_cost = R.x_cost, L.mcc = R.mcc, L.radius = R.radius, L.decrease_factor = R.decrease_factor, L.x_norm = R.x_norm;
+#pragma unroll
+            for (int k = 0; k < 21; ++k) L.H[k] = R.H[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) L.g[k] = R.g[k], L.scale[k] = R.scale[k];
+            L.iteration = R.iteration, L.done = R.done, L.successful = R.successful, L.started = R.started, L.enabled = R.enabled;
+            L.termination = R.termination, L.cost_init = R.cost_init, L.cost_final = R.cost_final;
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 5);
@@ -669,7 +715,7 @@ static __global__ void __launch_bounds__(256) k_lm_solve(FactorSoA f, const int*
         sync->epoch = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(rounds);
     }
     __syncthreads();  // block 0's hook may publish *st
-    post(L.x, blockIdx.x * 256 + tid, G * 256, false);
+    post(L.x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, false);
 }
 
 // Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
@@ -701,7 +747,10 @@ inline int lm_check_residency(int device) {
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCAL_E_HIP;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), 256, 0) != hipSuccess) return SCAL_E_HIP;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES) != hipSuccess)
+        return SCAL_E_HIP;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), LM_THREADS, LM_LDS_BYTES) != hipSuccess)
+        return SCAL_E_HIP;
     if (per_cu * prop.multiProcessorCount < 4 * LM_GRID) {
         set_error("device %d cannot keep %d LM workgroups resident (%d per CU x %d CUs)", device, LM_GRID, per_cu, prop.multiProcessorCount);
         return SCAL_E_NO_DEVICE;
@@ -715,9 +764,9 @@ inline int lm_set_poll_budget(int polls) {
 template <class Pre = LMNoHook, class Post = LMNoHook>
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
                             int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {
-    int g = (f.cap + 255) / 256;
+    int g = (f.cap + LM_THREADS - 1) / LM_THREADS;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
-    SCAL_LAUNCH_PROF(prof_name, (k_lm_solve<Pre, Post>), dim3(g), dim3(256), 0, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
+    SCAL_LAUNCH_PROF(prof_name, (k_lm_solve<Pre, Post>), dim3(g), dim3(LM_THREADS), LM_LDS_BYTES, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
 }
 
 }  // namespace scal

@@ -1144,7 +1144,7 @@ struct MapPoseDone {
                 }
             }
         }
-        if (first >= 256) return;  // block 0 only from here on
+        if (blockIdx.x != 0) return;  // block 0 only from here on
         if (first == 0 && !stop) {
             // q_wmap_wodom = q_w_curr * q_wodom_curr^-1 ; t_wmap_wodom = t_w_curr - q_wmap_wodom * t_wodom_curr
             const double* q_wodom = S->q_wodom;
@@ -1169,7 +1169,7 @@ struct MapPoseDone {
 
 // the same work as a launch of its own (Ceres-adapter mode: the caller's solver produced the pose)
 __global__ void __launch_bounds__(256) k_map_pose_done(MapPoseDone pd) {
-    pd(pd.st->x, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256, false);
+    pd(pd.st->x, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, false);
 }
 
 // End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
