@@ -214,6 +214,12 @@ int scal_sc_distance_pairs(scal_sc_t* ctx, const int* idx_a, const int* idx_b, i
 int scal_sc_distance_matrix(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* dist, int* shift);
 /* the same with DEVICE outputs (nq*nd doubles / ints), enqueued on the context's stream: scal_sc_sync() before reading them */
 int scal_sc_distance_matrix_device(scal_sc_t* ctx, int q0, int q1, int d0, int d1, int mode, double* d_dist, int* d_shift);
+/* Batch loop search over a stored session (offline loop mining; the exhaustive counterpart of detectLoopClosureID's ring-key
+ * prefilter + 7-shift search, Scancontext.cpp:336-427): for every query keyframe q in [q0, q1) the k (<= 16) smallest distances
+ * among the keyframes d < q - exclude_recent (NUM_EXCLUDE_RECENT = 30, Scancontext.h:92), from the dense distance block of `mode`
+ * (2 = all 60 shifts on the f64 matrix cores) with the top-k taken on the device.  Outputs [q1 - q0][k]: keyframe index (-1 =
+ * fewer than k eligible), distance, column shift; ascending distance, ties to the lower index.  Unsharded contexts only. */
+int scal_sc_batch_loop_search(scal_sc_t* ctx, int q0, int q1, int exclude_recent, int k, int mode, int* idx, double* dist, int* shift);
 /* sharded search pieces (one context per GPU): local top-3 for the newest GLOBAL key, then a merge of the
  * gathered per-shard records (the all-gather itself is the caller's: RCCL via torch.distributed). */
 typedef struct {

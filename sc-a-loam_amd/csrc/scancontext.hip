@@ -1215,6 +1215,61 @@ extern "C" int scal_sc_merge_candidates(const scal_sc_cand* gathered, int n_reco
     return SCAL_OK;
 }
 
+
+namespace scal {
+// Batch loop search: the k smallest distances of every row of a dense distance block, among the database entries that are older
+// than the query by more than `exclude` keyframes (NUM_EXCLUDE_RECENT, Scancontext.h:92): d0 + j < q0 + row - exclude.
+// One workgroup per row; k rounds of a block-wide argmin over (distance, index) keys that must exceed the previous pick:
+// deterministic, ties go to the lower index.  Entries with NaN distance (no overlapping sector at any shift) never win.
+__global__ void __launch_bounds__(256) k_sc_row_topk(const double* __restrict__ dist, const int* __restrict__ shift, int nq, int nd, int q0, int d0,
+                                                     int exclude, int k, int* __restrict__ out_idx, double* __restrict__ out_dist,
+                                                     int* __restrict__ out_shift) {
+    __shared__ unsigned long long s_d[4];
+    __shared__ int s_j[4];
+    const int row = blockIdx.x;
+    if (row >= nq) return;
+    const double* drow = dist + static_cast<size_t>(row) * nd;
+    const int limit = min(nd, q0 + row - exclude - d0);  // eligible columns: [0, limit)
+    unsigned long long last_d = 0;
+    int last_j = -1;
+    bool first = true;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long bd = ~0ull;
+        int bj = 0x7fffffff;
+        for (int j = threadIdx.x; j < limit; j += 256) {
+            const double v = drow[j];
+            if (!(v == v)) continue;
+            const unsigned long long u = static_cast<unsigned long long>(__double_as_longlong(v < 0 ? 0.0 : v));  // distances are >= 0: bit order = value order
+            const bool after = first || u > last_d || (u == last_d && j > last_j);
+            if (after && (u < bd || (u == bd && j < bj))) bd = u, bj = j;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long od = shfl_xor_u64(bd, o);
+            const int oj = __shfl_xor(bj, o, 64);
+            if (od < bd || (od == bd && oj < bj)) bd = od, bj = oj;
+        }
+        if (lane_id() == 0) s_d[wave_id()] = bd, s_j[wave_id()] = bj;
+        __syncthreads();
+        bd = s_d[0], bj = s_j[0];
+        for (int w = 1; w < 4; ++w)
+            if (s_d[w] < bd || (s_d[w] == bd && s_j[w] < bj)) bd = s_d[w], bj = s_j[w];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const bool have = bj != 0x7fffffff;
+            out_idx[row * k + r] = have ? d0 + bj : -1;
+            out_dist[row * k + r] = have ? drow[bj] : 10000000.0;
+            out_shift[row * k + r] = have ? shift[static_cast<size_t>(row) * nd + bj] : 0;
+        }
+        if (bj == 0x7fffffff) {  // fewer than k eligible entries: the remaining slots are empty too
+            for (int r2 = r + 1 + threadIdx.x; r2 < k; r2 += 256) out_idx[row * k + r2] = -1, out_dist[row * k + r2] = 10000000.0, out_shift[row * k + r2] = 0;
+            return;
+        }
+        last_d = bd, last_j = bj, first = false;
+    }
+}
+}  // namespace scal
+
 static int ensure_pairs(scal_sc* c, size_t n) {
     if (n > c->pair_cap) {
         SCAL_TRY(c->d_pairs.alloc(2 * n));
@@ -1332,6 +1387,46 @@ extern "C" int scal_sc_distance_matrix_device(scal_sc_t* c, int q0, int q1, int 
     if (q1 == q0 || d1 == d0) return SCAL_OK;
     SCAL_HIP(hipSetDevice(c->cfg.device));
     return enqueue_matrix(c, q0, q1, d0, d1, mode, d_dist, d_shift, c->stream);
+}
+
+// Exhaustive loop mining over a stored session: for every query keyframe q in [q0, q1) its k best matches among the keyframes older
+// than q - exclude_recent, by the dense distance block of `mode` (2: f64 matrix cores) - row tiles of 512 queries, top-k on the
+// device, only k records per query come back.
+extern "C" int scal_sc_batch_loop_search(scal_sc_t* c, int q0, int q1, int exclude_recent, int k, int mode, int* idx, double* dist, int* shift) {
+    if (!c || !idx || !dist || !shift || q0 < 0 || q1 < q0 || exclude_recent < 0 || k < 1 || k > 16 || mode < 0 || mode > 3) {
+        set_error("scal_sc_batch_loop_search: bad argument (1 <= k <= 16)");
+        return SCAL_E_ARG;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->cfg.n_shards > 1 || q1 > c->n_global) {
+        set_error("scal_sc_batch_loop_search: range outside the database (or sharded context)");
+        return SCAL_E_ARG;
+    }
+    if (q1 == q0) return SCAL_OK;
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    hipStream_t s = c->stream;
+    const int TILE_Q = 512;
+    const int nd_max = std::max(1, q1 - 1 - exclude_recent);  // the newest query sees [0, q1 - 1 - exclude)
+    SCAL_TRY(ensure_pairs(c, static_cast<size_t>(TILE_Q) * nd_max));
+    DevBuf<int> o_idx, o_shift;
+    DevBuf<double> o_dist;
+    SCAL_TRY(o_idx.alloc(static_cast<size_t>(TILE_Q) * k));
+    SCAL_TRY(o_shift.alloc(static_cast<size_t>(TILE_Q) * k));
+    SCAL_TRY(o_dist.alloc(static_cast<size_t>(TILE_Q) * k));
+    for (int t0 = q0; t0 < q1; t0 += TILE_Q) {
+        const int t1 = std::min(q1, t0 + TILE_Q), nq = t1 - t0;
+        const int nd = std::max(0, t1 - 1 - exclude_recent);  // columns any query of this tile can use
+        if (nd > 0) SCAL_TRY(enqueue_matrix(c, t0, t1, 0, nd, mode, c->d_dist.p, c->d_shift.p, s));
+        SCAL_LAUNCH_PROF("k_sc_row_topk", k_sc_row_topk, dim3(nq), dim3(256), 0, s, c->d_dist.p, c->d_shift.p, nq, nd, t0, 0, exclude_recent, k, o_idx.p,
+                         o_dist.p, o_shift.p);
+        SCAL_HIP(hipGetLastError());
+        const size_t off = static_cast<size_t>(t0 - q0) * k;
+        SCAL_HIP(hipMemcpyAsync(idx + off, o_idx.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipMemcpyAsync(dist + off, o_dist.p, sizeof(double) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipMemcpyAsync(shift + off, o_shift.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(hipStreamSynchronize(s));
+    }
+    return SCAL_OK;
 }
 
 extern "C" void* scal_sc_stream(scal_sc_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

@@ -95,7 +95,7 @@ EXPORTED_SYMBOLS = [
     "scal_features_sync",
     "scal_voxel_create", "scal_voxel_destroy", "scal_voxel_downsample", "scal_voxel_downsample_device",
     "scal_sc_create", "scal_sc_destroy", "scal_sc_size", "scal_sc_insert_cloud", "scal_sc_insert_cloud_device",
-    "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_detect_collect", "scal_sc_distance_pairs",
+    "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_batch_loop_search", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
     "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_debug_set_lm_polls", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_odom_adapter_begin", "scal_odom_associate", "scal_odom_get_blocks", "scal_odom_eval_blocks", "scal_odom_adapter_finish", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
@@ -480,6 +480,13 @@ class SCManager:
         s = np.zeros((max(0, q1 - q0), max(0, d1 - d0)), np.int32)
         _check(lib().scal_sc_distance_matrix(self.h, q0, q1, d0, d1, mode, _p(d, _f64p), _p(s, _i32p)))
         return d, s
+
+    def batch_loop_search(self, q0, q1, exclude_recent=30, k=3, mode=2):
+        """(idx, dist, shift) arrays [q1-q0][k]: the k best older keyframes of every query keyframe, exhaustive over the database"""
+        n = max(0, q1 - q0)
+        idx, dist, shift = np.zeros((n, k), np.int32), np.zeros((n, k)), np.zeros((n, k), np.int32)
+        _check(lib().scal_sc_batch_loop_search(self.h, q0, q1, exclude_recent, k, mode, _p(idx, _i32p), _p(dist, _f64p), _p(shift, _i32p)))
+        return idx, dist, shift
 
     def distance_matrix_device(self, q0, q1, d0, d1, mode, d_dist_ptr, d_shift_ptr):
         """Device outputs ((q1-q0)*(d1-d0) doubles / int32), enqueued on the context's stream; sync() before reading."""

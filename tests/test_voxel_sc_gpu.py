@@ -190,6 +190,62 @@ def test_sc_matrix_mfma(O, S):
     gm.close()
 
 
+def test_sc_batch_loop_search(O, S):
+    """Exhaustive loop mining over a stored session (scal_sc_batch_loop_search): per query keyframe the k best keyframes older than
+    q - exclude, against the oracle's distDirectSC over all 60 shifts (Scancontext.cpp:83-110,:113-147) on every eligible pair.
+    Ragged: 700 keyframes = one full 512-query tile + a partial one; exclusion window larger than the first queries' history;
+    an all-zero descriptor (distance 10000000, never a NaN winner); revisits (rolled copies) must come back first with their shift."""
+    rng = np.random.default_rng(29)
+    n = 700
+    descs = _random_descs(rng, n)
+    descs[40] = np.zeros((20, 60))
+    for q, j, sh in [(300, 100, 7), (650, 5, 59), (699, 600, 1), (530, 20, 33)]:
+        descs[q] = np.roll(descs[j], sh, axis=1)
+    gm = S.SCManager()
+    for d in descs:
+        gm.saveScancontextAndKeys(d)
+    K, EXCL = 4, 30
+    idx, dist, shift = gm.batch_loop_search(0, n, EXCL, K, 2)
+    assert idx.shape == (n, K)
+    assert np.all(idx[:EXCL + 1] == -1) and np.all(dist[:EXCL + 1] == 10000000)
+    assert np.all(idx[EXCL + 2, 2:] == -1) and np.all(idx[EXCL + 2, :2] >= 0)  # two eligible entries only
+    for q, j, sh in [(300, 100, 7), (650, 5, 59), (699, 600, 1), (530, 20, 33)]:
+        assert idx[q, 0] == j and dist[q, 0] <= 1e-12 and shift[q, 0] == sh
+    for q in [31, 33, 100, 300, 511, 512, 513, 650, 699]:
+        lim = q - EXCL
+        best = np.empty(lim)
+        arg = np.empty(lim, int)
+        for j in range(lim):
+            full = O.sc_distance_full(descs[q], descs[j])
+            full = np.where(np.isnan(full), 1e300, full)
+            arg[j] = int(np.argmin(full))
+            best[j] = full[arg[j]] if full[arg[j]] < 1e300 else 10000000.0
+        order = np.lexsort((np.arange(lim), best))[:K]
+        m = len(order)
+        assert np.all(np.abs(dist[q, :m] - best[order]) <= 1e-12), q
+        # the picks are the oracle's unless two candidates are closer than the matrix-core rounding
+        for r in range(m):
+            assert idx[q, r] == order[r] or abs(best[idx[q, r]] - best[order[r]]) <= 1e-12, (q, r)
+            assert shift[q, r] == arg[idx[q, r]]
+        assert np.all(idx[q, m:] == -1)
+    # a sub-range equals the same rows of the full answer; the matrix mode only changes the rounding
+    i2, d2, s2 = gm.batch_loop_search(500, 640, EXCL, K, 2)
+    assert np.array_equal(i2, idx[500:640]) and np.array_equal(d2, dist[500:640]) and np.array_equal(s2, shift[500:640])
+    i1, d1, s1 = gm.batch_loop_search(0, n, EXCL, K, 1)
+    assert np.abs(d1 - dist).max() <= 1e-12 and (i1 != idx).mean() < 0.01
+    D, Sh = gm.distance_matrix(0, n, 0, n, mode=2)
+    for q in range(n):
+        lim = max(0, q - EXCL)
+        order = np.lexsort((np.arange(lim), D[q, :lim]))[:K]
+        assert np.array_equal(idx[q, :len(order)], order) and np.array_equal(dist[q, :len(order)], D[q, order])
+    with pytest.raises(S.ScalError):
+        gm.batch_loop_search(0, n + 1, EXCL, K, 2)
+    with pytest.raises(S.ScalError):
+        gm.batch_loop_search(0, n, EXCL, 17, 2)
+    assert gm.batch_loop_search(5, 5, EXCL, K, 2)[0].shape == (0, K)
+    gm.close()
+
+
 def test_sc_matrix_mfma_real_scans(O, S, golden):
     """Modes 1-3 of the dense matrix on descriptors of the reference's real sample scans (two sessions, keyframes downsampled at
     0.4 m as the detector sees them, PGO :629-631), each also inserted rolled by a few sectors (a revisit with another heading):

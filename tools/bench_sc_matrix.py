@@ -176,6 +176,28 @@ def main():
     for x, y in f32_shift_pairs:
         full = O.sc_distance_full(descs[x], descs[y])
         f32_gap = max(f32_gap, abs(float(full[S3[x, y]]) - float(full[S2[x, y]])))
+    # batch loop search: the dense block in row tiles + top-3 per row on the device, only the records come back
+    K, EXCL = 3, 30
+    sc.batch_loop_search(0, n, EXCL, K, 2)
+    S.prof_reset()
+    S.prof_enable(True)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        bi, bd, bs = sc.batch_loop_search(0, n, EXCL, K, 2)
+    bls_dt = (time.perf_counter() - t1) / a.steps
+    S.prof_enable(False)
+    pr = S.prof_read_all()
+    topk_ms = pr["k_sc_row_topk"][0] / max(1, pr["k_sc_row_topk"][1])
+    bls_bad = 0
+    for q in range(n):
+        lim = max(0, q - EXCL)
+        row = D2[q, :lim]
+        order = np.lexsort((np.arange(lim), row))[:K]
+        want = np.full(K, -1)
+        want[:len(order)] = order
+        ok = np.array_equal(bi[q], want) and np.array_equal(bd[q][:len(order)], row[order]) and np.array_equal(bs[q][:len(order)], S2[q, order])
+        bls_bad += int(not ok)
+    n_pairs_bls = sum(max(0, min(n, t0 + 512) - 1 - EXCL) * (min(n, t0 + 512) - t0) for t0 in range(0, n, 512))
     probe = None
     if a.probe and os.path.exists(a.probe):
         try:
@@ -194,6 +216,8 @@ def main():
                            "achieved": FLOP_PER_PAIR * n * n / (f32_ms / f32_cnt * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                            "frac": FLOP_PER_PAIR * n * n / (f32_ms / f32_cnt * 1e-3) / 1e12 / 157.3, "max_abs_vs_mode2": f32_diff,
                            "shift_differs_from_mode2": f32_shift, "max_f64_gap_between_differing_shifts": f32_gap},
+        "batch_loop_search": {"queries": n, "k": K, "exclude_recent": EXCL, "ms": bls_dt * 1e3, "queries_per_s": n / bls_dt,
+                              "pairs_evaluated": n_pairs_bls, "k_sc_row_topk_avg_ms": topk_ms, "rows_differing_from_numpy_topk_of_the_matrix": bls_bad},
         "mode1_vector_alu": {"queries": ns, "ms": m1_ms / m1_cnt, "pairs_per_s": ns * n / (m1_ms / m1_cnt * 1e-3)},
         "cpu_baseline": {"value": a.cpu_pairs / cpu_dt, "unit": "pairs/s", "cores": 1, "kind": "port",
                          "sample": f"{a.cpu_pairs} random pairs through the oracle's 60-shift distDirectSC (incl. the ctypes call)"},
