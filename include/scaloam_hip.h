@@ -297,6 +297,11 @@ int scal_map_get_path_counters(scal_map_t* ctx, int* out4);
  * its first barrier: collect / step return SCAL_E_HIP ("LM solve abandoned"), the pose of that step is its prior, and the context
  * must keep working afterwards.  Exercises the bounded-wait path that would otherwise need a machine hogged by another process. */
 int scal_map_debug_set_lm_polls(scal_map_t* ctx, int polls);
+/* test hook: entries per 1 m cell of the one-launch neighbour-grid build of the queued steps (default: the number of filter voxels
+ * that can intersect a cell - 27 corner / 8 surf at the reference's 0.4 / 0.8 m; values above that are clamped).  A cell that
+ * receives more points stops the queued chain, and the step is redone with the general three-launch build: with 1 / 1 every
+ * queued step takes that route (path counter 3 counts them) and the poses must not change. */
+int scal_map_debug_set_grid_cap(scal_map_t* ctx, int cap_corner, int cap_surf);
 /* 1 (default): every enqueue first looks (without waiting) whether queued steps have finished or stopped; 0: a stopped chain is
  * only noticed by collect / finish, so that steps really get queued behind it (test switch for the replay path) */
 int scal_map_set_poll(scal_map_t* ctx, int enable);

@@ -61,7 +61,7 @@ struct MapCounters {
 
 // Persistent device-side state of the mapper.  The pose algebra of :143-153, the rolling-window decision of :313-508 and the
 // map sizes live here, so that a step can be queued behind the previous one without the host reading anything back.
-enum { MAP_ABORT_NONE = 0, MAP_ABORT_WINDOW = 1, MAP_ABORT_MERGE = 2 };
+enum { MAP_ABORT_NONE = 0, MAP_ABORT_WINDOW = 1, MAP_ABORT_MERGE = 2, MAP_ABORT_GRID = 3 };
 struct MapState {
     double q_wmap_wodom[4], t_wmap_wodom[3];  // :113-114
     double q_wodom[4], t_wodom[3];            // this step's /laser_odom_to_init pose (kept for transformUpdate)
@@ -149,6 +149,51 @@ __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* 
         const uint64_t b = __ballot(v);
         if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
+}
+
+// The cell grid in ONE launch for the speculative chain: every cell owns a fixed slice of `cap` entries of a (large, sparsely
+// touched) pool, so a point's place is known as soon as it has its rank in the cell - no allocation pass, no second walk over the
+// map.  `cap` = the number of filter voxels that can intersect a 1 m cell (27 at 0.4 m, 8 at 0.8 m): on this path the window did
+// not move, so every binned point is the only one of its voxel (the re-filter of the previous scan, :775-791).  A centroid rounded
+// across a cell face could still make a full cell overflow: that stops the chain (MAP_ABORT_GRID), the host clears the counters
+// and redoes the step with the three general launches below.
+__global__ void __launch_bounds__(256) k_grid_build(GridArgs a, int cap0, int cap1, MapState* S, MapCounters* C) {
+    if (S->abort) return;
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    int cls, first, stride;
+    grid_part(cls, first, stride);
+    const MapParams mp = S->mp;
+    const int n = S->n_map[cls];
+    const int cap = cls ? cap1 : cap0;
+    const MapCloud& m = a.m[cls];
+    bool over = false;
+    for (int i0 = first; i0 < n; i0 += stride) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < n;
+        bool v = false;
+        if (in && cube_valid(mp, m.cube[i])) {
+            v = true;
+            const float x = m.x[i], y = m.y[i], z = m.z[i];
+            const int c = grid_cell(mp, x, y, z);
+            const int r = atomicAdd(&a.cell[cls][c].x, 1);
+            a.rank[cls][i] = r;  // >= 0: this point's cell counter has to be cleared again
+            if (r < cap) {
+                a.g[cls].p[static_cast<size_t>(c) * cap + r] = make_float4(x, y, z, __int_as_float(i));
+                if (r == 0) a.cell[cls][c].y = c * cap;
+            } else {
+                over = true;
+            }
+        } else if (in) {
+            a.rank[cls][i] = -1;
+        }
+        const uint64_t b = __ballot(v);
+        if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
+    }
+    if (over) __hip_atomic_store(&S->abort, static_cast<int>(MAP_ABORT_GRID), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
 }
@@ -431,8 +476,13 @@ struct NNBuf {
 // so it wants every lane busy with a different point).
 __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, GridPts cg,
                                                    const int2* __restrict__ scell, GridPts sg, const LMState* __restrict__ st,
-                                                   const MapCounters* __restrict__ C, NNBuf nb) {
-    if (S->abort || !C->solve_on) return;
+                                                   MapCounters* C, NNBuf nb) {
+    if (S->abort) return;
+    // :555 - evaluated here (the map counts are complete once the grid launches are): the one-launch grid build has no later
+    // launch of its own that could do it; workgroup 0 publishes the decision for the fit, the solve and the host
+    const bool solve_on = C->n_valid[0] > 10 && C->n_valid[1] > 50;
+    if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = solve_on ? 1 : 0;
+    if (!solve_on) return;
     const MapParams mp = S->mp;
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
     const int n = min(nc + ns, nb.cap);
@@ -1204,7 +1254,9 @@ struct GridStore {
     DevBuf<int2> cell;
     DevBuf<int> rank;
     DevBuf<float4> g;
-    GridPts pts() { return GridPts{g.p}; }
+    DevBuf<float4> fixed;  // one-launch build: `fixed_cap` entries per cell
+    int fixed_cap = 0;
+    GridPts pts(bool fixed_pool = false) { return GridPts{fixed_pool ? fixed.p : g.p}; }
 };
 
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
@@ -1212,6 +1264,18 @@ SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
 
 using namespace scal;
 #include <deque>
+
+// filter voxels (leaf `leaf`, lattice = multiples of the leaf) that can intersect a 1 m cell, per axis
+int voxels_per_cell_axis(float leaf) {
+    const double inv = 1.0 / static_cast<double>(leaf);
+    int most = 1;
+    for (int c = 0; c < 1000; ++c) {  // 1e-4: the f32 leaf is off its decimal value by a few 1e-8, times c
+        const int lo = static_cast<int>(std::floor(c * inv + 1e-4)), hi = static_cast<int>(std::floor((c + 1) * inv - 1e-4));
+        most = std::max(most, hi - lo + 1);
+    }
+    return most;
+}
+
 
 // A step in flight.  Steps are queued speculatively ("fast": merge insert, window unchanged, nothing read back) behind each other;
 // a step that meets a case the fast chain does not cover stops the chain on the device (MapState::abort) and is redone by
@@ -1282,6 +1346,8 @@ struct scal_map {
     VoxelFilter vf, vf_side, vf_corner;  // main stream / prefetch (surf) / prefetch (corner, behind stage A): no shared scratch
     MapStore map[2];  // corner, surf
     GridStore grid[2];
+    bool grid_fixed = false;        // both fixed pools exist: speculative steps build the grid in one launch
+    int grid_cap_now[2] = {0, 0};   // <= fixed_cap (scal_map_debug_set_grid_cap lowers it to force the overflow path in tests)
     RadixSort sorter;
     DevBuf<unsigned long long> keys;
     DevBuf<int> vals, blockcnt;
@@ -1352,6 +1418,24 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         }
         A(c->grid[k].cell.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
         A(c->grid[k].g.alloc(mc));
+    }
+    if (rc == SCAL_OK) {  // fixed-slice pools of the one-launch grid build: 16 B x voxels per cell x 9.4 M cells, sparsely touched
+        int cap[2];
+        for (int k = 0; k < 2; ++k) {
+            const int a = voxels_per_cell_axis(k == 0 ? c->cfg.line_res : c->cfg.plane_res);
+            cap[k] = a * a * a;
+        }
+        if (cap[0] + cap[1] <= 48) {  // 5.3 GB at the reference's 0.4 / 0.8 m; finer filters keep the three-launch build
+            c->grid_fixed = true;
+            for (int k = 0; k < 2 && c->grid_fixed; ++k) {
+                if (c->grid[k].fixed.alloc(static_cast<size_t>(GCELLS) * cap[k]) != SCAL_OK) c->grid_fixed = false;  // not fatal: no memory, no shortcut
+                c->grid[k].fixed_cap = c->grid_cap_now[k] = cap[k];
+            }
+            if (!c->grid_fixed) {
+                (void)hipGetLastError();
+                for (int k = 0; k < 2; ++k) c->grid[k].fixed.release();
+            }
+        }
     }
     A(c->sorter.init(c->map_cap));
     A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
@@ -1449,12 +1533,12 @@ int enqueue_stack_filters(scal_map* c, VoxelFilter& vfc, VoxelFilter& vfs, hipSt
     return enqueue_surf_filter(c, vfs, s, n_surf_bound, st, surf_box_done);
 }
 
-GridArgs grid_args(scal_map* c, int par) {
+GridArgs grid_args(scal_map* c, int par, bool fixed_pool = false) {
     GridArgs ga;
     for (int k = 0; k < 2; ++k) {
         GridStore& G = c->grid[k];
         ga.m[k] = c->map[k].cloud(par);
-        ga.cell[k] = G.cell.p, ga.rank[k] = G.rank.p, ga.g[k] = G.pts();
+        ga.cell[k] = G.cell.p, ga.rank[k] = G.rank.p, ga.g[k] = G.pts(fixed_pool);
     }
     return ga;
 }
@@ -1588,11 +1672,16 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
     SCAL_LAUNCH_PROF("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
                      c->slot_cap);
-    // cell grids over the valid cubes (both classes per launch)
-    const GridArgs ga = grid_args(c, e.par);
-    SCAL_LAUNCH_PROF("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-    SCAL_LAUNCH_PROF("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-    SCAL_LAUNCH_PROF("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
+    // cell grids over the valid cubes (both classes per launch): one launch on the speculative chain, three in general
+    const bool fixed_pool = e.fast && c->grid_fixed && !prepare_only;
+    const GridArgs ga = grid_args(c, e.par, fixed_pool);
+    if (fixed_pool) {
+        SCAL_LAUNCH_PROF("k_grid_build", k_grid_build, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, c->grid_cap_now[0], c->grid_cap_now[1], S, C);
+    } else {
+        SCAL_LAUNCH_PROF("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+        SCAL_LAUNCH_PROF("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+        SCAL_LAUNCH_PROF("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
+    }
     if (prepare_only) {  // Ceres-adapter mode: the caller drives association and solve (scal_map_associate / scal_map_eval_blocks)
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
@@ -1605,7 +1694,7 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     for (int outer = 0; outer < 2; ++outer) {
         {
             SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
-                             c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), st, C, c->nnbuf());
+                             c->grid[0].cell.p, c->grid[0].pts(fixed_pool), c->grid[1].cell.p, c->grid[1].pts(fixed_pool), st, C, c->nnbuf());
         }
         SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
         // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
@@ -1625,7 +1714,6 @@ int report_device_error(scal_map* c, int err) {
 int general_insert(scal_map* c, MapStep& e);
 // General path, synchronous: the window may move, the insertion falls back to the full sort.  All earlier steps have finished.
 int run_general(scal_map* c, MapStep& e) {
-    hipStream_t s = c->stream;
     e.fast = false;
     e.par = c->cur;
     c->n_general++;
@@ -1717,6 +1805,8 @@ int recover(scal_map* c) {
     c->cur = e.par;
     if (at_pose) {
         c->n_recover_pose++;
+        if (c->res.p[e.slot].S1.abort == MAP_ABORT_GRID)  // a full cell: the one-launch build left its counters behind
+            SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
         SCAL_TRY(run_general(c, e));
     } else {
         c->n_recover_insert++;  // the pose of this step stands; only its insertion is redone, with the full sort
@@ -2306,6 +2396,18 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
 }
 
 extern "C" void* scal_map_stream(scal_map_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+extern "C" int scal_map_debug_set_grid_cap(scal_map_t* c, int cap_corner, int cap_surf) {
+    if (!c || cap_corner < 1 || cap_surf < 1) {
+        set_error("scal_map_debug_set_grid_cap: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (!c->grid_fixed) return SCAL_OK;
+    SCAL_TRY(map_finish(c));
+    c->grid_cap_now[0] = std::min(cap_corner, c->grid[0].fixed_cap);
+    c->grid_cap_now[1] = std::min(cap_surf, c->grid[1].fixed_cap);
+    return SCAL_OK;
+}
 
 extern "C" int scal_map_debug_set_lm_polls(scal_map_t* c, int polls) {
     if (!c || polls < 0) return SCAL_E_ARG;

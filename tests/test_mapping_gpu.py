@@ -121,6 +121,43 @@ def test_merge_insert_equals_full_sort(S, stage_ab):
     a.close(), b.close()
 
 
+def test_full_grid_cell_falls_back_to_the_general_build(S, hdl64_stream):
+    """Queued steps bin the map into fixed slices per 1 m cell in one launch (27 corner / 8 surf entries: one per filter voxel that
+    can intersect the cell).  A cell that would overflow stops the chain and the step is redone with the general three-launch
+    build.  Forced here by lowering the slices to 1 entry: every queued step overflows, is redone, and nothing may change -
+    poses, maps, composition - against a mapper that never uses the shortcut."""
+    n = 6
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(3)]
+    od = S.LaserOdometry(max_points=200000)
+    mk = lambda: S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=3000000)
+    a, g = mk(), mk()
+    a.debug_set_grid_cap(1, 1)
+    g.set_merge_insert(False)
+    for k in range(n):
+        r = regs[k % len(regs)]
+        r.laserCloudHandler(hdl64_stream(k))
+        _, _, qw, tw, _ = od.step_features(r)
+        qa, ta, sa = a.process_features(r, qw, tw)
+        qg, tg, sg = g.process_features(r, qw, tw)
+        assert np.array_equal(qa, qg) and np.array_equal(ta, tg), k
+        assert sa.n_corner_map == sg.n_corner_map and sa.n_surf_map == sg.n_surf_map
+    ca = a.path_counters()
+    assert ca[2] == n - 1, ca    # every queued step met a full cell and was redone from its start
+    a.debug_set_grid_cap(27, 8)  # back to the real slices: the shortcut holds on this data
+    for k in range(n, n + 4):
+        r = regs[k % len(regs)]
+        r.laserCloudHandler(hdl64_stream(k))
+        _, _, qw, tw, _ = od.step_features(r)
+        qa, ta, sa = a.process_features(r, qw, tw)
+        qg, tg, sg = g.process_features(r, qw, tw)
+        assert np.array_equal(qa, qg) and np.array_equal(ta, tg), k
+    assert a.path_counters()[2] == n - 1, a.path_counters()
+    for which in (0, 1):
+        ma, mg = _sorted_rows(a.export(which)), _sorted_rows(g.export(which))
+        assert ma.shape == mg.shape and np.array_equal(ma, mg), which
+    a.close(), g.close()
+
+
 @pytest.mark.parametrize("plane_res", [0.8, 0.25])
 def test_queued_steps_equal_general_path(S, hdl64_stream, plane_res):
     """Steps queued behind each other (pose composition, window decision and map sizes stay on the device; nothing is read back
