@@ -67,6 +67,27 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     }
     return v;
 }
+// The same minimum through the DPP network (row shifts + the two row broadcasts of gfx9) instead of six LDS-crossbar permutes:
+// ~30 VALU operations and no ds_bpermute latency chain.  The result is uniform (read from lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_min_step_u64(unsigned long long v) {
+    const int lo = static_cast<int>(v), hi = static_cast<int>(v >> 32);
+    const unsigned tl = static_cast<unsigned>(__builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false));
+    const unsigned th = static_cast<unsigned>(__builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false));
+    const unsigned long long t = (static_cast<unsigned long long>(th) << 32) | tl;
+    return t < v ? t : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long long v) {
+    v = dpp_min_step_u64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step_u64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step_u64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step_u64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row minimum
+    v = dpp_min_step_u64<0x142, 0xa>(v);  // row_bcast:15 -> rows 1 and 3 take in rows 0 and 2
+    v = dpp_min_step_u64<0x143, 0xc>(v);  // row_bcast:31 -> rows 2, 3 take in lane 31: lane 63 holds the wave minimum
+    const unsigned lo = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+    const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), 63));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int l = lane_id();

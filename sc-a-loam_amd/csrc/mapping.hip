@@ -255,82 +255,70 @@ __global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* 
 
 // ---------------------------------------------------------------------------------------------- association
 
-// Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE:
-// lanes 0..26 each own a neighbour cell (one round trip for the 27 (count, start) pairs); the candidates of all cells form
-// one virtual list that the 64 lanes read side by side (lane j finds the cell of candidate j from the cells' running
-// counts, 27 uniform compares), so a chunk of 256 candidates costs one more round trip; their 64-bit (f32 distance bits,
-// map index) keys stay in registers and five wave-argmin rounds per chunk pick the result.
+// Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE.
+// Lanes 2c and 2c+1 own neighbour cell c (one round trip for the 27 (count, start) pairs) and walk its points alternately, two
+// loads in flight per lane; every lane keeps the five best of ITS candidates as an ascending register list of 64-bit
+// (f32 distance bits, map index) keys.  The wave then takes the minimum of the list heads five times (DPP reduction), the owning
+// lane popping its head each time.  The instruction count follows the fullest cell, not the number of candidates.
 // Every lane returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
-constexpr int KNN_CHUNK = 256;
+__device__ __forceinline__ void knn5_insert(unsigned long long (&k)[5], int (&p)[5], unsigned long long key, int pos) {
+    // branch-free, statically indexed insertion into the ascending list (keys are distinct: they carry the map index)
+    const bool c0 = key < k[0], c1 = key < k[1], c2 = key < k[2], c3 = key < k[3], c4 = key < k[4];
+    k[4] = c3 ? k[3] : (c4 ? key : k[4]), p[4] = c3 ? p[3] : (c4 ? pos : p[4]);
+    k[3] = c2 ? k[2] : (c3 ? key : k[3]), p[3] = c2 ? p[2] : (c3 ? pos : p[3]);
+    k[2] = c1 ? k[1] : (c2 ? key : k[2]), p[2] = c1 ? p[1] : (c2 ? pos : p[2]);
+    k[1] = c0 ? k[0] : (c1 ? key : k[1]), p[1] = c0 ? p[0] : (c1 ? pos : p[1]);
+    k[0] = c0 ? key : k[0], p[0] = c0 ? pos : p[0];
+}
+__device__ __forceinline__ unsigned long long knn_key(const float4 pt, float qx, float qy, float qz) {
+    // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
+    const float dx = qx - pt.x, dy = qy - pt.y, dz = qz - pt.z;
+    float dist = dx * dx;
+    dist += dy * dy;
+    dist += dz * dz;
+    return (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(__float_as_int(pt.w));
+}
 __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int2* __restrict__ cell, const GridPts& g,
                                           float qx, float qy, float qz, unsigned long long (&bk)[5], int (&bp)[5]) {
     const int lane = lane_id();
 #pragma unroll
     for (int k = 0; k < 5; ++k) bk[k] = ~0ull, bp[k] = -1;
     const int cx = static_cast<int>(floorf(qx)) - mp.ox, cy = static_cast<int>(floorf(qy)) - mp.oy, cz = static_cast<int>(floorf(qz)) - mp.oz;
-    int my_cnt = 0, my_start = 0;
     // a query further than one cell outside the grid has no map point within 1 m
     const bool inside = !(cx < -1 || cx > GX || cy < -1 || cy > GY || cz < -1 || cz > GZ);
-    if (inside && lane < 27) {
-        const int xx = cx + (lane % 3) - 1, yy = cy + ((lane / 3) % 3) - 1, zz = cz + (lane / 9) - 1;
+    const int own = lane >> 1, half = lane & 1;
+    int cnt = 0, start = 0;
+    if (inside && own < 27) {
+        const int xx = cx + (own % 3) - 1, yy = cy + ((own / 3) % 3) - 1, zz = cz + (own / 9) - 1;
         if (xx >= 0 && xx < GX && yy >= 0 && yy < GY && zz >= 0 && zz < GZ) {
             const int2 h = cell[xx + GX * (yy + GY * zz)];
-            my_cnt = h.x, my_start = h.y;
+            cnt = h.x, start = h.y;
         }
     }
-    const int incl = wave_inclusive_scan(my_cnt);
-    const int rel = my_start - (incl - my_cnt);  // grid position of candidate j of my cell = rel + j
-    const int T = __shfl(incl, 63, 64);
-    for (int base = 0; base < T; base += KNN_CHUNK) {
-        unsigned long long k0[4];
-        int p0[4];
+    unsigned long long mk[5];
+    int mpos[5];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = base + lane + 64 * u;
-            int c = 0;  // cell of candidate j: the first one whose running count exceeds j
+    for (int k = 0; k < 5; ++k) mk[k] = ~0ull, mpos[k] = -1;
+    // my candidates: start + half, start + half + 2, ... (< start + cnt), two per trip
+    for (int t = start + half, end = start + cnt; __ballot(t < end) != 0; t += 4) {
+        const bool a = t < end, b = t + 2 < end;
+        float4 pa, pb;
+        if (a) pa = g.p[t];
+        if (b) pb = g.p[t + 2];
+        if (a) knn5_insert(mk, mpos, knn_key(pa, qx, qy, qz), t);
+        if (b) knn5_insert(mk, mpos, knn_key(pb, qx, qy, qz), t + 2);
+    }
 #pragma unroll
-            for (int cc = 0; cc < 26; ++cc) c += __builtin_amdgcn_readlane(incl, cc) <= j ? 1 : 0;
-            const int t = __shfl(rel, c, 64) + j;
-            k0[u] = ~0ull, p0[u] = -1;
-            if (j < T) {
-                // FLANN L2_Simple<float>: ((0 + dx^2) + dy^2) + dz^2
-                const float4 pt = g.p[t];
-                const float dx = qx - pt.x, dy = qy - pt.y, dz = qz - pt.z;
-                float dist = dx * dx;
-                dist += dy * dy;
-                dist += dz * dz;
-                k0[u] = (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(__float_as_int(pt.w));
-                p0[u] = t;
-            }
-        }
-        for (int round = 0; round < 5; ++round) {
-            unsigned long long mine = k0[0];
-            int mu = 0;
-#pragma unroll
-            for (int u = 1; u < 4; ++u)
-                if (k0[u] < mine) mine = k0[u], mu = u;
-            const unsigned long long best = wave_min_u64(mine);
-            if (best == ~0ull) break;
-            const uint64_t own = __ballot(mine == best);
-            const int owner = __ffsll(static_cast<long long>(own)) - 1;
-            int pm = p0[0];  // compile-time indices: the candidate list stays in registers
-#pragma unroll
-            for (int u = 1; u < 4; ++u)
-                if (mu == u) pm = p0[u];
-            const int pos = __shfl(pm, owner, 64);
-            if (lane == owner) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u == mu) k0[u] = ~0ull;
-            }
-            if (!(best < bk[4])) break;  // chunk keys come out ascending: nothing smaller is left in this chunk
-            // insert (best, pos) into the running ascending list, branch-free and statically indexed
-            const bool c0 = best < bk[0], c1 = best < bk[1], c2 = best < bk[2], c3 = best < bk[3];
-            bk[4] = c3 ? bk[3] : best, bp[4] = c3 ? bp[3] : pos;
-            bk[3] = c2 ? bk[2] : (c3 ? best : bk[3]), bp[3] = c2 ? bp[2] : (c3 ? pos : bp[3]);
-            bk[2] = c1 ? bk[1] : (c2 ? best : bk[2]), bp[2] = c1 ? bp[1] : (c2 ? pos : bp[2]);
-            bk[1] = c0 ? bk[0] : (c1 ? best : bk[1]), bp[1] = c0 ? bp[0] : (c1 ? pos : bp[1]);
-            bk[0] = c0 ? best : bk[0], bp[0] = c0 ? pos : bp[0];
+    for (int r = 0; r < 5; ++r) {
+        const unsigned long long best = wave_min_u64_dpp(mk[0]);
+        if (best == ~0ull) break;
+        const uint64_t ownb = __ballot(mk[0] == best);
+        const int owner = __ffsll(static_cast<long long>(ownb)) - 1;
+        bk[r] = best;
+        bp[r] = __builtin_amdgcn_readlane(mpos[0], owner);
+        if (lane == owner) {
+            mk[0] = mk[1], mk[1] = mk[2], mk[2] = mk[3], mk[3] = mk[4], mk[4] = ~0ull;
+            mpos[0] = mpos[1], mpos[1] = mpos[2], mpos[2] = mpos[3], mpos[3] = mpos[4], mpos[4] = -1;
         }
     }
 }
@@ -499,11 +487,8 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const Map
         associate_to_map(x7, ox, oy, oz, sel);
         unsigned long long bk[5];
         int bp[5];
-        const GridPts& g = is_edge ? cg : sg;
-        if (is_edge)
-            knn5_wave(mp, ccell, cg, sel[0], sel[1], sel[2], bk, bp);
-        else
-            knn5_wave(mp, scell, sg, sel[0], sel[1], sel[2], bk, bp);
+        const GridPts g = is_edge ? cg : sg;
+        knn5_wave(mp, is_edge ? ccell : scell, g, sel[0], sel[1], sel[2], bk, bp);
         // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
         int mine = bp[0];
 #pragma unroll
