@@ -616,7 +616,7 @@ def roofline_of(prof, K, c, pipelined=True):
            "bytes_formula": "(72 B x edge blocks + 56 B x plane blocks) x (1 + LM iterations), SURVEY.md section 8d",
            "stage_b": lb,
            "share_of_step_ms": prof["k_lm_solve_map"][0] / K,
-           "note": "latency-bound by design: <= 5 dependent evaluation rounds of ~9 us on <= 64 workgroups (DESIGN.md section 6)"}
+           "note": "latency-bound by design: <= 5 dependent evaluation rounds of ~9 us on <= 48 workgroups (DESIGN.md section 6)"}
     return out
 
 

@@ -543,7 +543,7 @@ struct LMNoHook {
 // read it).  Partials are double buffered by round parity: a workgroup can be at most one round ahead of the slowest one.
 // Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
 // sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
-constexpr int LM_GRID = 64;
+constexpr int LM_GRID = 48;
 constexpr int LM_THREADS = 256;   // (512-thread workgroups, i.e. half the arrivals and partial sums per round, measured slower: 64 vs 58 us)
 constexpr int LM_WAVES = LM_THREADS / 64;
 constexpr int LM_LDS_BYTES = LM_WAVES * LM_NACC * 65 * 8;
