@@ -76,9 +76,11 @@ int stage_lane(int stage) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
     if (g_stream_mode == 0) return stage == STAGE_MAP_PREFETCH ? 2 : 0;
     // Four streams, not five: an MI355X advances four dependent kernel chains at full rate, and with more streams than that they
-    // all slow down together (tools/stream_probe.hip: 0.62 M kernels/s with 4 streams, 0.25-0.35 M with 6-8).  So the two side
-    // jobs that only depend on stage A - stage C's prefetch and ScanContext - share one stream.
-    return stage == STAGE_ODOM ? 3 : stage == STAGE_MAP ? 4 : (stage == STAGE_SC || stage == STAGE_MAP_PREFETCH) ? 1 : 0;
+    // all slow down together (tools/stream_probe.hip: 0.62 M kernels/s with 4 streams, 0.25-0.35 M with 6-8).  The side jobs that
+    // only depend on stage A are spread so that the four chains come out about equally long (tools/gpu_chains.sh): stage C's surf
+    // filter and ScanContext's keyframe filter share the side stream, its corner filter rides behind stage A, and ScanContext's
+    // descriptor + search (short) ride behind stage B.
+    return (stage == STAGE_ODOM || stage == STAGE_SC) ? 3 : stage == STAGE_MAP ? 4 : (stage == STAGE_SC_FILTER || stage == STAGE_MAP_PREFETCH) ? 1 : 0;
 }
 
 void release_stream(int device, int lane) {

@@ -38,7 +38,7 @@ int select_device(int device);
 // scans overlap the way the reference's four ROS nodes do; every hand-over between contexts is ordered by events in both
 // directions (features_wait_done / features_note_reader).  Lane 5 is free for a context that must not queue behind another one
 // of its kind (scal_sc_config::side_stream = 5: the sharded database next to the descriptor builder, bench.py --gpus N).
-enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4, STAGE_MAP_PREFETCH = 2 };
+enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4, STAGE_MAP_PREFETCH = 2, STAGE_SC_FILTER = 5 };
 int stage_lane(int stage);
 int acquire_stream(int device, hipStream_t* out, int lane = 0);
 void release_stream(int device, int lane = 0);

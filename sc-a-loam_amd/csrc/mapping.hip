@@ -1328,7 +1328,7 @@ struct scal_map {
     SoAStore& surf_in(int st) { return surf_in2[st]; }
     SoAStore& corner_stack(int st) { return corner_stack2[st]; }
     SoAStore& surf_stack(int st) { return surf_stack2[st]; }
-    VoxelFilter vf, vf_side, vf_corner;  // main stream / prefetch (surf, behind stage A) / prefetch (corner, side stream): no shared scratch
+    VoxelFilter vf, vf_side, vf_corner;  // main stream / prefetch (surf, side stream) / prefetch (corner, behind stage A): no shared scratch
     MapStore map[2];  // corner, surf
     GridStore grid[2];
     bool grid_fixed = false;        // both fixed pools exist: speculative steps build the grid in one launch
@@ -1643,8 +1643,8 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     MapState* S = c->d_S.p;
     if (e.feat) {
         if (e.prefetched) {
-            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled: the corner cloud on the side stream ...
-            if (c->pre_a_used[st_]) SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre_a[st_], 0));  // ... the surf cloud behind stage A
+            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled: the surf cloud on the side stream ...
+            if (c->pre_a_used[st_]) SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre_a[st_], 0));  // ... the corner cloud behind stage A
         } else {
             FeatDeviceView v = features_view(e.feat);
             SCAL_TRY(features_wait_done(e.feat, s));
@@ -2040,10 +2040,9 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
         SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre_a[nset], hipEventDisableTiming));
         SCAL_HIP(hipEventCreateWithFlags(&c->ev_gather[nset], hipEventDisableTiming));
     }
-    // The gather (it also stores per-block bounding boxes of the surf cloud for the filter) and the surf filter ride on the features
-    // context's own stream, right behind stage A; the small corner filter runs on the side stream, which it shares with ScanContext.
-    // (More than four busy streams slow every stream down on this GPU; with the filters this way round the four chains are about
-    // equally long - the other way round the side stream was the longest, 3.3k against 3.5k scans/s.)
+    // The gather (it also stores per-block bounding boxes of the surf cloud for the filter) and the small corner filter ride on the
+    // features context's own stream, right behind stage A; the surf filter runs on the side stream, which it shares with
+    // ScanContext's keyframe filter.  (More than four busy streams slow every stream down on this GPU; see stage_lane().)
     hipStream_t sa = v.stream;
     const int nbc = std::max(1, div_up(ls_cap, 256));
     c->pre_a_used[nset] = true;
@@ -2052,10 +2051,10 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
                      c->surf_parts[nset].p);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(hipEventRecord(c->ev_gather[nset], sa));
-    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, sa, cap, nset, true));
+    SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, sa, ls_cap, nset));
     SCAL_HIP(hipEventRecord(c->ev_pre_a[nset], sa));
     SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_gather[nset], 0));
-    SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, c->side, ls_cap, nset));
+    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, true));
     SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
     c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
     c->n_pf++;

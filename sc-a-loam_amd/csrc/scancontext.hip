@@ -642,6 +642,13 @@ using namespace scal;
 struct scal_sc {
     scal_sc_config cfg;
     hipStream_t stream = nullptr;
+    // keyframe filter of the *_features entry points: on its own lane in the stage-pipelined mode (the filter is three quarters of a
+    // keyframe's device time, descriptor + search are short), on `stream` otherwise.  One set of filter outputs: ev_ds = filter
+    // done (the main stream waits for it), ev_tail = descriptor built from them (the next filter waits for it).
+    hipStream_t fstream = nullptr;
+    int flane = -1;
+    hipEvent_t ev_ds = nullptr, ev_tail = nullptr;
+    bool tail_recorded = false;
     std::mutex mu;  // insert and detect come from two threads in the reference with no common lock
     int cap = 0;
     int n_global = 0;  // keyframes inserted (global count)
@@ -727,6 +734,13 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
         set_error("hipStreamCreate failed");
         rc = SCAL_E_HIP;
     }
+    if (rc == SCAL_OK && c->cfg.side_stream <= 0 && stage_lane(STAGE_SC_FILTER) != c->lane) {
+        if (acquire_stream(c->cfg.device, &c->fstream, c->flane = stage_lane(STAGE_SC_FILTER)) != SCAL_OK ||
+            hipEventCreateWithFlags(&c->ev_ds, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess) {
+            set_error("hipStreamCreate failed");
+            rc = SCAL_E_HIP;
+        }
+    }
     // initialised on the context's own stream (the legacy null stream is not ordered against it)
     if (rc == SCAL_OK && (hipMemsetAsync(c->gcell.p, 0, sizeof(unsigned) * DESC, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
         rc = SCAL_E_HIP;
@@ -741,10 +755,16 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
 extern "C" void scal_sc_destroy(scal_sc_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->fstream) {
+        (void)hipStreamSynchronize(c->fstream);
+        release_stream(c->cfg.device, c->flane);
+    }
     if (c->stream) {
         (void)hipStreamSynchronize(c->stream);
         release_stream(c->cfg.device, c->lane);
     }
+    if (c->ev_ds) (void)hipEventDestroy(c->ev_ds);
+    if (c->ev_tail) (void)hipEventDestroy(c->ev_tail);
     if (c->ev) (void)hipEventDestroy(c->ev);
     for (int k = 0; k < scal_sc::DET_DEPTH; ++k)
         if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
@@ -872,14 +892,29 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
         SCAL_TRY(c->d_nds.alloc(2));
         c->vf_cap = v.cap;
     }
-    SCAL_TRY(features_wait_done(feat, c->stream));  // side stream: start after stage A of this scan
+    hipStream_t fs = c->fstream ? c->fstream : c->stream;
+    SCAL_TRY(features_wait_done(feat, fs));  // start after stage A of this scan
+    if (fs != c->stream && c->tail_recorded) SCAL_HIP(hipStreamWaitEvent(fs, c->ev_tail, 0));  // the previous descriptor has been built from the buffers
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
     // the bounding box comes with the features context (per-block parts from k_curv): no reset / bounding-box launches here
-    SCAL_TRY(c->vf.run(c->stream, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p,
+    SCAL_TRY(c->vf.run(fs, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p,
                        nullptr, v.box_parts, v.n_box_parts));
-    if (v.stream != c->stream) SCAL_TRY(features_note_reader(feat, c->stream));  // the filter was the last reader of feat's buffers
+    if (v.stream != fs) SCAL_TRY(features_note_reader(feat, fs));  // the filter was the last reader of feat's buffers
+    if (fs != c->stream) {
+        SCAL_HIP(hipEventRecord(c->ev_ds, fs));
+        SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev_ds, 0));
+    }
     *d_n = c->d_nds.p;
     *n_cap = v.cap;
+    return SCAL_OK;
+}
+
+// the descriptor has been built from the filter's output buffers: the next filter may overwrite them
+static int ds_consumed(scal_sc* c) {
+    if (c->fstream && c->fstream != c->stream) {
+        SCAL_HIP(hipEventRecord(c->ev_tail, c->stream));
+        c->tail_recorded = true;
+    }
     return SCAL_OK;
 }
 
@@ -893,7 +928,8 @@ extern "C" int scal_sc_insert_features(scal_sc_t* c, scal_features_t* feat) {
     const int* d_n;
     int cap;
     SCAL_TRY(ds_features(c, feat, &d_n, &cap));
-    return make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, true);
+    SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, true));
+    return ds_consumed(c);
 }
 
 static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bool wait) {
@@ -907,6 +943,7 @@ static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bo
     int cap;
     SCAL_TRY(ds_features(c, feat, &d_n, &cap));
     SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, false));
+    SCAL_TRY(ds_consumed(c));
     SCAL_HIP(hipMemcpyAsync(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
     if (wait) {
         SCAL_HIP(hipStreamSynchronize(c->stream));
