@@ -43,7 +43,9 @@ int scal_device_count(void);
 const char* scal_version(void);
 /* 0 (default): the stages of a scan share one in-order stream per device (plus the optional side streams).  1: every stage
  * context created afterwards gets its own stream, so that consecutive scans overlap the way the reference's four ROS nodes do
- * (A of scan k+1 during C of scan k ...); hand-overs between contexts are ordered by events.  Use two features contexts
+ * (A of scan k+1 during C of scan k ...); hand-overs between contexts are ordered by events.  Four streams carry the work (A + stage
+ * C's gather and corner filter; B + ScanContext's descriptor and search; C; one side stream for stage C's surf filter and
+ * ScanContext's keyframe filter), split so that the four chains are about equally long.  Use two or more features contexts
  * alternately in that mode: a context's outputs are rewritten by its next run, which waits for all their readers. */
 int scal_set_stream_mode(int mode);
 /* Optional per-kernel timing (HIP events on the launching stream), used by bench.py's roofline leg.
@@ -71,7 +73,8 @@ typedef struct scal_map scal_map_t;
 typedef struct scal_odom scal_odom_t;
 void* scal_features_stream(scal_features_t* ctx);
 void* scal_voxel_stream(scal_voxel_t* ctx);
-void* scal_sc_stream(scal_sc_t* ctx);
+void* scal_sc_stream(scal_sc_t* ctx); /* the stream of descriptors, keys, database and searches (in stream mode 1 the keyframe filter of
+                                       * the *_features entry points runs on a second, internal stream that this one waits for) */
 void* scal_map_stream(scal_map_t* ctx);
 void* scal_odom_stream(scal_odom_t* ctx);
 
