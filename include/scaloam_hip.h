@@ -273,7 +273,9 @@ int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double*
                            double* q_w_curr, double* t_w_curr, scal_map_stats* stats);
 /* Optional: start the pose-independent part of the next scal_map_step_features(ctx, feat, ...) - input gather and the stack
  * downsample (:543-551) - on the device's side stream, so that it overlaps with stage B.  Returns immediately.  Up to three
- * prefetches may be queued ahead of their steps (rotating input sets); steps consume them in order. */
+ * prefetches may be queued ahead of their steps (rotating input sets); steps consume them in order.  `feat` must not be run again
+ * before its step has been enqueued: the step would mix the prefetched inputs of one scan with the full-resolution cloud of the
+ * next; the step entry points check the features context's run counter and return SCAL_E_STATE in that case. */
 int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
 /* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns the oldest uncollected pose as soon as it
  * is on the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it.  Up to four steps may

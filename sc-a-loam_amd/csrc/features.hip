@@ -683,6 +683,7 @@ struct scal_features {
     bool reader_pending[MAX_READERS] = {};
     hipEvent_t done_ev = nullptr;    // end of the most recent run, recorded on demand
     bool done_recorded = false;
+    unsigned generation = 0;  // runs so far (FeatDeviceView::generation)
     bool cross_stream_consumers = false;
     std::mutex ev_mu;  // consumers may register from different host threads  // seen once: record done_ev right behind every run, before later main-stream work
     int cap = 0, nb_cap = 0;
@@ -727,6 +728,10 @@ FeatDeviceView features_view(scal_features* c) {
     v.stream = c->stream;
     v.device = c->cfg.device;
     v.n_scans = c->cfg.n_scans;
+    {
+        std::lock_guard<std::mutex> lk(c->ev_mu);
+        v.generation = c->generation;
+    }
     return v;
 }
 int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
@@ -867,6 +872,7 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
             c->reader_pending[i] = false;
         }
     c->done_recorded = false;
+    c->generation++;
     ev_lk.unlock();
     SCAL_LAUNCH_PROF("k_pre", k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
     SCAL_LAUNCH_PROF("k_classify", k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);

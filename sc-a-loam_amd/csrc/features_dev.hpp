@@ -29,6 +29,8 @@ struct FeatDeviceView {
     hipStream_t stream;
     int device;
     int n_scans;
+    unsigned generation;                 // runs of the features context so far: a consumer that took its inputs from run g (a prefetch)
+                                         // and comes back later checks that the context has not been run again in between
 };
 
 FeatDeviceView features_view(scal_features* c);

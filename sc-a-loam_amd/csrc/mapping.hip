@@ -1291,6 +1291,7 @@ struct scal_map {
     struct Prefetch {
         scal_features_t* feat;
         int set;
+        unsigned generation;  // run of `feat` the inputs were taken from
     };
     std::mutex pf_mu;  // prefetches may come from a second host thread
     Prefetch pf[MAX_PF];
@@ -2056,7 +2057,7 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_gather[nset], 0));
     SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, true));
     SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
-    c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset;
+    c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset, c->pf[c->n_pf].generation = v.generation;
     c->n_pf++;
     return SCAL_OK;
 }
@@ -2080,6 +2081,13 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
     {
         std::lock_guard<std::mutex> lk(c->pf_mu);
         if (c->n_pf > 0 && c->pf[0].feat == feat) {  // the oldest queued prefetch belongs to this step: take its set
+            if (c->pf[0].generation != v.generation) {
+                // the prefetched inputs are of an EARLIER scan than the one now in `feat` (its full-resolution cloud, read by the
+                // registration at the end of the step, has been overwritten): refuse instead of mixing two scans
+                c->n_pf = 0;
+                set_error("scal_map_enqueue_features: the features context was run again between scal_map_prefetch_features and this call");
+                return SCAL_E_STATE;
+            }
             e.prefetched = true;
             e.set = c->pf[0].set;
             for (int i = 1; i < c->n_pf; ++i) c->pf[i - 1] = c->pf[i];

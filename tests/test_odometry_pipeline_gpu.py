@@ -374,6 +374,17 @@ def test_async_entry_points_reject_misuse(S, hdl64_stream):
     assert e.value.code == S.E_STATE
     q2, t2, ms2 = mp.process_features(reg, qw, tw)   # consumes the oldest prefetch
     assert ms2.insert_path in (0, 1)
+    mp.finish()
+    # a features context that is run again between a prefetch and its step: the prefetched inputs belong to the previous scan,
+    # the step is refused (generation check) and the next step works again
+    reg.laserCloudHandler(hdl64_stream(1))
+    mp.prefetch_features(reg)
+    reg.laserCloudHandler(hdl64_stream(2))
+    with pytest.raises(S.ScalError) as e:
+        mp.enqueue_features(reg, qw, tw)
+    assert e.value.code == S.E_STATE and "run again" in str(e.value)
+    q3, t3, ms3 = mp.process_features(reg, qw, tw)
+    assert ms3.insert_path in (0, 1)
     for x in (reg, od, mp, sc):
         x.close()
 
