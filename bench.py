@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
-    ap.add_argument("--side-thread", type=int, default=1, help="queue the side-stream work from a second host thread (0/1)")
+    ap.add_argument("--side-thread", type=int, default=2, help="host threads besides the main one that queue work: 0 = none, 1 = one for stage A + "
+                    "stage C's prefetch + ScanContext, 2 = ScanContext on its own thread, 3 = stage B too: four host threads, as the "
+                    "reference runs four processes (the main thread keeps stage C)")
     ap.add_argument("--ring", type=int, default=6, help="features contexts used in turn by the stage pipeline")
     ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
@@ -326,21 +328,27 @@ def main():
     import queue
     import threading
     side_q, side_done = queue.Queue(), queue.Queue()
+    side2_q, side2_done = queue.Queue(), queue.Queue()
 
-    def side_worker():
+    def side_worker(q_in, q_out):
+        torch.cuda.set_device(local)
         while True:
-            job = side_q.get()
+            job = q_in.get()
             if job is None:
                 return
             try:
                 job()
-                side_done.put(None)
+                q_out.put(None)
             except Exception as e:  # surfaced in the main thread
-                side_done.put(e)
+                q_out.put(e)
 
-    side_thread = threading.Thread(target=side_worker, daemon=True) if (pipelined and a.side_thread) else None
+    side_thread = threading.Thread(target=side_worker, args=(side_q, side_done), daemon=True) if (pipelined and a.side_thread) else None
     if side_thread:
         side_thread.start()
+    # ScanContext's calls (keyframe filter, descriptor, insert, search, collect) from a thread of their own: ~20 launches per scan
+    side2_thread = threading.Thread(target=side_worker, args=(side2_q, side2_done), daemon=True) if (pipelined and a.side_thread >= 2 and world == 1) else None
+    if side2_thread:
+        side2_thread.start()
 
     # N > 1: the sharded ScanContext step blocks on two collectives and a few synchronisations per scan; a third host thread
     # runs it (same order on every rank) so that stages A-C of the following scans keep being queued meanwhile.
@@ -378,43 +386,80 @@ def main():
     def side_job(j, last):
         """Everything that only needs stage A, queued one iteration ahead of its use: for scan j+1 the stage-C prefetch, stage A of
         scan j+2, the loop answer of scan j (its search was queued by the previous job), then scan j+1's ScanContext insert + search."""
-        def run():
-            r_ = regs[(j + 1) % len(regs)] if j + 1 < last else None
+        r_ = regs[(j + 1) % len(regs)] if j + 1 < last else None
+
+        def run_a():
             if r_ is not None:
                 timed("side.prefetch", mp.prefetch_features, r_)   # first: its gather + corner filter ride on stage A's stream
             if j + 2 < last:
                 timed("A.run_device", stage_a, regs[(j + 2) % len(regs)], j + 2)
+            if r_ is not None and world > 1:
+                xchg_q.put((j + 1, r_))
+
+        def run_d():
+            if world != 1:
+                return
             if r_ is not None:
-                if world == 1:
-                    timed("D.insert", sc.insert_features, r_)
-                    timed("D.detect_enqueue", sc.detect_enqueue)
-                    pipe.setdefault("d_queued", set()).add(j + 1)
-                else:
-                    xchg_q.put((j + 1, r_))
-            if world == 1 and j in pipe.get("d_queued", ()):      # queued by the previous job: a whole period to finish
+                timed("D.insert", sc.insert_features, r_)
+                timed("D.detect_enqueue", sc.detect_enqueue)
+                pipe.setdefault("d_queued", set()).add(j + 1)
+            if j in pipe.get("d_queued", ()):      # queued by the previous job: a whole period to finish
                 pipe["loops"][j] = timed("D.detect_collect", sc.detect_collect)
                 pipe["d_queued"].discard(j)
-        return run
 
-    def run_side(job):
-        if side_thread:
-            side_q.put(job)
-            pipe["side_inflight"] = True
+        def run():
+            run_a()
+            run_d()
+        return run, run_a, run_d
+
+    def run_side(jobs):
+        both, job_a, job_d = jobs
+        if side_thread and side2_thread:
+            side_q.put(job_a)
+            side2_q.put(job_d)
+            pipe["side_inflight"] = 2
+        elif side_thread:
+            side_q.put(both)
+            pipe["side_inflight"] = 1
         else:
-            job()
+            both()
 
     def join_side():
         if pipe["side_inflight"]:
-            err = timed("side.join", side_done.get)
+            errs = [timed("side.join", side_done.get)]
+            if pipe["side_inflight"] == 2:
+                errs.append(timed("side2.join", side2_done.get))
             pipe["side_inflight"] = False
-            if err is not None:
-                raise err
+            for err in errs:
+                if err is not None:
+                    raise err
 
     def collect_c():
         k = pipe["c_inflight"].pop(0)
         qm, tm, mst = timed("C.collect", mp.collect)
         last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
         return k, mst
+
+    # stage B from a thread of its own (--side-thread 3): "go k" = queue B(k+1), collect B(k), hand the pose to the main thread
+    b_q, b_out = queue.Queue(), queue.Queue()
+
+    def b_worker():
+        torch.cuda.set_device(local)
+        while True:
+            job = b_q.get()
+            if job is None:
+                return
+            try:
+                k, nxt = job
+                if nxt is not None:
+                    timed("B.enqueue", od.enqueue_features, nxt)
+                b_out.put(timed("B.collect", od.collect))
+            except Exception as e:
+                b_out.put(e)
+
+    b_thread = threading.Thread(target=b_worker, daemon=True) if (pipelined and a.side_thread >= 3) else None
+    if b_thread:
+        b_thread.start()
 
     def step_pipelined(k, last):
         """Iteration k of the software pipeline: stage B of scan k+1 is queued before the pose of scan k's stage B is collected,
@@ -425,13 +470,23 @@ def main():
             od.enqueue_features(regs[k % len(regs)])
             pipe["b_queued"] = k
             pipe["started"] = True
-            side_job(k - 1, last)()   # A(k+1), prefetch(k), D(k)
+            side_job(k - 1, last)[0]()   # A(k+1), prefetch(k), D(k)
         join_side()                   # job k-1: A(k+1), prefetch(k), D(k) are queued
         run_side(side_job(k, last))
+        nxt = None
         if k + 1 < last and pipe["b_queued"] < k + 1:
-            timed("B.enqueue", od.enqueue_features, regs[(k + 1) % len(regs)])
+            nxt = regs[(k + 1) % len(regs)]
             pipe["b_queued"] = k + 1
-        qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
+        if b_thread:
+            b_q.put((k, nxt))
+            res = timed("B.wait_pose", b_out.get)
+            if isinstance(res, Exception):
+                raise res
+            qlc, tlc, qw, tw, ost = res
+        else:
+            if nxt is not None:
+                timed("B.enqueue", od.enqueue_features, nxt)
+            qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
         lm_account("odom", ost)
         timed("C.enqueue", mp.enqueue_features, regs[k % len(regs)], qw, tw)
         pipe["c_inflight"].append(k)

@@ -1,5 +1,7 @@
 // Error reporting and device selection for libscaloam_hip.so.
 #include "common.hpp"
+#include <chrono>
+#include <cstdlib>
 
 namespace scal {
 
@@ -155,6 +157,17 @@ void drain_entry(ProfEntry& p) {
 }  // namespace
 
 bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop) {
+    // development aid: SCALOAM_HOST_DELAY_US=n spins n microseconds in front of every launch - a slower host, to see when the
+    // host threads rather than the device chains bound the stage pipeline (tools/gpu_threads_ab.sh)
+    static const int delay_us = [] {
+        const char* e = std::getenv("SCALOAM_HOST_DELAY_US");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (delay_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() < delay_us) {
+        }
+    }
     if (!g_prof_on) return false;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (!g_prof_filter.empty()) {  // one name, or several separated by commas
