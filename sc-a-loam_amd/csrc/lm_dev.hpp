@@ -533,25 +533,28 @@ struct LMNoHook {
 
 // The whole <= 4-iteration solve in ONE launch.  A small grid (<= LM_GRID workgroups, all resident at once on 256 CUs)
 // walks the rounds together: every workgroup evaluates its tiles of residual blocks at the current point (round 0: the
-// accepted point, later: the candidate), publishes LM_NACC partial sums, meets the others at a grid barrier, then sums ALL
+// accepted point, later: the candidate), publishes LM_NACC partial sums, collects everybody's, sums ALL
 // partials in block order and advances Ceres' trust-region state machine on its own private copy of the state.  Same
 // inputs, same instruction sequence: the copies stay bitwise identical, so every workgroup takes the same decisions
 // (including when to stop) without a second exchange.  Workgroup 0 writes the state back.
 //
-// Grid barrier: arrivals are counted in a word that only grows; a round's target is epoch + G * (round + 1), with the
-// epoch read from memory at kernel start and advanced by workgroup 0 after the last round (when every workgroup has long
-// read it).  Partials are double buffered by round parity: a workgroup can be at most one round ahead of the slowest one.
-// Hand-off as in MI355X_MICROARCH.md "Valid forms": write-through stores drained with vmcnt(0) before the arrival,
-// sc1 loads after it.  A poll budget bounds every spin loop: on exhaustion the solve is abandoned with termination 5.
+// Exchange: there is no barrier of its own.  Every partial sum is published as two 64-bit words that carry 32 bits of the double
+// and the 32-bit sequence number of the round (LMSync::epoch + round + 1; the epoch is read at kernel start and advanced by
+// workgroup 0 after the last round, when every workgroup has long read it).  64-bit relaxed agent-scope atomics are single-copy
+// atomic and go to L2, so a consumer that polls a word sees either an older sequence number or the complete word: the data is
+// its own flag, and a round costs one store -> poll-load hop instead of store -> drain -> arrival counter -> poll -> load.
+// Words are double buffered by round parity: a workgroup can be at most one round ahead of the slowest one.  A poll budget
+// bounds the spin: on exhaustion the solve is abandoned with termination 5 and the host clears epoch and words.
 constexpr int LM_GRID = 48;
 constexpr int LM_THREADS = 256;   // (512-thread workgroups, i.e. half the arrivals and partial sums per round, measured slower: 64 vs 58 us)
 constexpr int LM_WAVES = LM_THREADS / 64;
+constexpr size_t LM_PARTIAL_WORDS = static_cast<size_t>(4) * LM_GRID * LM_NACC;
 constexpr int LM_LDS_BYTES = LM_WAVES * LM_NACC * 65 * 8;
 // poll budget of the grid barrier (per translation unit; scal_*_debug_set_lm_polls lowers it to force the give-up path in tests)
 static __device__ int g_lm_poll_budget = 1 << 22;
 struct LMSync {
-    unsigned arrivals;  // grows forever (wrap-around safe comparisons)
-    unsigned epoch;     // arrivals consumed by all earlier solves
+    unsigned reserved;
+    unsigned epoch;     // sequence numbers consumed by all earlier solves
 };
 
 template <class Pre, class Post>
@@ -625,49 +628,63 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
                 red[w][l] = sum;
             }
         }
+        if (tid == 0) s_ok = 1;
         __syncthreads();
-        double* mine = partials + (static_cast<size_t>(round & 1) * LM_GRID + blockIdx.x) * LM_NACC;
-        {
-            double wsum = red[0][tid < LM_NACC ? tid : 0];
+        // Exchange of the partial sums WITHOUT a separate barrier: every partial travels as two 64-bit words, each carrying 32
+        // bits of the double and the 32-bit sequence number of this round (64-bit relaxed atomics are single-copy atomic, so a
+        // word is either stale - older sequence number - or complete).  The consumers poll the words themselves: what used to be
+        // store -> drain -> arrival counter -> poll -> load is store -> poll-load.  Buffers are double buffered by round parity: a
+        // workgroup can be at most one round ahead of the slowest one (it needs everybody's partials of round r to leave round r).
+        const unsigned tag = epoch + static_cast<unsigned>(round) + 1u;
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(partials) + static_cast<size_t>(round & 1) * LM_GRID * LM_NACC * 2;
+        if (tid < LM_NACC) {
+            double wsum = red[0][tid];
 #pragma unroll
-            for (int w2 = 1; w2 < LM_WAVES; ++w2) wsum += red[w2][tid < LM_NACC ? tid : 0];  // fixed wave order
-            if (tid < LM_NACC) __hip_atomic_store(&mine[tid], wsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w2 = 1; w2 < LM_WAVES; ++w2) wsum += red[w2][tid];  // fixed wave order
+            const unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(wsum));
+            unsigned long long* mine = words + (static_cast<size_t>(blockIdx.x) * LM_NACC + tid) * 2;
+            __hip_atomic_store(&mine[0], (static_cast<unsigned long long>(tag) << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine[1], (static_cast<unsigned long long>(tag) << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 2);
-        if (tid == 0) {  // grid barrier
-            __hip_atomic_fetch_add(&sync->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // data already written through
-            const unsigned target = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(round + 1);
-            int ok = 0;
-            const int budget = g_lm_poll_budget;
-            for (int poll = 0; poll < budget; ++poll) {
-                const unsigned cur = __hip_atomic_load(&sync->arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (static_cast<int>(cur - target) >= 0) {
-                    ok = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) {  // poll budget exhausted: give up (termination 5); the host reports it and resets the counters
-            if (tid == 0) L.done = 1, L.termination = 5;
-            __syncthreads();
-            break;
-        }
-        if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 3);
-        {   // sum the per-workgroup partials: 8 groups of workgroups in parallel (independent sc1 loads), fixed order
+        {   // sum the per-workgroup partials: 8 groups of workgroups in parallel, fixed order inside a group and across groups
             double (*gsum)[LM_NACC][65] = xch;  // reuse the transpose buffer: gsum[g][k] = xch[0][k][g]
-            const double* all = partials + static_cast<size_t>(round & 1) * LM_GRID * LM_NACC;
+            constexpr int PER = (LM_GRID + 7) / 8;
             const int k = tid & 31, g = tid >> 5;
             if (k < LM_NACC && g < 8) {
+                unsigned long long lo[PER], hi[PER];
+                unsigned pending = 0;
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    if (g + 8 * i < G) pending |= 1u << i;
+                const int budget = g_lm_poll_budget;
+                for (int poll = 0; pending && poll < budget; ++poll) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i)
+                        if (pending & (1u << i)) {
+                            const unsigned long long* src = words + (static_cast<size_t>(g + 8 * i) * LM_NACC + k) * 2;
+                            lo[i] = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hi[i] = __hip_atomic_load(&src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                    for (int i = 0; i < PER; ++i)
+                        if ((pending & (1u << i)) && static_cast<unsigned>(lo[i] >> 32) == tag && static_cast<unsigned>(hi[i] >> 32) == tag) pending &= ~(1u << i);
+                    if (pending) __builtin_amdgcn_s_sleep(1);
+                }
+                if (pending) s_ok = 0;  // poll budget exhausted
                 double sacc = 0.0;
-                for (int b = g; b < G; b += 8) sacc += __hip_atomic_load(&all[b * LM_NACC + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    if (g + 8 * i < G) sacc += __longlong_as_double(static_cast<long long>((hi[i] << 32) | (lo[i] & 0xffffffffull)));
                 gsum[0][k][g] = sacc;
             }
             __syncthreads();
+            if (!s_ok) {  // give up (termination 5); the host reports it and resets the exchange buffers
+                if (tid == 0) L.done = 1, L.termination = 5;
+                __syncthreads();
+                break;
+            }
+            if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 3);
             if (tid < LM_NACC) {
                 double t8 = 0.0;
 #pragma unroll
@@ -712,7 +729,7 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
         L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
         L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
         *st = L;
-        sync->epoch = epoch + static_cast<unsigned>(G) * static_cast<unsigned>(rounds);
+        sync->epoch = epoch + static_cast<unsigned>(rounds);  // sequence numbers consumed by this solve
     }
     __syncthreads();  // block 0's hook may publish *st
     post(L.x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, false);
@@ -736,7 +753,8 @@ inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* 
                        b ? static_cast<int>(sizeof(B) / 4) : 0);
 }
 
-// host helper: one launch per solve.  `partials` holds 2 * LM_GRID * LM_NACC doubles, `sync` one zero-initialised LMSync.
+// host helper: one launch per solve.  `partials` holds 4 * LM_GRID * LM_NACC zero-initialised 64-bit words (two round parities x two
+// tagged words per partial, LM_PARTIAL_WORDS), `sync` one zero-initialised LMSync; both are cleared again after an abandoned solve.
 // The grid barrier needs all (<= LM_GRID) workgroups of a solve resident at once.  A plain launch does not promise that, a
 // cooperative launch would - but cooperative launches of different streams take turns on this runtime, and stage B's and stage
 // C's solves must overlap.  So the contexts check at creation that the device can hold LM_GRID such workgroups many times over

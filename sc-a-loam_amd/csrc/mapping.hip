@@ -1432,7 +1432,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
-    A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
+    A(c->partials.alloc(LM_PARTIAL_WORDS));
     A(c->lm_sync.alloc(1));
     A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
     A(c->bl_live.alloc(sc)); A(c->bl_rowoff.alloc(sc + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->d_x7.alloc(8));
@@ -1451,6 +1451,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cell.zero(c->stream);
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
         if (rc == SCAL_OK) rc = c->d_done.zero(c->stream);
         MapState& H = *c->h_S.p;
         std::memset(&H, 0, sizeof H);
@@ -1918,6 +1919,7 @@ int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* 
     if (R.st.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
+        (void)c->partials.zero(c->stream);
         (void)hipStreamSynchronize(c->stream);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;

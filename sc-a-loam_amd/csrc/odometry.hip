@@ -431,7 +431,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->less_flat.alloc(c->cap)); A(c->surf_last.alloc(c->cap));
     A(c->fvalid.alloc(c->slot_cap)); A(c->fkind.alloc(c->slot_cap));
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
-    A(c->partials.alloc((size_t)2 * LM_GRID * LM_NACC));
+    A(c->partials.alloc(LM_PARTIAL_WORDS));
     A(c->lm_sync.alloc(1));
     c->nch = std::max(1, div_up(c->cap, NN_TC));
     A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
@@ -447,6 +447,7 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     if (rc == SCAL_OK) {
         // everything is initialised on the context's own stream (the legacy null stream is not ordered against it)
         if (hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
         if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         SCAL_LAUNCH_PROF("k_odom_init_pose", k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
@@ -558,6 +559,7 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
     if (L.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
+        (void)c->partials.zero(c->stream);
         (void)hipStreamSynchronize(c->stream);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
