@@ -300,6 +300,17 @@ __device__ __forceinline__ uint64_t wave_match(uint32_t digit, bool valid) {
     return mask;
 }
 
+// the same with a run-time number of digit bits (uniform over the wave)
+__device__ __forceinline__ uint64_t wave_match_bits(uint32_t digit, bool valid, int bits) {
+    uint64_t mask = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const uint64_t bal = __ballot(bit && valid);
+        mask &= bit ? bal : ~bal;
+    }
+    return mask;
+}
+
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;

@@ -14,7 +14,6 @@ namespace scal {
 
 constexpr int RS_ITEMS = RadixSort::ITEMS;
 constexpr int RS_TILE = RadixSort::TILE;
-constexpr int RS_DIGIT_MAX = RadixSort::DIGIT_MAX;
 constexpr int RS_BINS_MAX = RadixSort::BINS_MAX;
 
 // this pass's digit position; false when the pass has nothing to do.  used = *d_used_bits, or the host's max_bits
@@ -78,7 +77,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     const int n = *d_n;
     const int nb = (n + RS_TILE - 1) / RS_TILE;
     if (static_cast<int>(blockIdx.x) >= nb) return;
-    __shared__ int cnt[4][RS_BINS_MAX];
+    __shared__ unsigned short cnt[4][RS_BINS_MAX];  // per-wave digit counters: at most 8 items x 64 lanes
     __shared__ int sbase[RS_BINS_MAX];
     __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
@@ -111,7 +110,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
             run += sum;
         }
     }
-    for (int i = threadIdx.x; i < 4 * RS_BINS_MAX; i += 256) (&cnt[0][0])[i] = 0;
+    for (int d = threadIdx.x; d < bins; d += 256) cnt[0][d] = 0, cnt[1][d] = 0, cnt[2][d] = 0, cnt[3][d] = 0;
     __syncthreads();
     const int base = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
     unsigned long long k[RS_ITEMS];
@@ -122,12 +121,12 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
         const bool valid = e < n;
         k[j] = valid ? keys[e] : 0ull;
         const uint32_t d = static_cast<uint32_t>(k[j] >> shift) & (bins - 1);
-        const uint64_t m = wave_match<RS_DIGIT_MAX>(d, valid);
+        const uint64_t m = wave_match_bits(d, valid, width);
         int prev = 0;
         if (valid) prev = cnt[w][d];
         rk[j] = prev + __popcll(m & lanemask_lt());
         __builtin_amdgcn_wave_barrier();
-        if (valid && (m & lanemask_lt()) == 0) cnt[w][d] = prev + __popcll(m);
+        if (valid && (m & lanemask_lt()) == 0) cnt[w][d] = static_cast<unsigned short>(prev + __popcll(m));
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -229,7 +228,7 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     const int nb = max(1, div_up(min(cap, max(n_bound, 1)), TILE));
     const bool big = nb > 256;  // every scatter workgroup summing the matrix rows itself stops paying off
     const int nt = div_up(BINS_MAX * nb, HS_TILE);
-    const int passes = div_up(max_bits, DIGIT_MAX);
+    const int passes = rs_passes(max_bits);
     for (int pass = 0; pass < passes; ++pass) {
         const int in = pass & 1, o = in ^ 1;
         SCAL_LAUNCH_PROF("k_rs_hist", k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, pass, max_bits, d_used_bits, hist.p, big ? 1 : 0);

@@ -1,9 +1,11 @@
 // Device-wide stable LSD radix sort of (uint64 key, int32 value) pairs and a small exclusive-scan helper.  Counts live on the
 // device (`d_n`): grids are sized for the capacity and surplus blocks exit, so a whole kernel chain can be enqueued without a
 // host round trip.  The number of key bits actually in use may also live on the device (`d_used_bits`): the digit width adapts
-// to it - ceil(used / 10) passes of ceil(used / passes) bits each, at most 10 - so a 25..27-bit voxel key takes three passes of
-// nine bits and a 28..30-bit one three of ten; passes beyond that return immediately and the result buffer is selected by
-// parity on the device.  The host enqueues ceil(max_bits / 10) passes.
+// to it - ceil(used / 10) passes of ceil(used / passes) bits each up to 30 bits, so a 25..27-bit voxel key takes three passes of
+// nine bits and a 28..30-bit one three of ten; wider keys take ceil(used / 12) passes of up to 12 bits (31..36 bits: still three
+// passes - slower ones, the scatter bases of 2048-4096 digits cost more - instead of a fourth launch pair that every sort of a
+// 36-bit-capable caller would have to enqueue).  Passes beyond the plan return immediately and the result buffer is selected by
+// parity on the device.  The host enqueues rs_passes(max_bits) passes.
 #pragma once
 #include "common.hpp"
 
@@ -18,7 +20,7 @@ struct SortedPairs {
 };
 
 struct RadixSort {
-    static constexpr int DIGIT_MAX = 10;
+    static constexpr int DIGIT_MAX = 12;
     static constexpr int BINS_MAX = 1 << DIGIT_MAX;
     static constexpr int ITEMS = 8;
     static constexpr int TILE = 256 * ITEMS;  // elements per block
@@ -35,14 +37,15 @@ struct RadixSort {
              SortedPairs* out);
 };
 
-// passes that do work and their digit width for a key of `used` bits
+// passes that do work for a key of `used` bits (host and device), and their digit width
+__host__ __device__ __forceinline__ int rs_passes(int used) { return used <= 30 ? (used + 9) / 10 : (used + RadixSort::DIGIT_MAX - 1) / RadixSort::DIGIT_MAX; }
 __device__ __forceinline__ void rs_plan(int used, int& passes, int& width) {
-    passes = (used + RadixSort::DIGIT_MAX - 1) / RadixSort::DIGIT_MAX;
+    passes = rs_passes(used);
     width = passes > 0 ? (used + passes - 1) / passes : 0;
 }
 __device__ __forceinline__ int sorted_sel(const SortedPairs& p) {
     if (p.fixed_sel >= 0) return p.fixed_sel;
-    return ((*p.d_used_bits + RadixSort::DIGIT_MAX - 1) / RadixSort::DIGIT_MAX) & 1;
+    return rs_passes(*p.d_used_bits) & 1;
 }
 
 // in-place exclusive scan of data[0 .. m) with m = bins * ceil(*d_n / tile), by one block; total -> *d_total (may be null)
