@@ -298,8 +298,8 @@ int scal_map_set_merge_insert(scal_map_t* ctx, int enable);
 /* how the steps ran so far: out4 = {queued speculatively, run on the general path, redone from the start after a stopped chain
  * (window moved), insertion redone with the full sort after a stopped chain}; for tests and measurements */
 int scal_map_get_path_counters(scal_map_t* ctx, int* out4);
-/* test hook: poll budget of the LM solve's grid barrier (default 2^22).  With 0 every solve of this library's stage C gives up at
- * its first barrier: collect / step return SCAL_E_HIP ("LM solve abandoned"), the pose of that step is its prior, and the context
+/* test hook: poll budget of the LM solve's partial-sum exchange between its workgroups (default 2^22).  With 0 every solve of this library's stage C gives up at
+ * its first exchange: collect / step return SCAL_E_HIP ("LM solve abandoned"), the pose of that step is its prior, and the context
  * must keep working afterwards.  Exercises the bounded-wait path that would otherwise need a machine hogged by another process. */
 int scal_map_debug_set_lm_polls(scal_map_t* ctx, int polls);
 /* test hook: entries per 1 m cell of the one-launch neighbour-grid build of the queued steps (default: the number of filter voxels
