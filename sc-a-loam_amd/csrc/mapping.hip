@@ -609,7 +609,7 @@ __device__ __forceinline__ unsigned long long map_key(const MapParams& mp, float
 }
 
 // appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
-//   key layout (36 sorted bits = 4 passes): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
+//   key layout (36 sorted bits = 3 passes of 12): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
 __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, const MapState* __restrict__ S, CSoA4 stack, const int* __restrict__ d_nstack,
                                                      const LMState* __restrict__ st, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
                                                      int* __restrict__ vals, MapCounters* C, int cls) {

@@ -1,10 +1,11 @@
-// Stable LSD radix sort (digits of up to 10 bits, width adapted to the key bits in use) for gfx950.  Two kernels per pass:
+// Stable LSD radix sort (digits of up to 10 bits for keys of up to 30 bits, up to 12 beyond; width adapted to the key bits in use)
+// for gfx950.  Two kernels per pass:
 //   k_rs_hist     per-block digit histogram (LDS atomics) -> histogram matrix
 //   k_rs_scatter  every block first derives its own scatter bases from the histogram matrix (sum of the earlier blocks'
 //                 counts per digit + exclusive prefix of the digit totals, 512 x nb L2-resident words - cheaper than a
 //                 separate scan launch while nb is small), then scatters stably: per wave, items are ranked with
-//                 ballot-based digit matching (ten ballots give the lanes holding the same digit), per-wave digit
-//                 counters live in LDS.
+//                 ballot-based digit matching (one ballot per digit bit gives the lanes holding the same digit), per-wave
+//                 16-bit digit counters live in LDS.
 // The element handled by (wave w, item j, lane l) of a block is base + w*ITEMS*64 + j*64 + l, so (w, j, l) order is
 // arrival order and equal keys keep their relative order.
 #include "radix_sort.hpp"
