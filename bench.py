@@ -60,7 +60,9 @@ def parse():
     ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
     ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
     ap.add_argument("--prof-every", type=int, default=8,
-                    help="attach start/stop timestamps to the instrumented kernel launches on every N-th timed step (0 = never)")
+                    help="0 = no kernel timing at all; otherwise the two LM solve kernels (the roofline line) carry start/stop timestamps on every "
+                         "N-th step of the timed region, and every instrumented kernel on --prof-steps extra steps behind it (outside the timing)")
+    ap.add_argument("--prof-steps", type=int, default=24, help="extra, untimed steps with per-kernel timestamps on every launch (kernel_ms_per_step)")
     ap.add_argument("--timeline-kernels", default="", help="with --timeline: only these kernels (comma separated), over the whole timed region")
     ap.add_argument("--timeline", default="", help="development aid: write (kernel, start ms, stop ms) of every dispatch of six timed steps to this CSV")
     ap.add_argument("--sync-dir", default="", help="start the timed region together with --sync-n other bench.py processes (ready files in this directory)")
@@ -189,7 +191,8 @@ def main():
     K, W = a.steps, a.warmup
     R = max(1, a.reps)
     do_h2d = bool(a.h2d) and world == 1
-    total = W + K * (R + (1 if do_h2d else 0))
+    P_STEPS = a.prof_steps if (a.prof_every > 0 and not a.timeline) else 0
+    total = W + K * (R + (1 if do_h2d else 0)) + P_STEPS
     # ---- synthetic HDL-64 sequence for this rank (weak scaling: one independent sequence per GPU)
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     world_gen = scansynth.World(scansynth.HDL64, a.seed + 1000 * rank, threads=threads)
@@ -541,16 +544,24 @@ def main():
     t_wall0 = time.time()
     n_prof_steps = 0
     rep_dt = []
+    # Timestamps on the dispatches cost throughput (tools/gpu_prof_overhead.sh: -8 % and jitter even with only the two solve
+    # kernels timed on every step), so inside the timed region only the two solve kernels of the roofline line carry them, on every
+    # N-th step; the per-kernel table comes from extra steps behind the timed ones.
+    LM_FILTER = "k_lm_solve_map,k_lm_solve_odom"
+    lm_only = a.prof_every > 0 and not a.timeline
     for rep in range(R):  # the same K-step region on consecutive scans of the sequence; the state (map, poses, database) carries on
         k0 = W + rep * K
         t0 = time.perf_counter()
         for k in range(k0, k0 + K):
-            on = a.prof_every > 0 and (k - W) % a.prof_every == 0
             if a.timeline:
                 on = True if a.timeline_kernels else (rep == R - 1 and K // 2 <= k - k0 < K // 2 + 6)
                 S.prof_timeline(on)
-            S.prof_enable(on, a.timeline_kernels or None)  # per-kernel timestamps on the sampled steps of the timed region
-            n_prof_steps += on
+                S.prof_enable(on, a.timeline_kernels or None)
+                n_prof_steps += on
+            else:
+                on = lm_only and (k - W) % a.prof_every == 0
+                S.prof_enable(on, LM_FILTER)
+                n_prof_steps += on
             step(k, k0 + K)
         if pipelined:
             drain()  # the last scan's pose and map insertion belong to the timed region
@@ -575,6 +586,22 @@ def main():
     gc.enable()
     S.prof_enable(False)
     prof = S.prof_read_all()
+    prof_all, n_all_steps = prof, n_prof_steps
+    if P_STEPS > 0:  # per-kernel table: every instrumented launch timed, outside the timed region; the run's statistics are put back
+        import copy
+        keep_stats, keep_lm = copy.deepcopy(stats), copy.deepcopy(lm_bytes)
+        S.prof_reset()
+        S.prof_enable(True)
+        k0 = W + K * (R + (1 if do_h2d else 0))
+        for k in range(k0, k0 + P_STEPS):
+            step(k, k0 + P_STEPS)
+        if pipelined:
+            drain()
+        fence()
+        S.prof_enable(False)
+        prof_all, n_all_steps = S.prof_read_all(), P_STEPS
+        stats.update(keep_stats)
+        lm_bytes.update(keep_lm)
     if a.timeline:
         S.prof_timeline_dump(a.timeline)
     # sizes of one representative scan (outside the timed region) for the algorithmic-byte formulas
@@ -616,7 +643,8 @@ def main():
                        "schedule": "stage-pipelined: one stream per stage, consecutive scans overlap as the reference's four nodes do" if pipelined
                        else "serial: one scan at a time"},
             "roofline": roofline, "cpu_baseline": cpu,
-            "kernel_ms_per_step": {k: v[0] / max(1, n_prof_steps) for k, v in sorted(prof.items())}, "profiled_steps": n_prof_steps,
+            "kernel_ms_per_step": {k: v[0] / max(1, n_all_steps) for k, v in sorted(prof_all.items())}, "profiled_steps": n_all_steps,
+            "roofline_timed_steps": n_prof_steps,
             "loops_detected": int(stats["loops"]), "input_gen_s": gen_s, "final_map_pose": final_pose_resident,
             "host_us_per_step": {k: v / K * 1e6 for k, v in host_t.items()} if a.host_timing else None,
             "timed_window_unix": [t_wall0, t_wall1],
