@@ -111,7 +111,6 @@ typedef struct {
     int n_tied_segments; /* segments whose sort met equal curvatures (std::sort order is unspecified there) */
 } scal_features_out;
 
-typedef struct scal_features scal_features_t;
 int scal_features_create(const scal_features_config* cfg, scal_features_t** ctx);
 void scal_features_destroy(scal_features_t* ctx);
 /* host input: xyz at xyz + i*stride_bytes (PointCloud2 layout). Synchronous. */
@@ -130,7 +129,6 @@ int scal_features_sync(scal_features_t* ctx);
 /* ------------------------------------------------------------------ voxel grid
  * Replaces pcl::VoxelGrid<PointXYZI>::filter at scanRegistration.cpp:414-418,
  * laserMapping.cpp:543-551, :793-801 and laserPosegraphOptimization.cpp:629-631. */
-typedef struct scal_voxel scal_voxel_t;
 int scal_voxel_create(int max_points, int device, scal_voxel_t** ctx);
 void scal_voxel_destroy(scal_voxel_t* ctx);
 int scal_voxel_downsample(scal_voxel_t* ctx, const float* xyzi, int n, float leaf, float* out_xyzi, int* n_out);
@@ -168,7 +166,6 @@ typedef struct {
     int cand_shift[3];
 } scal_sc_result;
 
-typedef struct scal_sc scal_sc_t;
 int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** ctx);
 void scal_sc_destroy(scal_sc_t* ctx);
 int scal_sc_size(scal_sc_t* ctx);
@@ -259,7 +256,6 @@ typedef struct {
     int insert_path;                /* how :738-802 ran: 0 = full sort of the map pool, 1 = merge of the scan's points into the sorted map */
 } scal_map_stats;
 
-typedef struct scal_map scal_map_t;
 int scal_map_create(const scal_map_config* cfg, scal_map_t** ctx);
 void scal_map_destroy(scal_map_t* ctx);
 /* one process() pass.  corner_last / surf_last / full_res: PointXYZI host arrays (full_res may be NULL).
@@ -346,7 +342,6 @@ typedef struct {
     int lm_iters[2], lm_success[2];
     double cost_init[2], cost_final[2];
 } scal_odom_stats;
-typedef struct scal_odom scal_odom_t;
 int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** ctx);
 void scal_odom_destroy(scal_odom_t* ctx);
 int scal_odom_step(scal_odom_t* ctx, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp,

@@ -553,15 +553,20 @@ constexpr int LM_LDS_BYTES = LM_WAVES * LM_NACC * 65 * 8;
 // poll budget of the grid barrier (per translation unit; scal_*_debug_set_lm_polls lowers it to force the give-up path in tests)
 static __device__ int g_lm_poll_budget = 1 << 22;
 struct LMSync {
-    unsigned reserved;
+    unsigned abandoned; // sticky: a workgroup of some solve ran out of polls.  Every later solve on this exchange returns at once
+                        // (its caller's chain drains as no-ops) until the host has cleared the words and this struct.
     unsigned epoch;     // sequence numbers consumed by all earlier solves
 };
+constexpr int LM_EPOCH_STEP = 8;   // sequence numbers reserved per solve (it uses at most 5: one per round), whatever happened in it
+constexpr int LM_ABORT_CODE = 4;   // written to the caller's abort word by a workgroup that gives up (stage C: MAP_ABORT_LM)
 
 template <class Pre, class Post>
 static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
                                                          const int* __restrict__ d_enable, double* partials, LMSync* sync,
-                                                         const int* __restrict__ d_abort, Pre pre, Post post) {
-    if (d_abort && *d_abort) {  // uniform over the grid (written by an earlier kernel): a stopped chain leaves the state alone
+                                                         int* d_abort, Pre pre, Post post) {
+    // uniform over the grid (both words are written by earlier kernels only): a stopped chain leaves the state alone, and so does
+    // every solve queued behind an abandoned one - its exchange words may hold tags of workgroups that gave up at different rounds
+    if ((d_abort && *d_abort) || sync->abandoned) {
         post(st->x, blockIdx.x * LM_THREADS + threadIdx.x, gridDim.x * LM_THREADS, true);
         return;
     }
@@ -590,11 +595,9 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
     const unsigned epoch = sync->epoch;
     if (tid == 0) L = *st;  // only x carries over from the previous solve; lm_tail(phase 0) re-arms the rest
     __syncthreads();
-    int rounds = 0;
     for (int round = 0; round < 5; ++round) {
         const int phase = round ? 1 : 0;
         if (phase && L.done) break;  // identical in every workgroup
-        rounds = round + 1;
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 0);
         double xl[7];
 #pragma unroll
@@ -679,8 +682,16 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
                 gsum[0][k][g] = sacc;
             }
             __syncthreads();
-            if (!s_ok) {  // give up (termination 5); the host reports it and resets the exchange buffers
-                if (tid == 0) L.done = 1, L.termination = 5;
+            if (!s_ok) {
+                // Give up (termination 5).  Workgroups may reach this in different rounds (or, in the last round, not at all), so
+                // the verdict is published where the kernels behind this one see it: the sticky word of the exchange and the
+                // caller's abort word (stage C: nothing of this step is committed, queued steps drain as no-ops).  The host reports
+                // the step as failed and clears words, epoch and both flags before anything else runs on this exchange.
+                if (tid == 0) {
+                    L.done = 1, L.termination = 5;
+                    __hip_atomic_store(&sync->abandoned, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d_abort) __hip_atomic_store(d_abort, LM_ABORT_CODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 __syncthreads();
                 break;
             }
@@ -729,10 +740,12 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
         L.log_iters[outer] = L.iteration, L.log_success[outer] = L.successful;
         L.log_cost_init[outer] = L.cost_init, L.log_cost_final[outer] = L.cost_final;
         *st = L;
-        sync->epoch = epoch + static_cast<unsigned>(rounds);  // sequence numbers consumed by this solve
+        // A fixed stride per solve, not the rounds it took: a tag a workgroup published before some other one gave up can then
+        // never equal a tag of a later solve.
+        sync->epoch = epoch + static_cast<unsigned>(LM_EPOCH_STEP);
     }
     __syncthreads();  // block 0's hook may publish *st
-    post(L.x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, false);
+    post(L.x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, L.termination == 5);
 }
 
 // Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
@@ -781,7 +794,7 @@ inline int lm_set_poll_budget(int polls) {
 
 template <class Pre = LMNoHook, class Post = LMNoHook>
 inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMState* st, const int* d_enable, double* partials, LMSync* sync,
-                            int outer, const int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {
+                            int outer, int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {
     int g = (f.cap + LM_THREADS - 1) / LM_THREADS;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
     SCAL_LAUNCH_PROF(prof_name, (k_lm_solve<Pre, Post>), dim3(g), dim3(LM_THREADS), LM_LDS_BYTES, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);

@@ -27,6 +27,7 @@
 #include "lm_dev.hpp"
 #include "features_dev.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <algorithm>
 
 namespace scal {
@@ -61,7 +62,8 @@ struct MapCounters {
 
 // Persistent device-side state of the mapper.  The pose algebra of :143-153, the rolling-window decision of :313-508 and the
 // map sizes live here, so that a step can be queued behind the previous one without the host reading anything back.
-enum { MAP_ABORT_NONE = 0, MAP_ABORT_WINDOW = 1, MAP_ABORT_MERGE = 2, MAP_ABORT_GRID = 3 };
+enum { MAP_ABORT_NONE = 0, MAP_ABORT_WINDOW = 1, MAP_ABORT_MERGE = 2, MAP_ABORT_GRID = 3, MAP_ABORT_LM = 4 };
+static_assert(MAP_ABORT_LM == LM_ABORT_CODE, "the LM solve raises the abort word itself when a workgroup gives up");
 struct MapState {
     double q_wmap_wodom[4], t_wmap_wodom[3];  // :113-114
     double q_wodom[4], t_wodom[3];            // this step's /laser_odom_to_init pose (kept for transformUpdate)
@@ -1274,6 +1276,8 @@ struct MapStep {
     bool prefetched = false, have_full = false, fast = false;
     bool pose_collected = false;  // the caller has the pose
     bool confirmed = false;       // the insertion is known to have completed; a step leaves the queue when both hold
+    bool failed = false;          // the LM solve was abandoned twice (MAP_ABORT_LM): nothing of this step was committed
+    unsigned feat_generation = 0; // run of `feat` this step was enqueued for: a replay must find the same scan in the context
     int n_corner_bound = 0, n_surf_bound = 0;
     int insert_path = 0;
 };
@@ -1316,6 +1320,8 @@ struct scal_map {
     bool poll_on_enqueue = true;  // scal_map_set_poll
     int cur = 0;                // parity of the map buffers once every queued step has been inserted
     bool initialised = false;   // at least one step went through the general path
+    // map <- odometry correction after the last step whose insertion is confirmed: what an abandoned solve is rolled back to
+    double good_q[4] = {0, 0, 0, 1}, good_t[3] = {0, 0, 0};
     int scan_cap = 0, map_cap = 0, slot_cap = 0;
     // host mirrors (laserMapping.cpp:110-120), refreshed when a pose is collected
     double q_wmap_wodom[4] = {0, 0, 0, 1}, t_wmap_wodom[3] = {0, 0, 0};
@@ -1405,7 +1411,26 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         A(c->grid[k].cell.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
         A(c->grid[k].g.alloc(mc));
     }
-    if (rc == SCAL_OK) {  // fixed-slice pools of the one-launch grid build: 16 B x voxels per cell x 9.4 M cells, sparsely touched
+    A(c->sorter.init(c->map_cap));
+    A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
+    for (int k = 0; k < 2; ++k) {
+        A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
+        A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX)); A(c->mblocktot[k].alloc(MERGE_CHUNKS));
+        A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 16));
+    }
+    A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
+    A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
+    A(c->partials.alloc(LM_PARTIAL_WORDS));
+    A(c->lm_sync.alloc(1));
+    A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
+    A(c->bl_live.alloc(sc)); A(c->bl_rowoff.alloc(sc + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->d_x7.alloc(8));
+    A(c->d_res.alloc(3 * sc)); A(c->d_jac.alloc(21 * sc)); A(c->d_blocks.alloc(10 * sc));
+    A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
+    // Optional, and therefore LAST (after every mandatory buffer, so that a device where they do not fit still gets a working context
+    // with the three-launch build): fixed-slice pools of the one-launch grid build, 16 B x voxels per cell x 9.4 M cells = 5.3 GB at
+    // the reference's 0.4 / 0.8 m, sparsely touched.  SCALOAM_MAP_FIXED_GRID=0 switches the shortcut (and its footprint) off.
+    const char* fixed_env = std::getenv("SCALOAM_MAP_FIXED_GRID");
+    if (rc == SCAL_OK && !(fixed_env && fixed_env[0] == '0')) {
         int cap[2];
         for (int k = 0; k < 2; ++k) {
             const int a = voxels_per_cell_axis(k == 0 ? c->cfg.line_res : c->cfg.plane_res);
@@ -1423,23 +1448,12 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
             }
         }
     }
-    A(c->sorter.init(c->map_cap));
-    A(c->keys.alloc(mc)); A(c->vals.alloc(mc)); A(c->blockcnt.alloc(div_up(c->map_cap, 256) + 1));
-    for (int k = 0; k < 2; ++k) {
-        A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
-        A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX)); A(c->mblocktot[k].alloc(MERGE_CHUNKS));
-        A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 16));
-    }
-    A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
-    A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
-    A(c->partials.alloc(LM_PARTIAL_WORDS));
-    A(c->lm_sync.alloc(1));
-    A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
-    A(c->bl_live.alloc(sc)); A(c->bl_rowoff.alloc(sc + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->d_x7.alloc(8));
-    A(c->d_res.alloc(3 * sc)); A(c->d_jac.alloc(21 * sc)); A(c->d_blocks.alloc(10 * sc));
-    A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     c->lane = stage_lane(STAGE_MAP);
     if (rc == SCAL_OK) rc = lm_check_residency<LMNoHook, MapPoseDone>(c->cfg.device);
+    // per device, hence here and not behind a process-wide flag at the first launch
+    if (rc == SCAL_OK && hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_keys), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(sizeof(unsigned long long) * MERGE_MAX)) != hipSuccess)
+        rc = SCAL_E_HIP;
     if (rc == SCAL_OK && acquire_stream(c->cfg.device, &c->stream, c->lane) != SCAL_OK) rc = SCAL_E_HIP;
     for (int k = 0; k < scal_map::NSLOTS && rc == SCAL_OK; ++k) {
         if (hipEventCreateWithFlags(&c->ev_pose[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
@@ -1571,12 +1585,7 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
         a.grid_cell[k] = c->grid[k].cell.p, a.grid_rank[k] = c->grid[k].rank.p;
     }
     a.cap = c->map_cap;
-    static bool attr_set = false;
-    const int lds = sizeof(unsigned long long) * MERGE_MAX;
-    if (!attr_set) {
-        SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_keys), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    const int lds = sizeof(unsigned long long) * MERGE_MAX;  // attribute set per device in scal_map_create
     SCAL_LAUNCH_PROF("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
     SCAL_LAUNCH_PROF("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
     MergeTail t{};
@@ -1698,15 +1707,57 @@ int report_device_error(scal_map* c, int err) {
     return err;
 }
 
+// ---- an abandoned LM solve (lm_dev.hpp: a workgroup ran out of polls - another process hogging the machine).  The solve raised
+// LMSync::abandoned and MapState::abort = MAP_ABORT_LM itself: the step's insertion and everything queued behind it drained as
+// no-ops, nothing was committed.  The host clears the exchange, rolls the map <- odometry correction back to the last confirmed
+// step (workgroup 0 may have applied transformUpdate before some other workgroup gave up) and runs the step once more; a second
+// failure is reported to the caller (SCAL_E_HIP, "LM solve abandoned") and the scan is dropped - the map never sees it.
+constexpr int MAP_RC_LM = 1000;  // internal: launch sequence fine, solve abandoned
+bool lm_gave_up(const MapResult& R) { return R.st.termination == 5 || R.S1.abort == MAP_ABORT_LM; }
+int lm_reset(scal_map* c, bool restore_pose) {
+    hipStream_t s = c->stream;
+    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), s));
+    SCAL_TRY(c->partials.zero(s));
+    SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+    if (restore_pose) {
+        double* h = reinterpret_cast<double*>(c->h_S.p);  // pinned scratch
+        for (int i = 0; i < 4; ++i) h[i] = c->good_q[i];
+        for (int i = 0; i < 3; ++i) h[4 + i] = c->good_t[i];
+        static_assert(offsetof(MapState, t_wmap_wodom) == offsetof(MapState, q_wmap_wodom) + 4 * sizeof(double), "pose fields are contiguous");
+        SCAL_HIP(hipMemcpyAsync(c->d_S.p->q_wmap_wodom, h, 7 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    SCAL_HIP(hipStreamSynchronize(s));
+    return SCAL_OK;
+}
+
 int general_insert(scal_map* c, MapStep& e);
 // General path, synchronous: the window may move, the insertion falls back to the full sort.  All earlier steps have finished.
-int run_general(scal_map* c, MapStep& e) {
+// Returns MAP_RC_LM (nothing committed, exchange not yet cleared) when the solve was abandoned.
+int run_general_once(scal_map* c, MapStep& e) {
     e.fast = false;
     e.par = c->cur;
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    if (lm_gave_up(c->res.p[e.slot])) return MAP_RC_LM;
     return general_insert(c, e);
+}
+int run_general(scal_map* c, MapStep& e) {
+    int rc = run_general_once(c, e);
+    for (int attempt = 0; rc == MAP_RC_LM; ++attempt) {
+        SCAL_TRY(lm_reset(c, true));
+        // a full cell grid was left behind by the stopped pose part: restore the zero invariant before the grid is built again
+        SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, c->stream, grid_args(c, e.par), c->d_S.p);
+        if (attempt == 1) {
+            SCAL_HIP(hipStreamSynchronize(c->stream));
+            e.failed = true;
+            set_error("LM solve abandoned: grid barrier timed out");
+            return SCAL_E_HIP;
+        }
+        rc = run_general_once(c, e);
+    }
+    return rc;
 }
 
 // second half of the general path: the pose stands (slot S1 / C1 published), insertion + registration + commit, synchronous
@@ -1763,8 +1814,18 @@ int launch_fast(scal_map* c, MapStep& e) {
 void confirm(scal_map* c, MapStep& e) {
     const MapResult& R = c->res.p[e.slot];
     for (int k = 0; k < 2; ++k) c->map[k].n = R.S2.n_map[k];
+    for (int i = 0; i < 4; ++i) c->good_q[i] = R.S1.q_wmap_wodom[i];
+    for (int i = 0; i < 3; ++i) c->good_t[i] = R.S1.t_wmap_wodom[i];
     c->last_insert_path = e.insert_path;
     e.confirmed = true;
+}
+// a step whose features context has been run again since it was enqueued cannot be redone: its inputs are gone
+int check_generation(const MapStep& e, bool needs_inputs) {
+    if (!e.feat || features_view(e.feat).generation == e.feat_generation) return SCAL_OK;
+    if (!needs_inputs && !e.have_full) return SCAL_OK;
+    set_error("scal_map: a stopped step has to be redone, but its features context has been run again since scal_map_enqueue_features "
+              "(the caller must not reuse a features context before its step has been collected)");
+    return SCAL_E_STATE;
 }
 void pop_done(scal_map* c) {
     while (!c->steps.empty() && c->steps.front().confirmed && c->steps.front().pose_collected) c->steps.pop_front();
@@ -1781,22 +1842,34 @@ int recover(scal_map* c) {
         MapStep& e = c->steps[i];
         if (e.confirmed) continue;
         const MapResult& R = c->res.p[e.slot];
-        if (R.S1.abort) { origin = i, at_pose = true; break; }
+        if (R.S1.abort || R.st.termination == 5) { origin = i, at_pose = true; break; }
         if (R.S2.abort) { origin = i, at_pose = false; break; }
         if (R.C2.error) return report_device_error(c, R.C2.error);
         confirm(c, e);  // in front of the stop: completed
     }
     if (origin == c->steps.size()) return SCAL_OK;  // nothing stopped
-    SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
     MapStep& e = c->steps[origin];
     c->cur = e.par;
+    bool dropped = false;
     if (at_pose) {
         c->n_recover_pose++;
-        if (c->res.p[e.slot].S1.abort == MAP_ABORT_GRID)  // a full cell: the one-launch build left its counters behind
+        const MapResult& R0 = c->res.p[e.slot];
+        const bool lm = lm_gave_up(R0);
+        if (lm) SCAL_TRY(lm_reset(c, true));  // clears the abort word too
+        else SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+        if (lm || R0.S1.abort == MAP_ABORT_GRID)  // the grid was built and the kernel that clears its counters never ran
             SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
-        SCAL_TRY(run_general(c, e));
+        SCAL_TRY(check_generation(e, !e.prefetched));
+        const int rc = run_general(c, e);
+        if (rc != SCAL_OK && !e.failed) return rc;
+        dropped = e.failed;  // abandoned again: the scan is dropped, the caller gets SCAL_E_HIP from collect
     } else {
         c->n_recover_insert++;  // the pose of this step stands; only its insertion is redone, with the full sort
+        if (c->res.p[e.slot].S2.abort == MAP_ABORT_LM) SCAL_TRY(lm_reset(c, false));  // a workgroup gave up in the last round, after workgroup 0 had finished
+        else SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+        if (c->res.p[e.slot].S2.abort == MAP_ABORT_LM)
+            SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+        SCAL_TRY(check_generation(e, false));
         const MapResult& R = c->res.p[e.slot];
         const int n_map[2] = {R.S2.n_map[0], R.S2.n_map[1]};  // not committed: still the sizes before the insertion
         e.fast = false, e.insert_path = 0;
@@ -1806,8 +1879,12 @@ int recover(scal_map* c) {
         if (R.C2.error) return report_device_error(c, R.C2.error);
         c->cur = e.par ^ 1;
     }
-    confirm(c, e);
-    for (size_t i = origin + 1; i < c->steps.size(); ++i) SCAL_TRY(launch_fast(c, c->steps[i]));
+    if (dropped) e.confirmed = true;  // nothing to confirm: map sizes and the last good correction stay as they were
+    else confirm(c, e);
+    for (size_t i = origin + 1; i < c->steps.size(); ++i) {
+        SCAL_TRY(check_generation(c->steps[i], !c->steps[i].prefetched));
+        SCAL_TRY(launch_fast(c, c->steps[i]));
+    }
     return SCAL_OK;
 }
 
@@ -1822,7 +1899,7 @@ int confirm_steps(scal_map* c, bool wait) {
             break;
         }
         const MapResult& R = c->res.p[slot];
-        if (R.S1.abort || R.S2.abort) {
+        if (R.S1.abort || R.S2.abort || R.st.termination == 5) {
             SCAL_TRY(recover(c));  // confirms at least this step
             if (!c->steps[i].confirmed) {
                 set_error("scal_map: internal error (recovery did not complete the stopped step)");
@@ -1905,7 +1982,7 @@ int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* 
     const int slot = pe->slot;
     for (int round = 0;; ++round) {
         SCAL_HIP(hipEventSynchronize(c->ev_pose[slot]));
-        if (!c->res.p[slot].S1.abort) break;
+        if (pe->failed || (!c->res.p[slot].S1.abort && c->res.p[slot].st.termination != 5)) break;
         if (round > scal_map::MAX_STEPS + 1) {
             set_error("scal_map_collect: internal error (recovery does not converge)");
             return SCAL_E_STATE;
@@ -1915,15 +1992,12 @@ int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* 
     pe->pose_collected = true;
     const MapResult& R = c->res.p[slot];
     const MapCounters& H = R.C1;
-    if (H.error) return report_device_error(c, H.error);
-    if (R.st.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
-        (void)c->partials.zero(c->stream);
-        (void)hipStreamSynchronize(c->stream);
+    if (pe->failed) {  // abandoned twice (recover / run_general): the scan was dropped, the exchange is clean again
+        pop_done(c);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
     }
+    if (H.error) return report_device_error(c, H.error);
     const double* xf = R.st.x;
     for (int i = 0; i < 4; ++i) q_out[i] = xf[i];
     for (int i = 0; i < 3; ++i) t_out[i] = xf[4 + i];
@@ -2075,6 +2149,7 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
     MapStep e;
     SCAL_TRY(new_step(c, &e));
     e.feat = feat;
+    e.feat_generation = v.generation;
     e.n_corner_bound = std::min(c->scan_cap, v.n_scans * 120);
     e.n_surf_bound = std::min(c->scan_cap, v.cap);
     e.have_full = true;

@@ -281,6 +281,7 @@ struct HandoverArgs {
     int* tab_reset;     // the set the association of this scan used: re-filled here for the next hand-over
     const LMState* st;  // the solved state goes to the host slot from here (no launch of its own)
     LMState* host_st;
+    const LMSync* sync; // an abandoned solve (any workgroup, this step or one queued in front of it) reaches the host as termination 5
 };
 __global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
     int b = blockIdx.x;
@@ -290,7 +291,9 @@ __global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
         for (int t = threadIdx.x; t < 4 * RING_TAB; t += 256) a.tab_reset[t] = ((t / RING_TAB) & 1) ? -1 : 0x7f7f7f7f;
         const unsigned* src = reinterpret_cast<const unsigned*>(a.st);
         unsigned* dst = reinterpret_cast<unsigned*>(a.host_st);
-        for (int t = threadIdx.x; t < static_cast<int>(sizeof(LMState) / 4); t += 256) dst[t] = src[t];
+        const bool abandoned = a.sync->abandoned != 0;
+        constexpr int TERM_WORD = static_cast<int>(offsetof(LMState, termination) / 4);
+        for (int t = threadIdx.x; t < static_cast<int>(sizeof(LMState) / 4); t += 256) dst[t] = (abandoned && t == TERM_WORD) ? 5u : src[t];
     }
     int* first_idx = a.tab_write + 2 * k * RING_TAB;
     int* last_idx = first_idx + RING_TAB;
@@ -537,7 +540,7 @@ int launch_handover(scal_odom* c, int slot) {
         h.nb0 = std::max(1, div_up(c->feat_cap, 256));
         h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
         h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
-        h.st = st, h.host_st = c->h_st.p + slot;
+        h.st = st, h.host_st = c->h_st.p + slot, h.sync = c->lm_sync.p;
         SCAL_LAUNCH_PROF("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
         c->tab_cur ^= 1;
     }
@@ -556,7 +559,10 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
     c->pending.pop_front();
     SCAL_HIP(hipEventSynchronize(c->ev[slot]));
     const LMState& L = c->h_st.p[slot];
-    if (L.termination == 5) {  // a grid barrier of the LM solve ran out of polls: never seen, but do not trust the pose
+    if (L.termination == 5) {
+        // A workgroup of this step's solve - or of a step queued in front of it: the flag is sticky on the device and every solve
+        // behind it returned at once - ran out of polls.  Never seen outside the test hook, but the pose cannot be trusted: the step
+        // is reported as failed (the pose keeps its last good value), and the exchange is cleared once everything queued has drained.
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
         (void)c->partials.zero(c->stream);

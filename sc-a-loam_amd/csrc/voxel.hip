@@ -339,6 +339,9 @@ int VoxelFilter::init(int capacity) {
     SCAL_TRY(blockcnt.alloc(div_up(cap, 256) + 1));
     SCAL_TRY(meta.alloc(1));
     SCAL_TRY(box_parts.alloc(6 * 128));
+    // every caller has selected its device by now: the attribute is per device, not per process
+    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vox_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 static_cast<int>(sizeof(unsigned long long) * VOX_SMALL)));
     return SCAL_OK;
 }
 
@@ -347,12 +350,7 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
     const float inv = 1.0f / leaf;  // inverse_leaf_size_ = 1 / leaf_size_ in f32
     const VoxTail tl = tail ? *tail : VoxTail();
     if (n_bound <= VOX_SMALL) {
-        static bool attr_set = false;
-        const int lds = sizeof(unsigned long long) * VOX_SMALL;
-        if (!attr_set) {
-            SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vox_small), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            attr_set = true;
-        }
+        const int lds = sizeof(unsigned long long) * VOX_SMALL;  // attribute set per device in VoxelFilter::init
         {
             SCAL_LAUNCH_PROF("k_vox_small", k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p, tl);
         }

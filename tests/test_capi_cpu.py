@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol(S):
     assert sorted(S.EXPORTED_SYMBOLS) == syms
 
 
+def test_header_is_plain_c99():
+    """include/scaloam_hip.h says "plain C": a strict C99 compiler must take it (no repeated typedefs, no C++-isms), and so must C++."""
+    for cmd in (["gcc", "-std=c99", "-pedantic-errors", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", HEADER],
+                ["g++", "-std=c++11", "-pedantic-errors", "-fsyntax-only", "-x", "c++", HEADER]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback_and_oracle_is_not_linked(S):
     import torch
     if torch.cuda.is_available():

@@ -34,6 +34,7 @@ def test_stream_parity(O, S, stage_ab):
     om = O.Mapper(0.4, 0.8, voxel_order=1, knn_mode=0)
     gm = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
     worst = 0.0
+    slack = dict(registered=0, map=0)
     for k, fr in enumerate(stage_ab):
         qo, to, so, rego = om.step(fr["corner"], fr["surf"], fr["full"], fr["q"], fr["t"], want_registered=True)
         qg, tg, sg, regg = gm.process(fr["corner"], fr["surf"], fr["full"], fr["q"], fr["t"], want_registered=True)
@@ -50,6 +51,7 @@ def test_stream_parity(O, S, stage_ab):
         assert d <= 1e-7, (k, d)
         # registered full-resolution cloud (:845-849): f32 results of an f64 transform
         nbad = (regg.view(np.uint32) != rego.view(np.uint32)).any(axis=1).sum()
+        slack["registered"] = max(slack["registered"], int(nbad))
         assert nbad <= max(5, regg.shape[0] // 10000), (k, nbad)
         # map content of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap for the next scan): same point set
         for which in (0, 1):
@@ -57,11 +59,12 @@ def test_stream_parity(O, S, stage_ab):
             mg = _sorted_rows(gm.export(which))
             assert mo.shape == mg.shape, (k, which, mo.shape, mg.shape)
             nb = (mo != mg).any(axis=1).sum()
+            slack["map"] = max(slack["map"], int(nb))
             assert nb <= max(3, mo.shape[0] // 5000), (k, which, nb, mo.shape[0])
         qa, ta = om.wmap_wodom()
         qb, tb = gm.wmap_wodom()
         assert np.abs(qa - qb).max() <= 1e-7 and np.abs(ta - tb).max() <= 1e-7
-    print("worst pose difference over the stream:", worst)
+    print("worst pose difference over the stream:", worst, "rows that differ from the oracle (max over scans):", slack)
     gm.close()
 
 
@@ -255,6 +258,7 @@ def test_long_stream_parity_device_pipeline(O, S, hdl64_stream):
     for which in (0, 1):
         mo, mg = _sorted_rows(om.export(which)), _sorted_rows(gm.export(which))
         assert mo.shape == mg.shape, (which, mo.shape, mg.shape)
+        print("map rows that differ from the oracle, class", which, ":", int((mo != mg).any(axis=1).sum()), "of", mo.shape[0])
         assert (mo != mg).any(axis=1).sum() <= max(3, mo.shape[0] // 5000), which
     for x in (reg, od, gm):
         x.close()
@@ -337,23 +341,75 @@ def test_ceres_adapter_mode(O, S, stage_ab):
 
 
 def test_lm_barrier_gives_up_cleanly(S, stage_ab):
-    """The LM solve's grid barrier is a bounded wait: when a round's arrivals do not show up within the poll budget every workgroup
-    leaves with termination 5, the step reports SCAL_E_HIP, and the context keeps working.  The budget is lowered to zero here to
-    force that path (it cannot be provoked otherwise without another process hogging the GPU)."""
+    """The LM solve's exchange is a bounded wait: when a round's partial sums do not show up within the poll budget the workgroup
+    gives up, raises the sticky flags (exchange + stage C's abort word), nothing of the step is committed and every kernel queued
+    behind it drains as a no-op.  The host clears the exchange, rolls the map <- odometry correction back and runs the step once
+    more; the second failure is reported as SCAL_E_HIP and the scan is dropped.  The budget is lowered to zero here to force that
+    path (it cannot be provoked otherwise without another process hogging the GPU).  Afterwards the context must behave exactly
+    like one that never saw the failure: the abandoned step left no trace in the map."""
     gm = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
     ref = S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=2000000)
     for fr in stage_ab[:3]:
         gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
         ref.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
-    gm.debug_set_lm_polls(0)
     fr = stage_ab[3]
-    with pytest.raises(S.ScalError) as e:
-        gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
-    assert e.value.code == S.E_HIP and "abandoned" in str(e.value)
-    gm.debug_set_lm_polls(1 << 22)
+    try:
+        gm.debug_set_lm_polls(0)   # process-global device symbol: always put back
+        for _ in range(2):         # twice: the second failure starts from a context that has already been cleaned up once
+            with pytest.raises(S.ScalError) as e:
+                gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+            assert e.value.code == S.E_HIP and "abandoned" in str(e.value)
+    finally:
+        gm.debug_set_lm_polls(1 << 22)
     gm.finish()
-    q, t, st, _ = gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])   # the same scan again: solves normally
-    assert st.solved == 1 and st.lm_iters[0] >= 1
-    q2, t2, st2, _ = ref.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
-    assert max(np.abs(q - q2).max(), np.abs(t - t2).max()) <= 5e-2   # (the abandoned step inserted the scan at its prior pose)
+    for fr in stage_ab[3:6]:       # the same scan again, and two more: solves normally, bit-identical to the undisturbed context
+        q, t, st, _ = gm.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+        assert st.solved == 1 and st.lm_iters[0] >= 1
+        q2, t2, st2, _ = ref.process(fr["corner"], fr["surf"], None, fr["q"], fr["t"])
+        assert np.array_equal(q, q2) and np.array_equal(t, t2)
+    for which in (0, 1):
+        assert np.array_equal(_sorted_rows(gm.export(which)), _sorted_rows(ref.export(which)))
     gm.close(), ref.close()
+
+
+def test_lm_give_up_on_the_queued_chain(S, hdl64_stream):
+    """The same failure with steps queued speculatively behind the abandoned one (device-resident features, nothing read back
+    between the steps): every queued step must come back as SCAL_E_HIP without touching the map, and the scans replayed afterwards
+    must give the poses and the map of a context that never failed."""
+    n0, nq = 4, 3
+    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=200000) for _ in range(nq)]
+    od = S.LaserOdometry(max_points=200000)
+    mk = lambda: S.LaserMapping(0.4, 0.8, max_scan_points=200000, max_map_points=3000000)
+    a, b = mk(), mk()
+    b.set_poll(False)
+    odo = []
+    for k in range(n0 + nq):
+        r = regs[k % nq]
+        r.laserCloudHandler(hdl64_stream(k))
+        _, _, qw, tw, _ = od.step_features(r)
+        odo.append((qw.copy(), tw.copy()))
+        if k < n0:
+            a.process_features(r, qw, tw), b.process_features(r, qw, tw)
+    # scans n0 .. n0+nq-1 are now in the three features contexts
+    try:
+        b.debug_set_lm_polls(0)
+        for k in range(n0, n0 + nq):
+            b.enqueue_features(regs[k % nq], *odo[k])
+        for k in range(n0, n0 + nq):
+            with pytest.raises(S.ScalError) as e:
+                b.collect()
+            assert e.value.code == S.E_HIP and "abandoned" in str(e.value), k
+    finally:
+        b.debug_set_lm_polls(1 << 22)
+    b.finish()
+    for k in range(n0, n0 + nq):
+        b.enqueue_features(regs[k % nq], *odo[k])
+    for k in range(n0, n0 + nq):
+        qa, ta, _ = a.process_features(regs[k % nq], *odo[k])
+        qb, tb, _ = b.collect()
+        assert np.array_equal(qa, qb) and np.array_equal(ta, tb), k
+    b.finish()
+    for which in (0, 1):
+        assert np.array_equal(_sorted_rows(a.export(which)), _sorted_rows(b.export(which)))
+    for x in regs + [od, a, b]:
+        x.close()

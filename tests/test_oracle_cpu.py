@@ -29,6 +29,29 @@ def test_kaist03_ring_ids_and_order(O, golden, name, float_math):
     assert 22000 <= f["less_flat"].shape[0] <= 24000
 
 
+def test_all_kaist03_sample_scans_pin_ring_ids_and_order(O):
+    """The wide form of the pin above, over EVERY keyframe the reference ships under utils/sample_data/KAIST03/Scans (21 files,
+    765,919 points - the count SURVEY.md section 8c measured): OS1-64 scanID of every point reproduced from xyz, ring-major
+    order = identity.  Reads the reference's data files where they lie (build container only; skipped on the GPU box, where
+    /root/reference does not exist); nothing from the reference is copied or shipped.  Seosan01's 21 keyframes cannot serve:
+    their fourth channel is the sensor's raw intensity (integers 3..7156), not scanID + 0.1 * relTime."""
+    import glob
+    from scaloam import formats
+    files = sorted(glob.glob("/root/reference/utils/sample_data/KAIST03/Scans/*.pcd"))
+    if not files:
+        pytest.skip("/root/reference/utils/sample_data is not on this host")
+    assert len(files) == 21
+    total = matched = 0
+    for f in files:
+        a = formats.read_pcd(f)
+        r = O.features(a[:, :3], O.OS1_64, 0.5)
+        assert r["rc"] == 0 and r["n_kept"] == a.shape[0], f
+        assert np.array_equal(r["src_index"], np.arange(a.shape[0])), f
+        matched += int((np.round(a[:, 3]).astype(int) == np.round(r["cloud"][:, 3]).astype(int)).sum())
+        total += a.shape[0]
+    assert total == 765919 and matched == total
+
+
 def test_ringkey_knn_matches_vendored_nanoflann(O):
     """D5: the oracle's brute-force f32 ring-key KNN vs the reference's own nanoflann (compiled into oracle/_ref)."""
     rng = np.random.default_rng(401)
