@@ -427,6 +427,68 @@ int scal_icp_align_device(scal_icp_t* ctx, const float* d_src_xyzi, int n_src, c
  * same correspondences, lowest target index on equal distances. */
 int scal_icp_set_search(scal_icp_t* ctx, int mode);
 
+/* ------------------------------------------------------------------ the four stages as ONE pipelined object
+ * The reference runs scanRegistration, laserOdometry, laserMapping and laserPosegraphOptimization as four processes that work on
+ * different scans at the same time (node main()s: scanRegistration.cpp:475-517, laserOdometry.cpp:186-600, laserMapping.cpp:909-952,
+ * laserPosegraphOptimization.cpp:874-906; hand-over by ROS topics with queue size 100).  scal_pipeline is that arrangement inside one
+ * process and one GPU: it owns a ring of features contexts, one odometry, one mapping and one ScanContext context, puts each stage on
+ * its own stream (scal_set_stream_mode(1) semantics) and keeps the schedule - which scan each stage may start, when a features
+ * context may be rewritten, how many stage-C steps are queued on the device - on three internal host threads (stage A + stage C's
+ * prefetch; stages B and C; ScanContext).  Scans go in with push, poses come out IN ORDER with pop; every scan passes through
+ * A -> B -> C and A -> D with the reference's data dependencies, and the poses are bit-identical to calling the four stage APIs one
+ * scan at a time.  A C++ host (host/replay_main.cpp) and bench.py drive the same object. */
+enum {
+    SCAL_PIPE_SC_OFF = 0,        /* stages A-C only */
+    SCAL_PIPE_SC_EVERY_SCAN = 1, /* makeAndSaveScancontextAndKeys + detectLoopClosureID for every scan (BASELINE config #2's "SC loop search" per scan) */
+    SCAL_PIPE_SC_DESCRIPTOR = 2  /* only build each scan's descriptor into device memory (sharded search: the caller exchanges it over RCCL) */
+};
+typedef struct {
+    int lidar_type, n_scans;      /* as scal_features_config */
+    double minimum_range;
+    int max_points;               /* capacity of one scan */
+    int float_math, check_finite;
+    float line_res, plane_res;    /* as scal_map_config */
+    int max_map_points;
+    double sc_max_radius, sc_dist_thres;
+    int sc_max_keyframes;
+    int sc_mode;                  /* SCAL_PIPE_SC_* */
+    int device;
+    int ring;                     /* features contexts used in turn: 4..16, 0 = 6 */
+    int depth;                    /* stage-C steps queued on the device and not collected: 1..3, 0 = 2 */
+} scal_pipeline_config;
+typedef struct {
+    long long seq;                        /* 0, 1, 2 ... in push order */
+    double q_w_curr[4], t_w_curr[3];      /* /aft_mapped_to_init (laserMapping.cpp:861-876) */
+    double q_odom[4], t_odom[3];          /* /laser_odom_to_init (laserOdometry.cpp:508-522) */
+    scal_odom_stats odom;
+    scal_map_stats map;
+    int have_loop;                        /* sc_mode 1: `loop` is detectLoopClosureID's answer with this scan as the query */
+    scal_sc_result loop;
+    const double* d_descriptor;           /* sc_mode 2: this scan's 20x60 descriptor in device memory (valid until `ring` more scans were pushed) */
+} scal_pipeline_result;
+typedef struct scal_pipeline scal_pipeline_t;
+int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeline_t** p);
+void scal_pipeline_destroy(scal_pipeline_t* p);
+/* One scan, xyz in device memory (stride in floats); returns as soon as the scan is registered - the buffer must stay valid until the
+ * scan's result has been popped.  Blocks only while `ring` scans are in flight; SCAL_E_STATE when 32 results wait to be popped. */
+int scal_pipeline_push_device(scal_pipeline_t* p, const float* d_xyz, int n, int stride_floats);
+/* The same from host memory (PointCloud2 layout, as scal_features_run): the scan is copied into pinned staging and uploaded on
+ * stage A's stream; the caller's buffer is free when the call returns. */
+int scal_pipeline_push_host(scal_pipeline_t* p, const void* xyz, int n, int stride_bytes);
+/* Result of the oldest scan not yet popped; blocks until its mapping pose (and, in sc_mode 1, its loop answer) is on the host.
+ * An error of any stage is returned here (and by every later call) with the failing stage's message in scal_last_error(). */
+int scal_pipeline_pop(scal_pipeline_t* p, scal_pipeline_result* out);
+/* waits until every pushed scan has its result ready AND the last scan's map insertion has finished; results stay queued for pop */
+int scal_pipeline_drain(scal_pipeline_t* p);
+/* scans pushed and not popped */
+int scal_pipeline_in_flight(scal_pipeline_t* p);
+/* the contexts inside (owned by the pipeline): pre-fill the ScanContext database, export the map, read statistics.  Only while the
+ * pipeline is drained. */
+scal_sc_t* scal_pipeline_sc(scal_pipeline_t* p);
+scal_map_t* scal_pipeline_map(scal_pipeline_t* p);
+scal_odom_t* scal_pipeline_odom(scal_pipeline_t* p);
+scal_features_t* scal_pipeline_features(scal_pipeline_t* p, int i);
+
 /* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
  * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,
  * for a host that keeps ceres::Problem orchestration.  kind: 0 LidarEdgeFactor(a,b),

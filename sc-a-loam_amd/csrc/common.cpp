@@ -74,6 +74,11 @@ int acquire_stream(int device, hipStream_t* out, int lane) {
     return SCAL_OK;
 }
 
+int stream_mode() {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    return g_stream_mode;
+}
+
 int stage_lane(int stage) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
     if (g_stream_mode == 0) return stage == STAGE_MAP_PREFETCH ? 2 : 0;

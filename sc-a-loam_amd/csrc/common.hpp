@@ -40,6 +40,7 @@ int select_device(int device);
 // of its kind (scal_sc_config::side_stream = 5: the sharded database next to the descriptor builder, bench.py --gpus N).
 enum { STAGE_FEATURES = 0, STAGE_SC = 1, STAGE_ODOM = 3, STAGE_MAP = 4, STAGE_MAP_PREFETCH = 2, STAGE_SC_FILTER = 5 };
 int stage_lane(int stage);
+int stream_mode();  // the value scal_set_stream_mode last set
 int acquire_stream(int device, hipStream_t* out, int lane = 0);
 void release_stream(int device, int lane = 0);
 

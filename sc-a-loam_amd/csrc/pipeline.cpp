@@ -1,0 +1,383 @@
+// scal_pipeline: the reference's four concurrently running nodes (scanRegistration.cpp:475-517, laserOdometry.cpp:186-600,
+// laserMapping.cpp:909-952, laserPosegraphOptimization.cpp:874-906) as one object on one GPU.  See include/scaloam_hip.h.
+//
+// The schedule (what round 2 kept in bench.py's Python threads) lives here, on three host threads that only ever queue work:
+//   front   stage A of scan k on features context k % ring, then stage C's pose-independent prefetch (input gather + stack filters);
+//           a features context is rewritten only when the scan that used it last has left stage C (pose collected), has been queued
+//           into stage B and has been handed to ScanContext (the library's reader events then order the device side);
+//   pose    stage B is queued up to two scans ahead of the pose it hands to stage C; the collected odometry pose goes straight into
+//           stage C's enqueue, which queues behind the stage-C steps still running on the device (`depth` uncollected);
+//   loop    ScanContext: keyframe filter + descriptor + insert + search per scan, answers collected one scan behind.
+// Nothing here touches the device except through the per-stage C-ABI, so the poses are those of the per-stage calls.
+#include "common.hpp"
+#include <condition_variable>
+#include <string>
+#include <thread>
+
+using namespace scal;
+
+namespace {
+constexpr int REC_N = 64;      // per-scan records (ring); at most 32 scans may be pushed and not popped
+constexpr int MAX_UNPOPPED = 32;
+constexpr int B_AHEAD = 2;     // stage-B steps queued and not collected
+constexpr int PF_AHEAD = 3;    // scal_map::MAX_PF: prefetches queued ahead of their steps
+
+struct Rec {
+    const float* d_xyz = nullptr;
+    const void* h_xyz = nullptr;
+    int n = 0, stride = 0;
+    bool host = false;
+    scal_pipeline_result res{};
+};
+}  // namespace
+
+struct scal_pipeline {
+    scal_pipeline_config cfg{};
+    int ring = 6, depth = 2;
+    std::vector<scal_features_t*> regs;
+    scal_odom_t* od = nullptr;
+    scal_map_t* mp = nullptr;
+    scal_sc_t* sc = nullptr;
+    double* d_desc = nullptr;  // sc_mode 2: ring x 1200 doubles
+    Rec rec[REC_N];
+    std::mutex mu;
+    std::condition_variable cv;
+    // monotone counters, all guarded by mu: scan k is "done" for a stage when counter > k
+    long long pushed = 0, a_done = 0, b_enq = 0, b_coll = 0, c_enq = 0, c_coll = 0, d_ins = 0, d_coll = 0, popped = 0;
+    int pop_waiting = 0;
+    bool drain_req = false, drained = true;
+    bool stop = false;
+    int err = SCAL_OK;
+    std::string errmsg;
+    std::thread t_front, t_pose, t_loop;
+
+    bool sc_on() const { return cfg.sc_mode != SCAL_PIPE_SC_OFF; }
+    Rec& r(long long k) { return rec[k % REC_N]; }
+    void fail(int rc) {  // called with mu held, from the thread whose stage call failed
+        if (err == SCAL_OK) {
+            err = rc;
+            errmsg = scal_last_error();
+        }
+        cv.notify_all();
+    }
+};
+
+namespace {
+
+void front_thread(scal_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        const long long k = p->a_done;
+        p->cv.wait(lk, [&] {
+            if (p->stop || p->err) return true;
+            if (p->pushed <= k) return false;
+            const long long old = k - p->ring;  // the scan that used this features context last
+            if (old >= 0 && (p->c_coll <= old || p->b_enq <= old || (p->sc_on() && p->d_ins <= old))) return false;
+            return k - p->c_enq < PF_AHEAD;     // prefetches queued ahead of their stage-C steps
+        });
+        if (p->stop || p->err) return;
+        Rec rc = p->r(k);
+        scal_features_t* reg = p->regs[k % p->ring];
+        lk.unlock();
+        int st = rc.host ? scal_features_enqueue_host(reg, rc.h_xyz, rc.n, rc.stride) : scal_features_run_device(reg, rc.d_xyz, rc.n, rc.stride);
+        if (st == SCAL_OK) st = scal_map_prefetch_features(p->mp, reg);
+        lk.lock();
+        if (st != SCAL_OK) {
+            p->fail(st);
+            return;
+        }
+        p->a_done = k + 1;
+        p->cv.notify_all();
+    }
+}
+
+void pose_thread(scal_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        enum { NONE, B_ENQ, B_COLL, C_COLL, FINISH } what = NONE;
+        p->cv.wait(lk, [&] {
+            if (p->stop || p->err) return true;
+            if (p->b_enq < p->a_done && p->b_enq - p->b_coll < B_AHEAD) { what = B_ENQ; return true; }
+            if (p->b_coll < p->b_enq) { what = B_COLL; return true; }
+            const long long inflight = p->c_enq - p->c_coll;
+            // A pose is collected when more than `depth` steps are queued on the device - or at once when the caller waits for it and
+            // nothing more can be queued meanwhile (every pushed scan is through stage B): never at the price of an empty queue.
+            if (inflight > p->depth || (inflight > 0 && (p->pop_waiting || p->drain_req) && p->b_coll == p->pushed)) { what = C_COLL; return true; }
+            if (p->drain_req && p->c_coll == p->pushed) { what = FINISH; return true; }
+            return false;
+        });
+        if (p->stop || p->err) return;
+        int st = SCAL_OK;
+        if (what == B_ENQ) {
+            const long long k = p->b_enq;
+            scal_features_t* reg = p->regs[k % p->ring];
+            lk.unlock();
+            st = scal_odom_enqueue_features(p->od, reg);
+            lk.lock();
+            if (st == SCAL_OK) p->b_enq = k + 1;
+        } else if (what == B_COLL) {
+            const long long k = p->b_coll;
+            scal_features_t* reg = p->regs[k % p->ring];
+            scal_pipeline_result& R = p->r(k).res;
+            lk.unlock();
+            double qlc[4], tlc[3];
+            st = scal_odom_collect(p->od, qlc, tlc, R.q_odom, R.t_odom, &R.odom);
+            if (st == SCAL_OK) st = scal_map_enqueue_features(p->mp, reg, R.q_odom, R.t_odom);  // the pose goes straight into stage C
+            lk.lock();
+            if (st == SCAL_OK) p->b_coll = k + 1, p->c_enq = k + 1;
+        } else if (what == C_COLL) {
+            const long long k = p->c_coll;
+            scal_pipeline_result& R = p->r(k).res;
+            lk.unlock();
+            st = scal_map_collect(p->mp, R.q_w_curr, R.t_w_curr, &R.map);
+            lk.lock();
+            if (st == SCAL_OK) p->c_coll = k + 1;
+        } else if (what == FINISH) {
+            lk.unlock();
+            st = scal_map_finish(p->mp);  // the last scan's map insertion (:738-802) belongs to the work
+            lk.lock();
+            if (st == SCAL_OK) p->drain_req = false, p->drained = true;
+        }
+        if (st != SCAL_OK) {
+            p->fail(st);
+            return;
+        }
+        p->cv.notify_all();
+    }
+}
+
+void loop_thread(scal_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    const bool search = p->cfg.sc_mode == SCAL_PIPE_SC_EVERY_SCAN;
+    for (;;) {
+        enum { NONE, INS, COLL } what = NONE;
+        p->cv.wait(lk, [&] {
+            if (p->stop || p->err) return true;
+            // Queueing comes first (it keeps the device fed; the context holds up to four searches / descriptors in flight); an answer
+            // is collected one scan behind its search - a whole period to finish - or as soon as somebody waits for it.
+            const long long infl = p->d_ins - p->d_coll;
+            if (p->d_ins < p->a_done && infl < 3) { what = INS; return true; }
+            if (infl >= 2 || (infl > 0 && (p->pop_waiting || p->drain_req))) { what = COLL; return true; }
+            return false;
+        });
+        if (p->stop || p->err) return;
+        int st = SCAL_OK;
+        if (what == INS) {
+            const long long k = p->d_ins;
+            scal_features_t* reg = p->regs[k % p->ring];
+            double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(k % p->ring) * 1200 : nullptr;
+            lk.unlock();
+            if (search) {
+                st = scal_sc_insert_features(p->sc, reg);
+                if (st == SCAL_OK) st = scal_sc_detect_enqueue(p->sc);
+            } else {
+                st = scal_sc_make_features_enqueue(p->sc, reg, dd);
+            }
+            lk.lock();
+            if (st == SCAL_OK) {
+                p->r(k).res.d_descriptor = dd;
+                p->d_ins = k + 1;
+            }
+        } else {
+            const long long k = p->d_coll;
+            scal_pipeline_result& R = p->r(k).res;
+            lk.unlock();
+            if (search) {
+                st = scal_sc_detect_collect(p->sc, &R.loop);
+                R.have_loop = st == SCAL_OK;
+            } else {
+                st = scal_sc_wait_descriptor(p->sc);
+            }
+            lk.lock();
+            if (st == SCAL_OK) p->d_coll = k + 1;
+        }
+        if (st != SCAL_OK) {
+            p->fail(st);
+            return;
+        }
+        p->cv.notify_all();
+    }
+}
+
+int report(scal_pipeline* p) {  // mu held
+    set_error("%s", p->errmsg.c_str());
+    return p->err;
+}
+
+int push(scal_pipeline* p, const float* d_xyz, const void* h_xyz, int n, int stride, bool host) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->err) return report(p);
+    if (p->pushed - p->popped >= MAX_UNPOPPED) {
+        set_error("scal_pipeline_push: %d results wait to be popped", MAX_UNPOPPED);
+        return SCAL_E_STATE;
+    }
+    const long long k = p->pushed;
+    Rec& rc = p->r(k);
+    rc = Rec();
+    rc.d_xyz = d_xyz, rc.h_xyz = h_xyz, rc.n = n, rc.stride = stride, rc.host = host;
+    rc.res.seq = k;
+    p->pushed = k + 1;
+    p->drained = false;
+    p->cv.notify_all();
+    // a host buffer belongs to the caller again when this returns: wait until stage A has staged it.  A device buffer is only
+    // registered; the call blocks while `ring` scans are in flight (back-pressure instead of an unbounded queue).
+    p->cv.wait(lk, [&] { return p->err || (host ? p->a_done > k : p->a_done + p->ring > k); });
+    if (p->err) return report(p);
+    return SCAL_OK;
+}
+
+}  // namespace
+
+extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeline_t** out) {
+    if (!cfg || !out) {
+        set_error("scal_pipeline_create: null argument");
+        return SCAL_E_ARG;
+    }
+    *out = nullptr;
+    const int ring = cfg->ring == 0 ? 6 : cfg->ring, depth = cfg->depth == 0 ? 2 : cfg->depth;
+    if (ring < 4 || ring > 16 || depth < 1 || depth > 3 || cfg->sc_mode < 0 || cfg->sc_mode > 2) {
+        set_error("scal_pipeline_create: ring must be 4..16, depth 1..3, sc_mode 0..2");
+        return SCAL_E_ARG;
+    }
+    SCAL_TRY(select_device(cfg->device));
+    const int mode_before = stream_mode();
+    SCAL_TRY(scal_set_stream_mode(1));  // one stream per stage; the contexts created below pick their lanes from it
+    auto* p = new scal_pipeline();
+    p->cfg = *cfg, p->ring = ring, p->depth = depth;
+    int rc = SCAL_OK;
+    scal_features_config fc{};
+    fc.lidar_type = cfg->lidar_type, fc.n_scans = cfg->n_scans, fc.minimum_range = cfg->minimum_range, fc.max_points = cfg->max_points;
+    fc.float_math = cfg->float_math, fc.check_finite = cfg->check_finite, fc.device = cfg->device;
+    for (int i = 0; i < ring && rc == SCAL_OK; ++i) {
+        scal_features_t* f = nullptr;
+        rc = scal_features_create(&fc, &f);
+        if (rc == SCAL_OK) p->regs.push_back(f);
+    }
+    if (rc == SCAL_OK) {
+        scal_odom_config oc{};
+        oc.max_points = cfg->max_points, oc.device = cfg->device;
+        rc = scal_odom_create(&oc, &p->od);
+    }
+    if (rc == SCAL_OK) {
+        scal_map_config mc{};
+        mc.line_res = cfg->line_res, mc.plane_res = cfg->plane_res, mc.max_scan_points = cfg->max_points, mc.max_map_points = cfg->max_map_points;
+        mc.device = cfg->device;
+        rc = scal_map_create(&mc, &p->mp);
+    }
+    if (rc == SCAL_OK && p->sc_on()) {
+        scal_sc_config sc{};
+        sc.max_radius = cfg->sc_max_radius, sc.dist_thres = cfg->sc_dist_thres, sc.max_keyframes = cfg->sc_max_keyframes;
+        sc.float_math = cfg->float_math, sc.device = cfg->device, sc.n_shards = 1, sc.shard = 0, sc.side_stream = 0;
+        rc = scal_sc_create(&sc, &p->sc);
+        if (rc == SCAL_OK && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR &&
+            hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(double) * 1200 * ring) != hipSuccess) {
+            set_error("scal_pipeline_create: hipMalloc of the descriptor ring failed");
+            rc = SCAL_E_HIP;
+        }
+    }
+    (void)scal_set_stream_mode(mode_before);  // the mode only matters while contexts are created
+    if (rc != SCAL_OK) {
+        const std::string keep = scal_last_error();
+        scal_pipeline_destroy(p);
+        set_error("%s", keep.c_str());
+        return rc;
+    }
+    p->t_front = std::thread(front_thread, p);
+    p->t_pose = std::thread(pose_thread, p);
+    if (p->sc_on()) p->t_loop = std::thread(loop_thread, p);
+    *out = p;
+    return SCAL_OK;
+}
+
+extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+        p->cv.notify_all();
+    }
+    if (p->t_front.joinable()) p->t_front.join();
+    if (p->t_pose.joinable()) p->t_pose.join();
+    if (p->t_loop.joinable()) p->t_loop.join();
+    (void)hipSetDevice(p->cfg.device);
+    // consumers first: their destructors wait for the streams that still read the features contexts
+    if (p->sc) scal_sc_destroy(p->sc);
+    if (p->mp) scal_map_destroy(p->mp);
+    if (p->od) scal_odom_destroy(p->od);
+    for (auto* f : p->regs) scal_features_destroy(f);
+    if (p->d_desc) (void)hipFree(p->d_desc);
+    delete p;
+}
+
+extern "C" int scal_pipeline_push_device(scal_pipeline_t* p, const float* d_xyz, int n, int stride_floats) {
+    if (!p || (!d_xyz && n > 0) || n < 0 || stride_floats < 3) {
+        set_error("scal_pipeline_push_device: bad argument");
+        return SCAL_E_ARG;
+    }
+    if (n > p->cfg.max_points) {
+        set_error("scan has %d points, capacity is %d", n, p->cfg.max_points);
+        return SCAL_E_TOO_MANY;
+    }
+    return push(p, d_xyz, nullptr, n, stride_floats, false);
+}
+
+extern "C" int scal_pipeline_push_host(scal_pipeline_t* p, const void* xyz, int n, int stride_bytes) {
+    if (!p || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || (stride_bytes % 4) != 0 || stride_bytes > 32) {
+        set_error("scal_pipeline_push_host: bad argument (stride_bytes must be a multiple of 4 in [12, 32])");
+        return SCAL_E_ARG;
+    }
+    if (n > p->cfg.max_points) {
+        set_error("scan has %d points, capacity is %d", n, p->cfg.max_points);
+        return SCAL_E_TOO_MANY;
+    }
+    return push(p, nullptr, xyz, n, stride_bytes, true);
+}
+
+extern "C" int scal_pipeline_pop(scal_pipeline_t* p, scal_pipeline_result* out) {
+    if (!p || !out) {
+        set_error("scal_pipeline_pop: null argument");
+        return SCAL_E_ARG;
+    }
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->popped >= p->pushed && !p->err) {
+        set_error("scal_pipeline_pop: nothing pushed");
+        return SCAL_E_STATE;
+    }
+    const long long k = p->popped;
+    p->pop_waiting++;
+    p->cv.notify_all();
+    p->cv.wait(lk, [&] { return p->err || (p->c_coll > k && (!p->sc_on() || p->d_coll > k)); });
+    p->pop_waiting--;
+    if (p->err) return report(p);
+    *out = p->r(k).res;
+    p->popped = k + 1;
+    p->cv.notify_all();
+    return SCAL_OK;
+}
+
+extern "C" int scal_pipeline_drain(scal_pipeline_t* p) {
+    if (!p) return SCAL_E_ARG;
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->err) return report(p);
+    if (p->drained) return SCAL_OK;
+    p->drain_req = true;
+    p->pop_waiting++;  // the loop thread collects its last answer, the pose thread every queued pose
+    p->cv.notify_all();
+    p->cv.wait(lk, [&] { return p->err || (p->drained && (!p->sc_on() || p->d_coll == p->pushed)); });
+    p->pop_waiting--;
+    if (p->err) return report(p);
+    return SCAL_OK;
+}
+
+extern "C" int scal_pipeline_in_flight(scal_pipeline_t* p) {
+    if (!p) return 0;
+    std::lock_guard<std::mutex> lk(p->mu);
+    return static_cast<int>(p->pushed - p->popped);
+}
+
+extern "C" scal_sc_t* scal_pipeline_sc(scal_pipeline_t* p) { return p ? p->sc : nullptr; }
+extern "C" scal_map_t* scal_pipeline_map(scal_pipeline_t* p) { return p ? p->mp : nullptr; }
+extern "C" scal_odom_t* scal_pipeline_odom(scal_pipeline_t* p) { return p ? p->od : nullptr; }
+extern "C" scal_features_t* scal_pipeline_features(scal_pipeline_t* p, int i) {
+    return (p && i >= 0 && i < static_cast<int>(p->regs.size())) ? p->regs[i] : nullptr;
+}

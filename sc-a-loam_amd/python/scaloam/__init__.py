@@ -88,6 +88,19 @@ class OdomStats(C.Structure):
                 ("cost_init", C.c_double * 2), ("cost_final", C.c_double * 2)]
 
 
+class PipelineConfig(C.Structure):
+    _fields_ = [("lidar_type", C.c_int), ("n_scans", C.c_int), ("minimum_range", C.c_double), ("max_points", C.c_int),
+                ("float_math", C.c_int), ("check_finite", C.c_int), ("line_res", C.c_float), ("plane_res", C.c_float),
+                ("max_map_points", C.c_int), ("sc_max_radius", C.c_double), ("sc_dist_thres", C.c_double), ("sc_max_keyframes", C.c_int),
+                ("sc_mode", C.c_int), ("device", C.c_int), ("ring", C.c_int), ("depth", C.c_int)]
+
+
+class PipelineResult(C.Structure):
+    _fields_ = [("seq", C.c_longlong), ("q_w_curr", C.c_double * 4), ("t_w_curr", C.c_double * 3), ("q_odom", C.c_double * 4),
+                ("t_odom", C.c_double * 3), ("odom", OdomStats), ("map", MapStats), ("have_loop", C.c_int), ("loop", SCResult),
+                ("d_descriptor", C.c_void_p)]
+
+
 # every symbol include/scaloam_hip.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = [
     "scal_last_error", "scal_device_count", "scal_version", "scal_prof_enable", "scal_prof_filter", "scal_prof_reset", "scal_prof_read", "scal_prof_names", "scal_prof_timeline", "scal_prof_timeline_dump",
@@ -103,6 +116,8 @@ EXPORTED_SYMBOLS = [
     "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_align_device", "scal_icp_set_search",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
     "scal_factors_eval",
+    "scal_pipeline_create", "scal_pipeline_destroy", "scal_pipeline_push_device", "scal_pipeline_push_host", "scal_pipeline_pop", "scal_pipeline_drain",
+    "scal_pipeline_in_flight", "scal_pipeline_sc", "scal_pipeline_map", "scal_pipeline_odom", "scal_pipeline_features",
 ]
 
 _lib = None
@@ -220,6 +235,19 @@ def lib():
     L.scal_odom_enqueue_features.argtypes = [vp, vp]
     L.scal_odom_collect.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, C.POINTER(OdomStats)]
     L.scal_factors_eval.argtypes = [C.c_int, C.c_int, _i32p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.scal_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.POINTER(vp)]
+    L.scal_pipeline_destroy.argtypes = [vp]
+    L.scal_pipeline_destroy.restype = None
+    L.scal_pipeline_push_device.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.scal_pipeline_push_host.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.scal_pipeline_pop.argtypes = [vp, C.POINTER(PipelineResult)]
+    L.scal_pipeline_drain.argtypes = [vp]
+    L.scal_pipeline_in_flight.argtypes = [vp]
+    for fn in ("scal_pipeline_sc", "scal_pipeline_map", "scal_pipeline_odom"):
+        getattr(L, fn).restype = C.c_void_p
+        getattr(L, fn).argtypes = [vp]
+    L.scal_pipeline_features.restype = C.c_void_p
+    L.scal_pipeline_features.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -804,3 +832,59 @@ def factors_eval(kind, cp, pa, pb, x7, device=0):
     _check(lib().scal_factors_eval(device, kind.shape[0], _p(kind, _i32p), _p(cp, _f64p), _p(pa, _f64p), _p(pb, _f64p), _p(x7, _f64p),
                                    _p(cost, _f64p), _p(g, _f64p), _p(H, _f64p)))
     return cost[0], g, H
+
+
+# ---------------------------------------------------------------------------------------------- the four stages as one object
+SC_OFF, SC_EVERY_SCAN, SC_DESCRIPTOR = 0, 1, 2
+
+
+def _borrow(cls, handle):
+    """A wrapper of `cls` around a context that somebody else (a Pipeline) owns: same methods, close() does nothing."""
+    o = cls.__new__(cls)
+    o.h = C.c_void_p(handle)
+    o.close = lambda: None
+    return o
+
+
+class Pipeline:
+    """scal_pipeline: the reference's four nodes (scanRegistration, laserOdometry, laserMapping, laserPosegraphOptimization's
+    ScanContext part) working on consecutive scans at the same time, scheduled inside the library.  push() a scan, pop() poses in order."""
+
+    def __init__(self, lidar_type, minimum_range, max_points=400000, line_res=0.4, plane_res=0.8, max_map_points=4000000, sc_mode=SC_EVERY_SCAN,
+                 sc_max_radius=80.0, sc_dist_thres=0.2, sc_max_keyframes=8192, device=0, ring=0, depth=0, float_math=0, check_finite=1):
+        self.cfg = PipelineConfig(lidar_type, SCAN_LINES.get(lidar_type, 0), float(minimum_range), max_points, float_math, check_finite, line_res,
+                                  plane_res, max_map_points, sc_max_radius, sc_dist_thres, sc_max_keyframes, sc_mode, device, ring, depth)
+        self.h = C.c_void_p()
+        _check(lib().scal_pipeline_create(C.byref(self.cfg), C.byref(self.h)))
+        self.sc = _borrow(SCManager, lib().scal_pipeline_sc(self.h)) if sc_mode != SC_OFF else None
+        self.map = _borrow(LaserMapping, lib().scal_pipeline_map(self.h))
+        self.odom = _borrow(LaserOdometry, lib().scal_pipeline_odom(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.scal_pipeline_destroy(self.h)
+        self.h = None
+
+    __del__ = close
+
+    def push_device(self, d_ptr, n, stride_floats=3):
+        _check(lib().scal_pipeline_push_device(self.h, C.c_void_p(d_ptr), n, stride_floats))
+
+    def push(self, xyz):
+        a = _f32(xyz)
+        _check(lib().scal_pipeline_push_host(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]))
+
+    def pop(self):
+        r = PipelineResult()
+        _check(lib().scal_pipeline_pop(self.h, C.byref(r)))
+        return dict(seq=r.seq, q=np.array(r.q_w_curr[:]), t=np.array(r.t_w_curr[:]), q_odom=np.array(r.q_odom[:]), t_odom=np.array(r.t_odom[:]),
+                    odom=r.odom, map=r.map, loop=SCManager._result(r.loop) if r.have_loop else None, d_descriptor=r.d_descriptor)
+
+    def drain(self):
+        _check(lib().scal_pipeline_drain(self.h))
+
+    def in_flight(self):
+        return lib().scal_pipeline_in_flight(self.h)
+
+    def features(self, i):
+        return _borrow(ScanRegistration, lib().scal_pipeline_features(self.h, i))
