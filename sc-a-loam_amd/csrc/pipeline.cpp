@@ -98,8 +98,9 @@ void pose_thread(scal_pipeline* p) {
         p->cv.wait(lk, [&] {
             if (p->stop || p->err) return true;
             if (p->b_enq < p->a_done && p->b_enq - p->b_coll < B_AHEAD) { what = B_ENQ; return true; }
-            if (p->b_coll < p->b_enq) { what = B_COLL; return true; }
             const long long inflight = p->c_enq - p->c_coll;
+            // collecting stage B's pose queues the scan's stage-C step: at most depth + 1 of them in flight (scal_map allows 4)
+            if (p->b_coll < p->b_enq && inflight <= p->depth) { what = B_COLL; return true; }
             // A pose is collected when more than `depth` steps are queued on the device - or at once when the caller waits for it and
             // nothing more can be queued meanwhile (every pushed scan is through stage B): never at the price of an empty queue.
             if (inflight > p->depth || (inflight > 0 && (p->pop_waiting || p->drain_req) && p->b_coll == p->pushed)) { what = C_COLL; return true; }

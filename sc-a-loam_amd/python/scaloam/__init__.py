@@ -840,9 +840,9 @@ SC_OFF, SC_EVERY_SCAN, SC_DESCRIPTOR = 0, 1, 2
 
 def _borrow(cls, handle):
     """A wrapper of `cls` around a context that somebody else (a Pipeline) owns: same methods, close() does nothing."""
-    o = cls.__new__(cls)
+    sub = type(cls.__name__ + "Borrowed", (cls,), {"close": lambda self: None, "__del__": lambda self: None})
+    o = sub.__new__(sub)
     o.h = C.c_void_p(handle)
-    o.close = lambda: None
     return o
 
 

@@ -121,3 +121,27 @@ def read_kitti_bin(path):
 
 def write_kitti_bin(path, xyzi):
     np.ascontiguousarray(xyzi, "<f4").reshape(-1, 4).tofile(path)
+
+
+def write_scan_stream(path, scans):
+    """A recorded sequence of raw scans for the C++ replay host (sc-a-loam_amd/host/replay_main.cpp): "SCALSCN1", int32 count, then
+    per scan int32 n + n x 3 float32 xyz.  No counterpart in the reference (its input is a rosbag / KITTI .bin directory)."""
+    with open(path, "wb") as f:
+        f.write(b"SCALSCN1")
+        f.write(np.int32(len(scans)).tobytes())
+        for s in scans:
+            a = np.ascontiguousarray(np.asarray(s, np.float32)[:, :3])
+            f.write(np.int32(a.shape[0]).tobytes())
+            f.write(a.tobytes())
+
+
+def read_scan_stream(path):
+    with open(path, "rb") as f:
+        if f.read(8) != b"SCALSCN1":
+            raise ValueError(f"{path} is not a scan stream file")
+        count = int(np.frombuffer(f.read(4), np.int32)[0])
+        out = []
+        for _ in range(count):
+            n = int(np.frombuffer(f.read(4), np.int32)[0])
+            out.append(np.frombuffer(f.read(12 * n), np.float32).reshape(n, 3).copy())
+        return out

@@ -36,6 +36,16 @@ def test_header_is_plain_c99():
         assert r.returncode == 0, r.stderr
 
 
+def test_plain_c_caller_links_and_runs(S):
+    """sc-a-loam_amd/host/abi_check.c is compiled by `gcc -std=c99 -pedantic-errors -Werror` against the public header and linked with
+    the shared library (Makefile target bin/abi_check): the boundary is a C ABI, usable without hipcc or any C++."""
+    exe = os.path.join(ROOT, "sc-a-loam_amd", "bin", "abi_check")
+    assert os.path.exists(exe), "make -C sc-a-loam_amd builds bin/abi_check"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("abi ok"), (r.stdout, r.stderr)
+    assert os.path.exists(os.path.join(ROOT, "sc-a-loam_amd", "bin", "replay_main"))   # the C++ host builds as well
+
+
 def test_no_cpu_fallback_and_oracle_is_not_linked(S):
     import torch
     if torch.cuda.is_available():
