@@ -3,32 +3,37 @@
 ScanContext loop search on KITTI-like HDL-64 scans (~120k points), one MI355X per process.
 
 A "step" is one scan through the whole hot path on one GPU, inputs already resident in HBM:
-  stage A  scal_features_run_device                      (scanRegistration.cpp:134-421)
-  stage B  scal_odom_enqueue_features / scal_odom_collect  (laserOdometry.cpp:267-568)   - provides the prior for stage C
-  stage C  scal_map_prefetch_features / _enqueue_features / _collect (laserMapping.cpp:310-802,:845-849)   2 outer x <=4 LM iterations
-  stage D  scal_sc_insert_features + scal_sc_detect_*    (Scancontext.cpp:151-260, :336-427) over a pre-filled keyframe DB
-Default schedule: stage-pipelined - every stage on its own stream and consecutive scans overlapping, the way the reference's four
-ROS nodes (scanRegistration, laserOdometry, laserMapping, laserPosegraphOptimization) process different scans at the same time;
-every scan still goes through A -> B -> C and A -> D with the reference's data dependencies (C(k) registers against the map that
-contains scan k-1), and the K timed steps end only when the last scan's map insertion is done.  --no-overlap runs one scan
-at a time on one stream; both schedules give bit-identical poses (tools/gpu_sched_check.sh).
-N > 1 (one process per GPU, torch.distributed/RCCL): stages A-C do not shard (pose k+1 depends on pose k and on the
-map), so every rank replays its own seeded sequence ("replicas only", weak scaling); the ScanContext keyframe database
-IS sharded (keyframe i on rank i % N) and every step exchanges descriptors and per-shard top-3 records with two RCCL
-all-gathers.
+  stage A  feature extraction                 (scanRegistration.cpp:134-421)
+  stage B  scan-to-scan odometry              (laserOdometry.cpp:267-568)   - provides the prior for stage C
+  stage C  scan-to-map, 2 outer x <=4 LM its  (laserMapping.cpp:310-802, :845-849)
+  stage D  ScanContext insert + loop search   (Scancontext.cpp:151-260, :336-427) over a pre-filled keyframe database
+Default schedule: scal_pipeline (include/scaloam_hip.h) - the four stages on their own streams with consecutive scans overlapping,
+the way the reference's four ROS nodes (scanRegistration, laserOdometry, laserMapping, laserPosegraphOptimization) work on different
+scans at the same time.  The schedule lives INSIDE the library (three C++ host threads); this file only pushes scans and pops poses,
+exactly what the C++ host sc-a-loam_amd/host/replay_main.cpp does.  Every scan still goes through A -> B -> C and A -> D with the
+reference's data dependencies, and the K timed steps end only when the last scan's map insertion is done.  --no-overlap runs one
+scan at a time through the per-stage calls on one stream; both schedules give bit-identical poses (`final_map_pose`).
+N > 1 (one process per GPU, torch.distributed/RCCL): stages A-C do not shard (pose k+1 depends on pose k and on the map), so every
+rank replays its own seeded sequence ("replicas only", weak scaling); the ScanContext keyframe database IS sharded (keyframe i on
+rank i % N): descriptors and per-shard top-3 records are exchanged with two RCCL all-gathers per --sc-exchange-every scans
+(SURVEY.md section 8e).
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launching stream for the
-dominant kernel over the timed region; `cpu_baseline` is the oracle (CPU restatement of the reference path) timed on
-this host's cores on a bounded sample of the same scans (rank 0, N=1 only).
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the launching streams (dominant kernel over the
+timed region, per-stage lines from extra untimed steps); `cpu_baseline` is the oracle (CPU restatement of the reference path) timed
+on this host's cores on a bounded sample of the same scans (rank 0, N=1 only); `as_integrated` is the C++ host replaying the first
+scans through the synchronous host-array entry points, one thread per stage, as INTEGRATION.md has a maintainer wire them.
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
-# The stage pipeline keeps five HIP streams busy (A, B, C, C's prefetch, D) next to torch's; the runtime multiplexes streams
-# onto 4 hardware queues by default, which would serialise stages that share a queue.  Must be set before HIP initialises.
+# four busy HIP streams next to torch's; the runtime multiplexes streams onto 4 hardware queues by default, which would serialise
+# stages that share a queue.  Must be set before HIP initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -38,6 +43,8 @@ for p in ("oracle", os.path.join("sc-a-loam_amd", "python"), os.path.join("tools
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REPLAY = os.path.join(ROOT, "sc-a-loam_amd", "bin", "replay_main")
+METRIC = "scans/sec (feat-extract + scan-to-map ICP + SC loop search), KITTI HDL-64"
 
 
 def parse():
@@ -48,35 +55,92 @@ def parse():
     ap.add_argument("--rate", type=float, default=10.0, help="config 3, realtime: scans per second of the replay (10 Hz sensor)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--reps", type=int, default=3, help="the timed region of K steps is run this many times on consecutive scans; value = median")
+    ap.add_argument("--reps", type=int, default=3, help="the timed region of K steps is run at least this many times on consecutive scans; value = median")
+    ap.add_argument("--min-timed-s", type=float, default=0.3, help="repetitions are added until the timed regions together last about this long "
+                    "(a 20-step region is ~6 ms: three of those are three noisy samples)")
     ap.add_argument("--h2d", type=int, default=1, help="N=1: one more repetition with every scan uploaded from host memory inside the timed region (reported beside value)")
     ap.add_argument("--sc-db", type=int, default=5000, help="keyframes pre-filled into the ScanContext database")
+    ap.add_argument("--sc-revisits", type=int, default=-1, help="of those, keyframes that are earlier visits of the places the timed scans see, re-rendered "
+                    "with a random heading and 0.5 m lateral offset (true loops exist); -1 = one per three scans of the sequence")
     ap.add_argument("--cpu-sample", type=int, default=60, help="scans timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpp-sample", type=int, default=60, help="scans the C++ host (replay_main) replays as integrated / through scal_pipeline (0 = skip)")
     ap.add_argument("--seed", type=int, default=205)
-    ap.add_argument("--side-thread", type=int, default=2, help="host threads besides the main one that queue work: 0 = none, 1 = one for stage A + "
-                    "stage C's prefetch + ScanContext, 2 = ScanContext on its own thread, 3 = stage B too: four host threads, as the "
-                    "reference runs four processes (the main thread keeps stage C)")
-    ap.add_argument("--ring", type=int, default=6, help="features contexts used in turn by the stage pipeline")
-    ap.add_argument("--host-timing", action="store_true", help="report the host time spent inside each library call (us per step)")
-    ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream (no stage pipelining)")
+    ap.add_argument("--ring", type=int, default=6, help="features contexts used in turn by the pipeline")
+    ap.add_argument("--depth", type=int, default=2, help="stage-C steps queued on the device and not collected")
+    ap.add_argument("--ahead", type=int, default=4, help="scans pushed beyond the one whose pose is awaited")
+    ap.add_argument("--no-overlap", action="store_true", help="one scan at a time on one stream through the per-stage calls (no pipeline)")
+    ap.add_argument("--sc-exchange-every", type=int, default=1, help="N > 1: scans whose descriptors / candidate records travel in one pair of all-gathers "
+                    "(the reference searches at 1 Hz, laserPosegraphOptimization.cpp:732-741; answers are identical for every value)")
     ap.add_argument("--prof-every", type=int, default=8,
                     help="0 = no kernel timing at all; otherwise the two LM solve kernels (the roofline line) carry start/stop timestamps on every "
                          "N-th step of the timed region, and every instrumented kernel on --prof-steps extra steps behind it (outside the timing)")
     ap.add_argument("--prof-steps", type=int, default=24, help="extra, untimed steps with per-kernel timestamps on every launch (kernel_ms_per_step)")
     ap.add_argument("--timeline-kernels", default="", help="with --timeline: only these kernels (comma separated), over the whole timed region")
     ap.add_argument("--timeline", default="", help="development aid: write (kernel, start ms, stop ms) of every dispatch of six timed steps to this CSV")
-    ap.add_argument("--sync-dir", default="", help="start the timed region together with --sync-n other bench.py processes (ready files in this directory)")
-    ap.add_argument("--sync-n", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
     return ap.parse_args()
 
 
 def synth_descs(rng, n):
-    """ScanContext-like descriptors (occupancy ~0.5, heights -2..18 m, a few empty sectors; SURVEY.md section 8d #4)."""
+    """ScanContext-like filler descriptors (occupancy ~0.5, heights -2..18 m, a few empty sectors; SURVEY.md section 8d #4)."""
     d = rng.uniform(-2.0, 18.0, (n, 60, 20)) * (rng.uniform(size=(n, 60, 20)) < 0.5)
     for i in range(n):
         d[i, rng.integers(0, 60, 3), :] = 0.0
     return d  # [n][sector][ring] == column-major 20x60
+
+
+def revisit_descriptors(S, world_gen, ks, cap, device, seed):
+    """Descriptors of EARLIER VISITS of places the sequence passes (SURVEY.md section 8d #4 "revisits = earlier places re-rendered
+    with yaw U(0, 2 pi) and 0.5 m lateral offset"): pose of scan k turned by a random heading and moved 0.5 m sideways, rendered by
+    the same sensor model with its own noise, through stage A and makeScancontext on the GPU.  Returned as [ring, sector] arrays."""
+    if not ks:
+        return []
+    rng = np.random.default_rng(seed)
+    reg = S.ScanRegistration(S.HDL64, 5.0, max_points=cap, device=device)
+    sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=len(ks) + 8, device=device)
+    out = []
+    for i, k in enumerate(ks):
+        q, t = world_gen.pose(k)
+        psi = rng.uniform(0.0, 2.0 * np.pi)
+        qz = np.array([0.0, 0.0, np.sin(psi / 2), np.cos(psi / 2)])
+        # q' = q * Rz(psi), storage (x, y, z, w)
+        a, b = q, qz
+        q2 = np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2],
+                       a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+        yaw = 2.0 * np.arctan2(q[2], q[3])
+        side = 0.5 if (i & 1) else -0.5
+        t2 = t + side * np.array([-np.sin(yaw), np.cos(yaw), 0.0])
+        xyz = world_gen.scan_pose(q2, t2, 700001 + 13 * k)
+        reg.laserCloudHandler(xyz)
+        sc.insert_features(reg)
+        out.append(sc.get(i)[0])
+    reg.close(), sc.close()
+    return out
+
+
+def build_database(S, world_gen, a, n_scans, cap, device):
+    """The pre-filled keyframe database: revisits of the sequence's own places first (oldest keyframes: inside every query's tree and
+    outside its 30 newest), filler descriptors behind them."""
+    n_rev = a.sc_revisits if a.sc_revisits >= 0 else n_scans // 3
+    n_rev = max(0, min(n_rev, a.sc_db))
+    ks = [int(round(j * (n_scans - 1) / max(1, n_rev - 1))) for j in range(n_rev)] if n_rev else []
+    rev = revisit_descriptors(S, world_gen, ks, cap, device, 401)
+    fill = synth_descs(np.random.default_rng(4242), a.sc_db - len(rev))
+    return rev + [d.T for d in fill], len(rev)
+
+
+def cpp_host(mode, stream_file, n_warm, sc_db, resident=0, timeout=600):
+    """The C++ host (sc-a-loam_amd/host/replay_main.cpp: includes include/scaloam_hip.h, links libscaloam_hip.so) as a child process."""
+    if not os.path.exists(REPLAY):
+        return {"error": "sc-a-loam_amd/bin/replay_main is not built"}
+    try:
+        r = subprocess.run([REPLAY, "--scans", stream_file, "--mode", mode, "--warmup", str(n_warm), "--sc-db", str(sc_db), "--resident", str(resident)],
+                           capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            return {"error": f"replay_main rc {r.returncode}: {r.stderr[-300:]}"}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except (OSError, ValueError, subprocess.TimeoutExpired) as e:
+        return {"error": str(e)}
 
 
 def run_stream(a):
@@ -89,7 +153,7 @@ def run_stream(a):
     import scansynth
     from scaloam.pgo import KeyframeGate
     K, W = a.steps, a.warmup
-    world_gen = scansynth.World(scansynth.OS1_64, 301, threads=os.cpu_count() or 8)
+    world_gen = scansynth.World(scansynth.OS1_64, 301, threads=min(16, len(os.sched_getaffinity(0))))
     scans = [world_gen.scan(k) for k in range(W + K)]
     cap = max(s.shape[0] for s in scans) + 1024
     d_scans = [torch.from_numpy(s).cuda() for s in scans]
@@ -102,11 +166,13 @@ def run_stream(a):
         sc.saveScancontextAndKeys(d.T)
     gate = KeyframeGate(1.0, 10.0)
     out = dict(keyframes=0, loops=0, dropped=0, lat=[])
+    lm = dict(map=0.0, map_launches=0, odom=0.0, odom_launches=0, map_blocks=0, map_evals=0)
 
     def one(k, t_arrival=None):
         reg.run_device(d_scans[k].data_ptr(), scans[k].shape[0], 3)
-        qlc, tlc, qw, tw, _ = od.step_features(reg)
-        qm, tm, _ = mp.process_features(reg, qw, tw)
+        qlc, tlc, qw, tw, ost = od.step_features(reg)
+        qm, tm, mst = mp.process_features(reg, qw, tw)
+        lm_account(lm, "odom", ost), lm_account(lm, "map", mst)
         if t_arrival is not None:
             out["lat"].append(time.perf_counter() - t_arrival)
         if gate(qm, tm):
@@ -118,6 +184,10 @@ def run_stream(a):
     for k in range(W):
         one(k)
     torch.cuda.synchronize()
+    for key in lm:
+        lm[key] = 0
+    S.prof_reset()
+    S.prof_enable(a.prof_every > 0, "k_lm_solve_map,k_lm_solve_odom")
     t0 = time.perf_counter()
     if a.replay == "lockstep":
         for k in range(W, W + K):
@@ -141,7 +211,13 @@ def run_stream(a):
             k = newest + 1
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    S.prof_enable(False)
+    prof = S.prof_read_all()
     lat = np.array(out["lat"]) * 1e3 if out["lat"] else None
+    roofline = roofline_of(prof, dict(lm=lm), False)
+    cpu = None
+    if a.cpu_sample > 0:
+        cpu = cpu_baseline(scans[: min(len(scans), a.cpu_sample)], a.sc_db, sensor="OS1_64", min_range=0.5, sc_thres=0.2, gate=(1.0, 10.0))
     print(json.dumps({
         "metric": "scans/sec, MulRan-like OS1-64 stream: full odom + mapping, ScanContext on keyframes (BASELINE config #3)",
         "value": K / dt, "unit": "scans/s", "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
@@ -149,9 +225,25 @@ def run_stream(a):
         "config": {"workload": "OS1-64 (64 beams x 1024 columns, seed 301, minimum_range 0.5, line/plane 0.4/0.8, keyframe gap 1 m / 10 deg, "
                                "sc_dist_thres 0.2), replay " + a.replay + (f" at {a.rate:g} Hz" if a.replay != "lockstep" else ""),
                    "points_per_scan_in": int(np.mean([s.shape[0] for s in scans])), "sc_db_keyframes": a.sc_db},
+        "roofline": roofline, "cpu_baseline": cpu,
         "keyframes": out["keyframes"], "loops_detected": int(out["loops"]), "scans_dropped_by_mapping": out["dropped"],
         "latency_ms": None if lat is None else {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "max": float(lat.max())},
         "final_map_pose": {"q": pose[0].tolist(), "t": pose[1].tolist()}}))
+
+
+def lm_account(lm, which, st_):
+    """algorithmic bytes of the LM solves (SURVEY.md section 8d: 72 B per edge block, 56 B per plane block, read once per evaluation;
+    evaluations of a solve = 1 + its iterations), stage C and stage B separately"""
+    for o in range(2):
+        ne, npl, it = st_.n_edge[o], st_.n_plane[o], st_.lm_iters[o]
+        if ne + npl == 0:
+            continue
+        lm[which] += (72.0 * ne + 56.0 * npl) * (1 + it)
+        lm[which + "_E"] = lm.get(which + "_E", 0.0) + 72.0 * ne + 56.0 * npl
+        lm[which + "_launches"] += 1
+        if which == "map":
+            lm["map_blocks"] += ne + npl
+            lm["map_evals"] += 1 + it
 
 
 def main():
@@ -187,337 +279,206 @@ def main():
             out_t.copy_(torch.stack(parts).reshape(out_t.shape))
     import scaloam as S
     import scansynth
+    from scaloam.sharded import TreePeriodBook
 
     K, W = a.steps, a.warmup
-    R = max(1, a.reps)
+    # enough repetitions that the timed regions together last ~min_timed_s (estimated at 0.3 ms per step), at most 1600 timed steps
+    R = max(1, a.reps, min(int(math.ceil(a.min_timed_s / (K * 0.3e-3))), max(1, 1600 // K)))
     do_h2d = bool(a.h2d) and world == 1
     P_STEPS = a.prof_steps if (a.prof_every > 0 and not a.timeline) else 0
     total = W + K * (R + (1 if do_h2d else 0)) + P_STEPS
-    # ---- synthetic HDL-64 sequence for this rank (weak scaling: one independent sequence per GPU)
-    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    # ---- synthetic HDL-64 sequence for this rank (weak scaling: one independent sequence per GPU).  The trajectory is a 100 m
+    # circle at 1 m per scan: after 628 scans the vehicle drives through places it has mapped before.
+    threads = max(1, min(16, len(os.sched_getaffinity(0))) // max(1, world))
     world_gen = scansynth.World(scansynth.HDL64, a.seed + 1000 * rank, threads=threads)
     t0 = time.time()
     scans = [world_gen.scan(k) for k in range(total)]
     gen_s = time.time() - t0
     npts = [s.shape[0] for s in scans]
     d_scans = [torch.from_numpy(s).cuda(local) for s in scans]  # inputs resident in HBM before the timed region
-    cap = max(npts) + 1024
+    cap = min(400000, max(npts) + 1024)
+    t0 = time.time()
+    descs, n_rev = build_database(S, world_gen, a, total, cap, local)
+    db_s = time.time() - t0
 
     pipelined = not a.no_overlap
-    # One stream per stage, consecutive scans overlapping like the reference's four ROS nodes (scanRegistration, laserOdometry,
-    # laserMapping, laserPosegraphOptimization run concurrently on different scans); two features contexts used alternately.
-    S.set_stream_mode(1 if pipelined else 0)
-    # pipelined: a features context is not run again before the stage-C step that used it has been collected (scal_map_enqueue_features)
-    regs = [S.ScanRegistration(S.HDL64, 5.0, max_points=min(400000, cap), device=local) for _ in range((max(a.ring, 8) if world > 1 else a.ring) if pipelined else 1)]  # N > 1: the exchange thread may lag 3 scans
-    reg = regs[0]
-    od = S.LaserOdometry(max_points=cap, device=local)
-    mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
-    # N > 1, pipelined: the database shard gets its own stream (lane 5) so that its small insert/query kernels never queue behind
-    # the next scan's descriptor build, which runs in a separate builder context on the stage-D stream
-    sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=a.sc_db // world + total * world + 64, device=local,
-                     n_shards=world, shard=rank, side_stream=5 if (pipelined and world > 1) else 0)
-    sc_build = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=8, device=local) if (pipelined and world > 1) else None
-    rng = np.random.default_rng(4242)
-    for d in synth_descs(rng, a.sc_db):
-        sc.saveScancontextAndKeys(d.T)  # every shard sees every insert and keeps the ones it owns
-
-    if world > 1:
-        d_q = [torch.zeros(1200, dtype=torch.float64, device="cuda") for _ in range(2)]  # scan k+1's descriptor is queued early
-        all_q = torch.zeros(world, 1200, dtype=torch.float64, device="cuda")
-        d_rec = torch.zeros(world * 3 * 24, dtype=torch.uint8, device="cuda")
-        all_rec = torch.zeros(world, world * 3 * 24, dtype=torch.uint8, device="cuda")
-    sc_state = dict(counter=0, size_at_rebuild=0, n_global=a.sc_db)
-    stats = dict(loops=0, blocks=0, stack_pts=0, solved=0, map_pts=0)
-    # algorithmic bytes of the LM solves (72 B per edge block, 56 B per plane block, read once per evaluation;
-    # evaluations of a solve = 1 + its iterations), stage C and stage B separately
+    Q = max(1, min(a.sc_exchange_every, 64 // max(1, world)))
+    ring = max(a.ring, 8) if world > 1 else a.ring
+    stats = dict(loops=0, blocks=0, stack_pts=0, solved=0, map_pts=0, win_pts=0, edge=0, plane=0, evals=0, odom_blocks=0, odom_evals=0)
     lm_bytes = dict(map=0.0, map_launches=0, odom=0.0, odom_launches=0, map_blocks=0, map_evals=0)
-
-    def lm_account(which, st_):
-        for o in range(2):
-            ne, npl, it = st_.n_edge[o], st_.n_plane[o], st_.lm_iters[o]
-            if ne + npl == 0:
-                continue
-            lm_bytes[which] += (72.0 * ne + 56.0 * npl) * (1 + it)
-            lm_bytes[which + "_launches"] += 1
-            if which == "map":
-                lm_bytes["map_blocks"] += ne + npl
-                lm_bytes["map_evals"] += 1 + it
-
-    host_t = {}
-
-    def timed(name, fn, *args):
-        if not a.host_timing:
-            return fn(*args)
-        t = time.perf_counter()
-        r = fn(*args)
-        host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
-        return r
-
-    sc_ext = torch.cuda.ExternalStream(sc.stream_ptr()) if (world > 1 and a.backend == "nccl") else None
-
-    def sc_sharded(k, queued=False):
-        """stage D with the database sharded over the ranks: two all-gathers (descriptors, candidate records).  Under RCCL the
-        collectives (torch's stream) and the shard's kernels (the library's stream, scal_sc_stream) are ordered against each other
-        on the device; the host only waits for the final records.  The gloo rehearsal stages through the host and synchronises."""
-        if queued:
-            sc_build.wait_descriptor()  # the oldest queued descriptor (scan k); younger builds keep running
-        else:
-            sc.make_features(reg, d_q[k % 2].data_ptr())
-        all_gather(all_q, d_q[k % 2])
-        if sc_ext is not None:
-            sc_ext.wait_stream(torch.cuda.current_stream())
-        else:
-            torch.cuda.current_stream().synchronize()
-        sc.insert_descriptors_device(all_q.data_ptr(), world)  # global insertion order: rank 0..N-1 of this step, one launch
-        sc_state["n_global"] += world
-        # detectLoopClosureID's tree period (Scancontext.cpp:353-365), one query per rank in global order
-        limits = []
-        for rr in range(world):
-            if sc_state["counter"] % 30 == 0:
-                sc_state["size_at_rebuild"] = sc_state["n_global"]
-            sc_state["counter"] += 1
-            limits.append(sc_state["size_at_rebuild"])
-        sc.shard_query_batch_device(all_q.data_ptr(), limits, d_rec.data_ptr())  # every query against its own tree size
-        if sc_ext is not None:
-            torch.cuda.current_stream().wait_stream(sc_ext)
-        else:
-            sc.sync()
-        all_gather(all_rec, d_rec)
-        rec = all_rec.cpu().numpy().reshape(world, world, 3, 24)[:, rank]  # shard s's three records for my query (the one host wait)
-        cands = [S.SCCand.from_buffer_copy(rec[s, j].tobytes()) for s in range(world) for j in range(3)]
-        return S.merge_candidates(cands, 0.4)
-
     last_pose = {}
+    sc_max = a.sc_db // world + total * world + 64
 
-    def account(mst, r):
-        lm_account("map", mst)
-        stats["loops"] += r["loop_id"] >= 0
+    P = reg = od = mp = None
+    if pipelined:
+        desc_ring = torch.zeros(ring, 1200, dtype=torch.float64, device="cuda") if world > 1 else None
+        P = S.Pipeline(S.HDL64, 5.0, max_points=cap, line_res=0.4, plane_res=0.8, max_map_points=4000000,
+                       sc_mode=S.SC_EVERY_SCAN if world == 1 else S.SC_DESCRIPTOR, sc_max_radius=80.0, sc_dist_thres=0.4,
+                       sc_max_keyframes=sc_max if world == 1 else 8, device=local, ring=ring, depth=a.depth,
+                       d_desc_ring=desc_ring.data_ptr() if world > 1 else None)
+        sc = P.sc if world == 1 else S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=sc_max, device=local, n_shards=world, shard=rank, side_stream=5)
+    else:
+        S.set_stream_mode(0)
+        reg = S.ScanRegistration(S.HDL64, 5.0, max_points=cap, device=local)
+        od = S.LaserOdometry(max_points=cap, device=local)
+        mp = S.LaserMapping(0.4, 0.8, max_scan_points=cap, max_map_points=4000000, device=local)
+        sc = S.SCManager(max_radius=80.0, dist_thres=0.4, max_keyframes=sc_max, device=local, n_shards=world, shard=rank)
+    for d in descs:
+        sc.saveScancontextAndKeys(d)  # every shard sees every insert and keeps the ones it owns
+
+    # ---- N > 1: the exchange of the sharded ScanContext search (two all-gathers per Q scans), on a host thread of its own so that
+    # neither the collectives nor their waits hold up pushing and popping
+    book = TreePeriodBook(a.sc_db)
+    if world > 1:
+        import queue
+        import threading
+        q_buf = [torch.zeros(Q, 1200, dtype=torch.float64, device="cuda") for _ in range(2)]
+        all_q = torch.zeros(world, Q, 1200, dtype=torch.float64, device="cuda")
+        d_rec = torch.zeros(Q * world * 3 * 24, dtype=torch.uint8, device="cuda")
+        all_rec = torch.zeros(world, Q * world * 3 * 24, dtype=torch.uint8, device="cuda")
+        sc_ext = torch.cuda.ExternalStream(sc.stream_ptr()) if a.backend == "nccl" else None
+        xq, loop_out, slot_free = queue.Queue(), queue.Queue(), [threading.Event(), threading.Event()]
+        for e in slot_free:
+            e.set()
+
+        def exchange(slot, nq):
+            """nq scans of every rank at once.  Global order of the descriptors: scan-major, rank-minor - the order in which a
+            one-exchange-per-scan run would have inserted and queried them (TreePeriodBook), so the answers are the same."""
+            if nq < Q:
+                q_buf[slot][nq:].zero_()
+            all_gather(all_q, q_buf[slot])
+            perm = all_q.permute(1, 0, 2)[:nq].contiguous().view(nq * world, 1200)
+            if sc_ext is not None:
+                sc_ext.wait_stream(torch.cuda.current_stream())
+            else:
+                torch.cuda.current_stream().synchronize()
+            sc.insert_descriptors_device(perm.data_ptr(), nq * world)
+            sc.shard_query_batch_device(perm.data_ptr(), book.batch(nq, world), d_rec.data_ptr())
+            if sc_ext is not None:
+                torch.cuda.current_stream().wait_stream(sc_ext)
+            else:
+                sc.sync()
+            all_gather(all_rec, d_rec)
+            rec = all_rec.cpu().numpy().reshape(world, Q * world, 3, 24)  # [shard][query][candidate]: the one host wait
+            slot_free[slot].set()
+            for j in range(nq):
+                cands = [S.SCCand.from_buffer_copy(rec[s, j * world + rank, c].tobytes()) for s in range(world) for c in range(3)]
+                loop_out.put(S.merge_candidates(cands, 0.4))
+
+        def xchg_worker():
+            torch.cuda.set_device(local)
+            while True:
+                job = xq.get()
+                if job is None:
+                    return
+                try:
+                    exchange(*job)
+                except Exception as e:  # surfaced in the main thread
+                    loop_out.put(e)
+
+        xthread = threading.Thread(target=xchg_worker, daemon=True)
+        xthread.start()
+        xstate = dict(slot=0, n=0, pending=0)
+
+        def feed_exchange(res, flush=False):
+            if res is not None:
+                s_ = xstate["slot"]
+                if xstate["n"] == 0:
+                    slot_free[s_].wait()
+                    slot_free[s_].clear()
+                q_buf[s_][xstate["n"]].copy_(desc_ring[res["seq"] % ring])  # scan k's descriptor, valid since it was popped
+                xstate["n"] += 1
+            if xstate["n"] == Q or (flush and xstate["n"] > 0):
+                xq.put((xstate["slot"], xstate["n"]))
+                xstate["pending"] += xstate["n"]
+                xstate["slot"] ^= 1
+                xstate["n"] = 0
+
+        def take_loops(block):
+            while xstate["pending"] and (block or not loop_out.empty()):
+                r = loop_out.get()
+                if isinstance(r, Exception):
+                    raise r
+                stats["loops"] += r["loop_id"] >= 0
+                xstate["pending"] -= 1
+
+    def account_step(mst, ost, loop):
+        lm_account(lm_bytes, "map", mst)
+        lm_account(lm_bytes, "odom", ost)
+        if loop is not None:
+            stats["loops"] += loop["loop_id"] >= 0
         stats["blocks"] += mst.n_edge[0] + mst.n_plane[0] + mst.n_edge[1] + mst.n_plane[1]
+        stats["edge"] += mst.n_edge[0] + mst.n_edge[1]
+        stats["plane"] += mst.n_plane[0] + mst.n_plane[1]
+        stats["evals"] += (1 + mst.lm_iters[0]) * (mst.n_edge[0] + mst.n_plane[0] > 0) + (1 + mst.lm_iters[1]) * (mst.n_edge[1] + mst.n_plane[1] > 0)
+        stats["odom_blocks"] += ost.n_edge[0] + ost.n_plane[0] + ost.n_edge[1] + ost.n_plane[1]
+        stats["odom_evals"] += 2 + ost.lm_iters[0] + ost.lm_iters[1]
         stats["stack_pts"] += mst.n_corner_stack + mst.n_surf_stack
         stats["solved"] += mst.solved
         stats["map_pts"] += mst.n_map_corner_total + mst.n_map_surf_total
+        stats["win_pts"] += mst.n_corner_map + mst.n_surf_map
 
-    mode = dict(h2d=False)
+    def on_result(res):
+        last_pose["q"], last_pose["t"] = res["q"].tolist(), res["t"].tolist()
+        account_step(res["map"], res["odom"], res["loop"])
+        if world > 1:
+            feed_exchange(res)
+            take_loops(False)
 
-    def stage_a(r_, k):
-        """stage A of scan k: from the copy resident in HBM, or (h2d leg) from host memory through pinned staging + async upload"""
-        if mode["h2d"]:
-            r_.enqueue_host(scans[k])
-        else:
-            r_.run_device(d_scans[k].data_ptr(), npts[k], 3)
+    prof_plan = dict(fn=None)
 
-    def step_serial(k):
-        """one scan at a time: A -> B -> C -> D, each stage finished before the next starts"""
-        timed("A.run_device", stage_a, reg, k)
-        qlc, tlc, qw, tw, ost = od.step_features(reg)
-        lm_account("odom", ost)
-        qm, tm, mst = timed("C.process", mp.process_features, reg, qw, tw)
-        last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
-        if world == 1:
-            sc.insert_features(reg)
-            r = sc.detectLoopClosureID()
-        else:
-            r = sc_sharded(k)
-        account(mst, r)
-
-    # ---- stage-pipelined schedule.  Nothing on the pose chains waits for the host any more: stage C composes its prior, decides
-    # the rolling window and tracks the map sizes on the device, so scan k's stage C is queued while scan k-1's (and k-2's) still
-    # runs; stage B is kept one scan ahead of the pose it hands to stage C, stage A two scans ahead.
-    pipe = dict(c_inflight=[], loops={}, side_inflight=False, b_queued=-1, started=False)
-    PENDING = object()
-    C_DEPTH = 2   # stage-C steps queued and not collected (the library allows 4)
-
-    # A second host thread queues the side-stream work and stage A (the library calls release the GIL).
-    import queue
-    import threading
-    side_q, side_done = queue.Queue(), queue.Queue()
-    side2_q, side2_done = queue.Queue(), queue.Queue()
-
-    def side_worker(q_in, q_out):
-        torch.cuda.set_device(local)
-        while True:
-            job = q_in.get()
-            if job is None:
-                return
-            try:
-                job()
-                q_out.put(None)
-            except Exception as e:  # surfaced in the main thread
-                q_out.put(e)
-
-    side_thread = threading.Thread(target=side_worker, args=(side_q, side_done), daemon=True) if (pipelined and a.side_thread) else None
-    if side_thread:
-        side_thread.start()
-    # ScanContext's calls (keyframe filter, descriptor, insert, search, collect) from a thread of their own: ~20 launches per scan
-    side2_thread = threading.Thread(target=side_worker, args=(side2_q, side2_done), daemon=True) if (pipelined and a.side_thread >= 2 and world == 1) else None
-    if side2_thread:
-        side2_thread.start()
-
-    # N > 1: the sharded ScanContext step blocks on two collectives and a few synchronisations per scan; a third host thread
-    # runs it (same order on every rank) so that stages A-C of the following scans keep being queued meanwhile.
-    xchg_q, loop_q = queue.Queue(), queue.Queue()
-
-    def xchg_worker():
-        torch.cuda.set_device(local)
-        prev = None
-        while True:
-            job = xchg_q.get()
-            if job is None:
-                return
-            try:
-                if job != "flush":
-                    k, r_ = job
-                    sc_build.make_features_enqueue(r_, d_q[k % 2].data_ptr())  # scan k's descriptor starts building ...
-                if prev is not None:
-                    loop_q.put(sc_sharded(prev, True))                         # ... while scan k-1's is exchanged and searched
-                prev = None if job == "flush" else k
-            except Exception as e:
-                loop_q.put(e)
-
-    xchg_thread = threading.Thread(target=xchg_worker, daemon=True) if (pipelined and world > 1) else None
-    if xchg_thread:
-        xchg_thread.start()
-
-    def loop_result(k):
-        if world == 1:
-            return pipe["loops"].pop(k)
-        r = loop_q.get()
-        if isinstance(r, Exception):
-            raise r
-        return r
-
-    def side_job(j, last):
-        """Everything that only needs stage A, queued one iteration ahead of its use: for scan j+1 the stage-C prefetch, stage A of
-        scan j+2, the loop answer of scan j (its search was queued by the previous job), then scan j+1's ScanContext insert + search."""
-        r_ = regs[(j + 1) % len(regs)] if j + 1 < last else None
-
-        def run_a():
-            if r_ is not None:
-                timed("side.prefetch", mp.prefetch_features, r_)   # first: its gather + corner filter ride on stage A's stream
-            if j + 2 < last:
-                timed("A.run_device", stage_a, regs[(j + 2) % len(regs)], j + 2)
-            if r_ is not None and world > 1:
-                xchg_q.put((j + 1, r_))
-
-        def run_d():
-            if world != 1:
-                return
-            if r_ is not None:
-                timed("D.insert", sc.insert_features, r_)
-                timed("D.detect_enqueue", sc.detect_enqueue)
-                pipe.setdefault("d_queued", set()).add(j + 1)
-            if j in pipe.get("d_queued", ()):      # queued by the previous job: a whole period to finish
-                pipe["loops"][j] = timed("D.detect_collect", sc.detect_collect)
-                pipe["d_queued"].discard(j)
-
-        def run():
-            run_a()
-            run_d()
-        return run, run_a, run_d
-
-    def run_side(jobs):
-        both, job_a, job_d = jobs
-        if side_thread and side2_thread:
-            side_q.put(job_a)
-            side2_q.put(job_d)
-            pipe["side_inflight"] = 2
-        elif side_thread:
-            side_q.put(both)
-            pipe["side_inflight"] = 1
-        else:
-            both()
-
-    def join_side():
-        if pipe["side_inflight"]:
-            errs = [timed("side.join", side_done.get)]
-            if pipe["side_inflight"] == 2:
-                errs.append(timed("side2.join", side2_done.get))
-            pipe["side_inflight"] = False
-            for err in errs:
-                if err is not None:
-                    raise err
-
-    def collect_c():
-        k = pipe["c_inflight"].pop(0)
-        qm, tm, mst = timed("C.collect", mp.collect)
-        last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
-        return k, mst
-
-    # stage B from a thread of its own (--side-thread 3): "go k" = queue B(k+1), collect B(k), hand the pose to the main thread
-    b_q, b_out = queue.Queue(), queue.Queue()
-
-    def b_worker():
-        torch.cuda.set_device(local)
-        while True:
-            job = b_q.get()
-            if job is None:
-                return
-            try:
-                k, nxt = job
-                if nxt is not None:
-                    timed("B.enqueue", od.enqueue_features, nxt)
-                b_out.put(timed("B.collect", od.collect))
-            except Exception as e:
-                b_out.put(e)
-
-    b_thread = threading.Thread(target=b_worker, daemon=True) if (pipelined and a.side_thread >= 3) else None
-    if b_thread:
-        b_thread.start()
-
-    def step_pipelined(k, last):
-        """Iteration k of the software pipeline: stage B of scan k+1 is queued before the pose of scan k's stage B is collected,
-        that pose goes straight into scan k's stage C, which queues behind the stage-C steps still running; the oldest of those
-        is collected when more than C_DEPTH are outstanding."""
-        if not pipe["started"]:  # first scan of a run: what the previous iterations would have queued
-            stage_a(regs[k % len(regs)], k)
-            od.enqueue_features(regs[k % len(regs)])
-            pipe["b_queued"] = k
-            pipe["started"] = True
-            side_job(k - 1, last)[0]()   # A(k+1), prefetch(k), D(k)
-        join_side()                   # job k-1: A(k+1), prefetch(k), D(k) are queued
-        run_side(side_job(k, last))
-        nxt = None
-        if k + 1 < last and pipe["b_queued"] < k + 1:
-            nxt = regs[(k + 1) % len(regs)]
-            pipe["b_queued"] = k + 1
-        if b_thread:
-            b_q.put((k, nxt))
-            res = timed("B.wait_pose", b_out.get)
-            if isinstance(res, Exception):
-                raise res
-            qlc, tlc, qw, tw, ost = res
-        else:
-            if nxt is not None:
-                timed("B.enqueue", od.enqueue_features, nxt)
-            qlc, tlc, qw, tw, ost = timed("B.collect", od.collect)
-        lm_account("odom", ost)
-        timed("C.enqueue", mp.enqueue_features, regs[k % len(regs)], qw, tw)
-        pipe["c_inflight"].append(k)
-        while len(pipe["c_inflight"]) > C_DEPTH:
-            kk, mst = collect_c()
-            pipe.setdefault("accounts", []).append((kk, mst))
-        # N > 1: the exchange thread may lag two scans behind (their features contexts are still intact)
-        while pipe.get("accounts") and (len(pipe["accounts"]) > 2 if world > 1 else pipe["accounts"][0][0] in pipe["loops"]):
-            kk, mst = pipe["accounts"].pop(0)
-            account(mst, timed("D.loop_result", loop_result, kk))
-
-    def drain():
-        join_side()
-        while pipe["c_inflight"]:
-            pipe.setdefault("accounts", []).append(collect_c())
-        if world == 1:
-            for j in sorted(pipe.get("d_queued", ())):
-                pipe["loops"][j] = sc.detect_collect()
-            pipe["d_queued"] = set()
-        elif xchg_thread and pipe.get("accounts"):
-            xchg_q.put("flush")  # the exchange of the last scan runs one job late
-        for kk, mst in pipe.get("accounts", []):
-            account(mst, loop_result(kk))
-        pipe["accounts"] = []
-        pipe["started"] = False
+    def run_region(k0, n, h2d=False):
+        """n consecutive scans through the hot path; returns when the last scan's pose, loop answer AND map insertion are done"""
+        if pipelined:
+            in_flight = 0
+            for k in range(k0, k0 + n):
+                if prof_plan["fn"]:
+                    prof_plan["fn"](k)
+                if h2d:
+                    P.push(scans[k])
+                else:
+                    P.push_device(d_scans[k].data_ptr(), npts[k], 3)
+                in_flight += 1
+                while in_flight > a.ahead:
+                    on_result(P.pop())
+                    in_flight -= 1
+            P.drain()
+            while in_flight:
+                on_result(P.pop())
+                in_flight -= 1
+            if world > 1:
+                feed_exchange(None, flush=True)
+                take_loops(True)
+            return
+        for k in range(k0, k0 + n):  # serial: A -> B -> C -> D, each stage finished before the next starts
+            if prof_plan["fn"]:
+                prof_plan["fn"](k)
+            if h2d:
+                reg.enqueue_host(scans[k])
+            else:
+                reg.run_device(d_scans[k].data_ptr(), npts[k], 3)
+            qlc, tlc, qw, tw, ost = od.step_features(reg)
+            qm, tm, mst = mp.process_features(reg, qw, tw)
+            last_pose["q"], last_pose["t"] = qm.tolist(), tm.tolist()
+            if world == 1:
+                sc.insert_features(reg)
+                r = sc.detectLoopClosureID()
+            else:
+                dq = q_buf[0][0]
+                sc.make_features(reg, dq.data_ptr())
+                gathered = torch.zeros(world, 1200, dtype=torch.float64, device="cuda")
+                all_gather(gathered, dq)
+                torch.cuda.current_stream().synchronize()
+                sc.insert_descriptors_device(gathered.data_ptr(), world)
+                rec1 = torch.zeros(world * 3 * 24, dtype=torch.uint8, device="cuda")
+                sc.shard_query_batch_device(gathered.data_ptr(), book.step(world), rec1.data_ptr())
+                sc.sync()
+                allr = torch.zeros(world, world * 3 * 24, dtype=torch.uint8, device="cuda")
+                all_gather(allr, rec1)
+                rec = allr.cpu().numpy().reshape(world, world, 3, 24)[:, rank]
+                r = S.merge_candidates([S.SCCand.from_buffer_copy(rec[s, c].tobytes()) for s in range(world) for c in range(3)], 0.4)
+            account_step(mst, ost, r)
         mp.finish()
-
-    step = step_pipelined if pipelined else (lambda k, last: step_serial(k))
 
     def fence():
         torch.cuda.synchronize()
@@ -525,78 +486,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(W):
-        step(k, W)
-    if pipelined:
-        drain()
+    run_region(0, W)
     S.prof_reset()
-    host_t.clear()
     for key in stats:
         stats[key] = 0
+    for key in lm_bytes:
+        lm_bytes[key] = 0
     import gc
     gc.collect()
-    gc.disable()  # a generation-2 collection inside a ~40 ms timed region would be a visible fraction of it
+    gc.disable()  # a generation-2 collection inside a ~6-40 ms timed region would be a visible fraction of it
     fence()
-    if a.sync_dir and a.sync_n > 1:  # several independent sequences on one GPU (tools/gpu_multi_seq.sh): common start
-        open(os.path.join(a.sync_dir, f"ready_{os.getpid()}"), "w").close()
-        while len([f for f in os.listdir(a.sync_dir) if f.startswith("ready_")]) < a.sync_n:
-            time.sleep(0.0005)
     t_wall0 = time.time()
-    n_prof_steps = 0
+    n_prof_steps = [0]
     rep_dt = []
-    # Timestamps on the dispatches cost throughput (tools/gpu_prof_overhead.sh: -8 % and jitter even with only the two solve
-    # kernels timed on every step), so inside the timed region only the two solve kernels of the roofline line carry them, on every
-    # N-th step; the per-kernel table comes from extra steps behind the timed ones.
+    # Timestamps on the dispatches cost throughput (tools/gpu_prof_overhead.sh), so inside the timed region only the two solve kernels
+    # of the roofline line carry them, on every N-th step; the per-kernel table comes from extra steps behind the timed ones.
     LM_FILTER = "k_lm_solve_map,k_lm_solve_odom"
     lm_only = a.prof_every > 0 and not a.timeline
     for rep in range(R):  # the same K-step region on consecutive scans of the sequence; the state (map, poses, database) carries on
         k0 = W + rep * K
-        t0 = time.perf_counter()
-        for k in range(k0, k0 + K):
+
+        def plan(k, rep=rep, k0=k0):
             if a.timeline:
                 on = True if a.timeline_kernels else (rep == R - 1 and K // 2 <= k - k0 < K // 2 + 6)
                 S.prof_timeline(on)
                 S.prof_enable(on, a.timeline_kernels or None)
-                n_prof_steps += on
             else:
                 on = lm_only and (k - W) % a.prof_every == 0
                 S.prof_enable(on, LM_FILTER)
-                n_prof_steps += on
-            step(k, k0 + K)
-        if pipelined:
-            drain()  # the last scan's pose and map insertion belong to the timed region
+            n_prof_steps[0] += on
+        prof_plan["fn"] = plan
+        t0 = time.perf_counter()
+        run_region(k0, K)
         fence()
         rep_dt.append(time.perf_counter() - t0)
+    prof_plan["fn"] = None
     S.prof_enable(False)
     t_wall1 = time.time()
     final_pose_resident = dict(last_pose)
+    loops_timed = int(stats["loops"])
     dt_h2d = None
     if do_h2d:  # PCIe-inclusive leg: every scan starts in (pageable) host memory; never reported as `value`
-        mode["h2d"] = True
         k0 = W + R * K
         t0 = time.perf_counter()
-        for k in range(k0, k0 + K):
-            step(k, k0 + K)
-        if pipelined:
-            drain()
+        run_region(k0, K, h2d=True)
         fence()
         dt_h2d = time.perf_counter() - t0
-        mode["h2d"] = False
     dt = float(np.median(rep_dt))
     gc.enable()
-    S.prof_enable(False)
     prof = S.prof_read_all()
-    prof_all, n_all_steps = prof, n_prof_steps
+    prof_all, n_all_steps = prof, n_prof_steps[0]
     if P_STEPS > 0:  # per-kernel table: every instrumented launch timed, outside the timed region; the run's statistics are put back
         import copy
         keep_stats, keep_lm = copy.deepcopy(stats), copy.deepcopy(lm_bytes)
         S.prof_reset()
         S.prof_enable(True)
-        k0 = W + K * (R + (1 if do_h2d else 0))
-        for k in range(k0, k0 + P_STEPS):
-            step(k, k0 + P_STEPS)
-        if pipelined:
-            drain()
+        run_region(W + K * (R + (1 if do_h2d else 0)), P_STEPS)
         fence()
         S.prof_enable(False)
         prof_all, n_all_steps = S.prof_read_all(), P_STEPS
@@ -606,12 +551,18 @@ def main():
         S.prof_timeline_dump(a.timeline)
     # sizes of one representative scan (outside the timed region) for the algorithmic-byte formulas
     kr = W + R * K - 1
-    reg.run_device(d_scans[kr].data_ptr(), npts[kr], 3)
-    fz = reg.fetch()
+    rz = S.ScanRegistration(S.HDL64, 5.0, max_points=cap, device=local)
+    rz.run_device(d_scans[kr].data_ptr(), npts[kr], 3)
+    fz = rz.fetch()
+    kf = S.VoxelGrid(cap, device=local)
+    n_kf = kf.filter(fz["cloud"], 0.4).shape[0]  # the keyframe cloud ScanContext builds its descriptor from (:629-631)
+    rz.close(), kf.close()
     nsteps = K * (R + (1 if do_h2d else 0))
+    per = lambda key: stats[key] / max(1, nsteps)  # noqa: E731
     counts = dict(n_in=npts[kr], n_kept=fz["n_kept"], n_sharp=len(fz["sharp"]), n_less_sharp=len(fz["less_sharp"]), n_flat=len(fz["flat"]),
-                  n_less_flat=fz["less_flat"].shape[0], stack_pts=stats["stack_pts"] / max(1, nsteps), blocks=stats["blocks"] / max(1, 2 * nsteps),
-                  map_pts=stats["map_pts"] / max(1, nsteps), lm=lm_bytes)
+                  n_less_flat=fz["less_flat"].shape[0], n_keyframe_ds=n_kf, stack_pts=per("stack_pts"), blocks=stats["blocks"] / max(1, 2 * nsteps),
+                  map_pts=per("map_pts"), win_pts=per("win_pts"), edge=per("edge"), plane=per("plane"), evals=per("evals"),
+                  odom_blocks=per("odom_blocks"), odom_evals=per("odom_evals"), n_db=a.sc_db + W + nsteps // 2, n_scans_sensor=64, lm=lm_bytes)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -620,49 +571,93 @@ def main():
     out = None
     if rank == 0:
         value = world * K / dt
-        # ---- roofline of the dominant kernel (HBM bound): algorithmic bytes per launch / measured average launch time
-        roofline = roofline_of(prof, max(1, n_prof_steps), counts, pipelined)
-        cpu = None
+        roofline = roofline_of(prof, counts, pipelined, prof_all, n_all_steps)
+        cpu = cpp = None
         if world == 1 and a.cpu_sample > 0:
             cpu = cpu_baseline(scans[: min(total, a.cpu_sample)], a.sc_db)
+        as_integrated = None
+        if world == 1 and a.cpp_sample > 0:
+            from scaloam import formats
+            n_cpp = min(total, a.cpp_sample + 5)
+            with tempfile.TemporaryDirectory() as td:
+                f = os.path.join(td, "scans.bin")
+                formats.write_scan_stream(f, scans[:n_cpp])
+                if P is not None:
+                    P.close()  # the child builds its own contexts (5.3 GB of grid pools each): free ours first
+                    P = None
+                integ = cpp_host("integrated", f, 5, a.sc_db)
+                cpp = {"integrated": integ, "pipeline_resident": cpp_host("pipeline", f, 5, a.sc_db, resident=1),
+                       "pipeline_host_scans": cpp_host("pipeline", f, 5, a.sc_db, resident=0)}
+            if "error" not in integ:
+                as_integrated = {"value": integ["scans_per_s"], "unit": "scans/s", "ms_per_scan": integ["ms_per_scan"],
+                                 "latency_ms_p50": integ["latency_ms"]["p50"], "latency_ms_p99": integ["latency_ms"]["p99"], "scans": integ["scans"],
+                                 "note": "sc-a-loam_amd/host/replay_main.cpp --mode integrated (C++, a child process): the synchronous host-array entry "
+                                         "points scal_features_run / scal_odom_step / scal_map_step / scal_voxel_downsample + scal_sc_insert_cloud + "
+                                         "scal_sc_detect exactly as INTEGRATION.md sections 1-4 place them in the reference's four nodes, one thread per "
+                                         "stage, clouds handed over as host arrays; latency = scan in -> mapping pose on the host; not the metric's value"}
         out = {
-            "metric": "scans/sec (feat-extract + scan-to-map ICP + SC loop search), KITTI HDL-64",
-            "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
-            "repetitions": R, "rep_ms_per_step": [x / K * 1e3 for x in rep_dt],
+            "metric": METRIC, "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+            "repetitions": R, "timed_total_s": float(sum(rep_dt)), "rep_ms_per_step": [x / K * 1e3 for x in rep_dt],
             "h2d_inclusive": None if dt_h2d is None else {
                 "value": world * K / dt_h2d, "unit": "scans/s", "ms_per_step": dt_h2d / K * 1e3,
                 "note": "one more repetition of the K steps with every scan starting in pageable host memory: copy into pinned staging + "
-                        "asynchronous upload on stage A's stream inside the timed region (scal_features_enqueue_host); not the metric's value"},
+                        "asynchronous upload on stage A's stream inside the timed region (scal_pipeline_push_host); not the metric's value"},
+            "as_integrated": as_integrated,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 points / f64 pose algebra",
             "data": "synthetic",
             "config": {"workload": "KITTI-like HDL-64 (64 beams x 1900 az, seeded procedural world, ~95k pts after the reference's ring filter) "
                                    "scan-to-map: 2 outer x <=4 LM iterations edge+surf correspondence + JtJ, with stage A features, stage B "
                                    "odometry prior and ScanContext insert+detect per scan",
-                       "points_per_scan_in": int(np.mean(npts)), "sc_db_keyframes": a.sc_db, "line_res": 0.4, "plane_res": 0.8,
-                       "parallelism": "replicas for A-C, SC database sharded i % N with RCCL all-gather" if world > 1 else "single GPU",
-                       "schedule": "stage-pipelined: one stream per stage, consecutive scans overlap as the reference's four nodes do" if pipelined
-                       else "serial: one scan at a time"},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "points_per_scan_in": int(np.mean(npts)), "sc_db_keyframes": a.sc_db, "sc_db_revisits": n_rev, "line_res": 0.4, "plane_res": 0.8,
+                       "parallelism": (f"replicas for A-C, SC database sharded i % N with two RCCL all-gathers per {Q} scan(s)" if world > 1 else "single GPU"),
+                       "schedule": "scal_pipeline (in-library, three C++ host threads): one stream per stage, consecutive scans overlap as the "
+                                   "reference's four nodes do" if pipelined else "serial: one scan at a time through the per-stage calls"},
+            "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
             "kernel_ms_per_step": {k: v[0] / max(1, n_all_steps) for k, v in sorted(prof_all.items())}, "profiled_steps": n_all_steps,
-            "roofline_timed_steps": n_prof_steps,
-            "loops_detected": int(stats["loops"]), "input_gen_s": gen_s, "final_map_pose": final_pose_resident,
-            "host_us_per_step": {k: v / K * 1e6 for k, v in host_t.items()} if a.host_timing else None,
+            "roofline_timed_steps": n_prof_steps[0],
+            "loops_detected": loops_timed, "input_gen_s": gen_s, "database_gen_s": db_s, "final_map_pose": final_pose_resident,
             "timed_window_unix": [t_wall0, t_wall1],
         }
         print(json.dumps(out))
     if world > 1:
+        xq.put(None)
         dist.barrier()
         dist.destroy_process_group()
     return out
 
 
-def roofline_of(prof, K, c, pipelined=True):
+# SURVEY.md section 8d's algorithmic bytes per scan, evaluated on the run's own counts
+def stage_bytes(c):
+    A = 12.0 * c["n_in"] + 16.0 * c["n_kept"] + 16.0 * (c["n_sharp"] + c["n_less_sharp"] + c["n_flat"] + c["n_less_flat"])
+    E = 72.0 * c["edge"] + 56.0 * c["plane"]  # both outer iterations together
+    Pw, M, N = c["win_pts"], c["stack_pts"], c["n_kept"]
+    C = 16.0 * (2 * Pw + 2 * Pw + 2 * N) + 2 * 16.0 * M * 6 + E + c["lm"]["map"] / max(1, c["lm"]["map_launches"]) * 2
+    Tc, Ts = c["n_less_sharp"], c["n_less_flat"]
+    w = 5.0 / max(1, c["n_scans_sensor"] * 0.8) * Ts  # points of the target cloud inside the +-2 ring window a plane query walks (:402-455)
+    ob = (c["lm"]["odom"] + c["lm"].get("odom_E", 0.0)) / max(1, c["lm"]["odom_launches"]) * 2  # blocks written once, read once per evaluation
+    B = 16.0 * (Tc + Ts) + 2 * 16.0 * (c["n_sharp"] + c["n_flat"]) * (1 + w) + ob
+    D = 80.0 * c["n_db"] + 4 * 9600.0 + 16.0 * c["n_kept"] + 16.0 * c["n_keyframe_ds"]
+    return {"A": A, "B": B, "C": C, "D": D}
+
+
+STAGE_KERNELS = {
+    "A": ("k_pre", "k_classify", "k_ringscan", "k_scatter", "k_curv", "k_ring", "k_finalize", "k_compact"),
+    "B": ("k_odom_gather", "k_odom_nn", "k_odom_assoc", "k_lm_solve_odom", "k_odom_handover"),
+    "C": ("k_map_gather", "k_map_begin", "k_grid_build", "k_grid_count", "k_grid_alloc", "k_grid_fill", "k_grid_clear", "k_assoc_knn", "k_assoc_fit",
+          "k_lm_solve_map", "k_merge_keys", "k_merge_lookup", "k_merge_write", "k_map_end", "k_insert_keys", "k_map_heads", "k_map_reduce",
+          "k_transform_cloud", "k_scan"),
+    "D": ("k_sc_bin", "k_sc_finish", "k_sc_keys", "k_sc_store", "k_sc_topk", "k_sc_detect"),
+}
+
+
+def roofline_of(prof, c, pipelined=True, prof_all=None, n_all_steps=0):
     """Roofline line of the dominant kernel: the stage-C LM solve (k_lm_solve, the largest single kernel of the pose chains).
     achieved = ALGORITHMIC bytes per launch / average launch duration, both measured in THIS run:
       bytes  = SURVEY.md section 8d's per-unit figures - 72 B per edge block, 56 B per plane block, read once per evaluation - times
                the residual blocks and evaluations (1 + LM iterations) the solves of the timed steps really had (scal_map_stats);
       time   = HIP events attached to the dispatches on stage C's stream (sampled steps).
-    Stage B's solves run the same kernel on ~10x fewer blocks and are priced separately (`stage_b`)."""
+    Stage B's solves run the same kernel on ~10x fewer blocks and are priced separately (`stage_b`).  `stages`: section 8d's per-scan
+    byte formulas over the summed kernel time of each stage (extra, untimed steps with every launch timed)."""
     if not prof:
         return None
     lm = c["lm"]
@@ -680,52 +675,70 @@ def roofline_of(prof, K, c, pipelined=True):
     lb = line("k_lm_solve_odom", lm["odom"], lm["odom_launches"])
     if lc is None:
         return None
-    # HBM traffic of that kernel from the committed PMC passes of THIS build (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate
-    # runs of this benchmark: bench.py cannot collect counters on itself); null when the file is missing
+    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of this
+    # benchmark: bench.py cannot collect counters on itself); null when the file is missing
     traffic, src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fetch_write.json")))
-        k = pmc["kernels"].get("k_lm_solve_map")
-        if k:
-            traffic = (k["fetch_kb_per_dispatch"] + k["write_kb_per_dispatch"]) * 1024.0
-            src = "profiles/r02_pmc_fetch_write.json: " + pmc.get("config", "")
-    except (OSError, KeyError, ValueError):
-        pass
+    for name in ("r03_pmc_fetch_write.json", "r02_pmc_fetch_write.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            k = pmc["kernels"].get("k_lm_solve_map")
+            if k:
+                traffic = (k["fetch_kb_per_dispatch"] + k["write_kb_per_dispatch"]) * 1024.0
+                src = f"profiles/{name}: " + pmc.get("config", "")
+                break
+        except (OSError, KeyError, ValueError):
+            pass
+    stages = None
+    if prof_all and n_all_steps and "n_in" in c:
+        sb = stage_bytes(c)
+        stages = {}
+        for st, names in STAGE_KERNELS.items():
+            ms = sum(v[0] for k, v in prof_all.items() if k in names or k.endswith("." + st)) / n_all_steps
+            if ms > 0:
+                gbs = sb[st] / (ms * 1e-3) / 1e9
+                stages[st] = {"algorithmic_bytes_per_scan": sb[st], "kernel_ms_per_scan": ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
     out = {"bound": "hbm", "kernel": "k_lm_solve (stage C)", "achieved": lc["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": lc["achieved"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
            "avg_launch_us": lc["avg_launch_us"], "timed_launches": lc["timed_launches"],
            "algorithmic_bytes_per_launch": lc["algorithmic_bytes_per_launch"],
            "blocks_per_launch": lm["map_blocks"] / max(1, lm["map_launches"]), "evaluations_per_launch": lm["map_evals"] / max(1, lm["map_launches"]),
            "bytes_formula": "(72 B x edge blocks + 56 B x plane blocks) x (1 + LM iterations), SURVEY.md section 8d",
-           "stage_b": lb,
-           "share_of_step_ms": prof["k_lm_solve_map"][0] / K,
+           "stage_b": lb, "stages": stages,
+           "stages_note": "per scan: SURVEY.md section 8d's byte formulas (A: 12 N_in + 16 N_kept + 16 features; B: targets + 2 x queries x (1 + ring "
+                          "window) + evaluations; C: 16 (4 P + 2 N) + 2 x 16 M x 6 + (1 + evaluations) x E; D: 80 n_db + 38,400 + the keyframe "
+                          "VoxelGrid) over the summed device time of the stage's kernels",
            "note": "latency-bound by design: <= 5 dependent evaluation rounds of ~9 us on <= 48 workgroups (DESIGN.md section 6)"}
     return out
 
 
-def cpu_baseline(scans, sc_db):
+def cpu_baseline(scans, sc_db, sensor="HDL64", min_range=5.0, sc_thres=0.4, gate=None):
     """The oracle (dependency-free CPU restatement of the reference path, g++ -O3, one thread per stage) on the same scans:
     (iii) the serial sum on one core and (ii) the pipelined figure 1 / max(stage) - the reference's four ROS nodes run as four
     processes, so its throughput on >= 4 cores is bounded by its slowest stage, not by the sum."""
     import oracle_py as O
-    oo, om, osc = O.Odometry(), O.Mapper(0.4, 0.8), O.SCManager(max_radius=80.0, dist_thres=0.4)
+    oo, om, osc = O.Odometry(), O.Mapper(0.4, 0.8), O.SCManager(max_radius=80.0, dist_thres=sc_thres)
     rng = np.random.default_rng(4242)
     for d in synth_descs(rng, sc_db):
         osc.saveScancontextAndKeys(d.T)
+    kg = None
+    if gate:
+        from scaloam.pgo import KeyframeGate
+        kg = KeyframeGate(*gate)
     t_stage = np.zeros(4)
     t0 = time.perf_counter()
     for xyz in scans:
         ta = time.perf_counter()
-        f = O.features(xyz, O.HDL64, 5.0)
+        f = O.features(xyz, getattr(O, sensor), min_range)
         c = f["cloud"]
         tb = time.perf_counter()
         x = oo.step(c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
         tc = time.perf_counter()
-        om.step(c[f["less_sharp"]], f["less_flat"], c, x[2], x[3], want_registered=True)
+        qm, tm, _, _ = om.step(c[f["less_sharp"]], f["less_flat"], c, x[2], x[3], want_registered=True)
         td = time.perf_counter()
-        ds, _ = O.voxel_grid(c, 0.4)
-        osc.makeAndSaveScancontextAndKeys(ds)
-        osc.detectLoopClosureID()
+        if kg is None or kg(qm, tm):
+            ds, _ = O.voxel_grid(c, 0.4)
+            osc.makeAndSaveScancontextAndKeys(ds)
+            osc.detectLoopClosureID()
         te = time.perf_counter()
         t_stage += [tb - ta, tc - tb, td - tc, te - td]
     dt = time.perf_counter() - t0

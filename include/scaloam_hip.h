@@ -455,6 +455,8 @@ typedef struct {
     int device;
     int ring;                     /* features contexts used in turn: 4..16, 0 = 6 */
     int depth;                    /* stage-C steps queued on the device and not collected: 1..3, 0 = 2 */
+    double* d_desc_ring;          /* sc_mode 2: caller-owned device memory for ring x 1200 doubles, scan k's descriptor at slot k % ring
+                                   * (NULL: allocated by the pipeline) - so that an RCCL all-gather can read it in place */
 } scal_pipeline_config;
 typedef struct {
     long long seq;                        /* 0, 1, 2 ... in push order */

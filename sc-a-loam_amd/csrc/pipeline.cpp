@@ -11,6 +11,8 @@
 // Nothing here touches the device except through the per-stage C-ABI, so the poses are those of the per-stage calls.
 #include "common.hpp"
 #include <condition_variable>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <thread>
 
@@ -19,8 +21,37 @@ using namespace scal;
 namespace {
 constexpr int REC_N = 64;      // per-scan records (ring); at most 32 scans may be pushed and not popped
 constexpr int MAX_UNPOPPED = 32;
-constexpr int B_AHEAD = 2;     // stage-B steps queued and not collected
-constexpr int PF_AHEAD = 3;    // scal_map::MAX_PF: prefetches queued ahead of their steps
+// development knobs (environment), read once: how far the stages may run ahead of each other
+int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* e = std::getenv(name);
+    if (!e) return dflt;
+    const int v = std::atoi(e);
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+const int B_AHEAD = env_int("SCALOAM_PIPE_B_AHEAD", 2, 1, 3);     // stage-B steps queued and not collected
+const int PF_AHEAD = env_int("SCALOAM_PIPE_PF_AHEAD", 3, 1, 3);   // scal_map::MAX_PF: prefetches queued ahead of their steps
+
+// SCALOAM_PIPE_TIMING=1: host time spent inside each stage call, printed per scan when the pipeline is destroyed (development aid)
+const bool TIMING = env_int("SCALOAM_PIPE_TIMING", 0, 0, 1) != 0;
+struct HostTimer {
+    const char* name[12] = {};
+    double total[12] = {};
+    long calls[12] = {};
+    template <class F>
+    int run(int slot, const char* nm, F&& f) {
+        if (!TIMING) return f();
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = f();
+        name[slot] = nm;
+        total[slot] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        calls[slot]++;
+        return rc;
+    }
+    void print(const char* thread) const {
+        for (int i = 0; i < 12; ++i)
+            if (calls[i]) std::fprintf(stderr, "[scal_pipeline] %-6s %-28s %8.1f us/call x %ld\n", thread, name[i], total[i] / calls[i], calls[i]);
+    }
+};
 
 struct Rec {
     const float* d_xyz = nullptr;
@@ -39,6 +70,7 @@ struct scal_pipeline {
     scal_map_t* mp = nullptr;
     scal_sc_t* sc = nullptr;
     double* d_desc = nullptr;  // sc_mode 2: ring x 1200 doubles
+    bool own_desc = false;
     Rec rec[REC_N];
     std::mutex mu;
     std::condition_variable cv;
@@ -50,6 +82,7 @@ struct scal_pipeline {
     int err = SCAL_OK;
     std::string errmsg;
     std::thread t_front, t_pose, t_loop;
+    HostTimer tm_front, tm_pose, tm_loop;
 
     bool sc_on() const { return cfg.sc_mode != SCAL_PIPE_SC_OFF; }
     Rec& r(long long k) { return rec[k % REC_N]; }
@@ -79,8 +112,10 @@ void front_thread(scal_pipeline* p) {
         Rec rc = p->r(k);
         scal_features_t* reg = p->regs[k % p->ring];
         lk.unlock();
-        int st = rc.host ? scal_features_enqueue_host(reg, rc.h_xyz, rc.n, rc.stride) : scal_features_run_device(reg, rc.d_xyz, rc.n, rc.stride);
-        if (st == SCAL_OK) st = scal_map_prefetch_features(p->mp, reg);
+        int st = p->tm_front.run(0, "A: features_run", [&] {
+            return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz, rc.n, rc.stride) : scal_features_run_device(reg, rc.d_xyz, rc.n, rc.stride);
+        });
+        if (st == SCAL_OK) st = p->tm_front.run(1, "C: map_prefetch_features", [&] { return scal_map_prefetch_features(p->mp, reg); });
         lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
@@ -113,7 +148,7 @@ void pose_thread(scal_pipeline* p) {
             const long long k = p->b_enq;
             scal_features_t* reg = p->regs[k % p->ring];
             lk.unlock();
-            st = scal_odom_enqueue_features(p->od, reg);
+            st = p->tm_pose.run(0, "B: odom_enqueue_features", [&] { return scal_odom_enqueue_features(p->od, reg); });
             lk.lock();
             if (st == SCAL_OK) p->b_enq = k + 1;
         } else if (what == B_COLL) {
@@ -122,15 +157,16 @@ void pose_thread(scal_pipeline* p) {
             scal_pipeline_result& R = p->r(k).res;
             lk.unlock();
             double qlc[4], tlc[3];
-            st = scal_odom_collect(p->od, qlc, tlc, R.q_odom, R.t_odom, &R.odom);
-            if (st == SCAL_OK) st = scal_map_enqueue_features(p->mp, reg, R.q_odom, R.t_odom);  // the pose goes straight into stage C
+            st = p->tm_pose.run(1, "B: odom_collect (wait)", [&] { return scal_odom_collect(p->od, qlc, tlc, R.q_odom, R.t_odom, &R.odom); });
+            if (st == SCAL_OK)  // the pose goes straight into stage C
+                st = p->tm_pose.run(2, "C: map_enqueue_features", [&] { return scal_map_enqueue_features(p->mp, reg, R.q_odom, R.t_odom); });
             lk.lock();
             if (st == SCAL_OK) p->b_coll = k + 1, p->c_enq = k + 1;
         } else if (what == C_COLL) {
             const long long k = p->c_coll;
             scal_pipeline_result& R = p->r(k).res;
             lk.unlock();
-            st = scal_map_collect(p->mp, R.q_w_curr, R.t_w_curr, &R.map);
+            st = p->tm_pose.run(3, "C: map_collect (wait)", [&] { return scal_map_collect(p->mp, R.q_w_curr, R.t_w_curr, &R.map); });
             lk.lock();
             if (st == SCAL_OK) p->c_coll = k + 1;
         } else if (what == FINISH) {
@@ -169,8 +205,8 @@ void loop_thread(scal_pipeline* p) {
             double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(k % p->ring) * 1200 : nullptr;
             lk.unlock();
             if (search) {
-                st = scal_sc_insert_features(p->sc, reg);
-                if (st == SCAL_OK) st = scal_sc_detect_enqueue(p->sc);
+                st = p->tm_loop.run(0, "D: sc_insert_features", [&] { return scal_sc_insert_features(p->sc, reg); });
+                if (st == SCAL_OK) st = p->tm_loop.run(1, "D: sc_detect_enqueue", [&] { return scal_sc_detect_enqueue(p->sc); });
             } else {
                 st = scal_sc_make_features_enqueue(p->sc, reg, dd);
             }
@@ -184,7 +220,7 @@ void loop_thread(scal_pipeline* p) {
             scal_pipeline_result& R = p->r(k).res;
             lk.unlock();
             if (search) {
-                st = scal_sc_detect_collect(p->sc, &R.loop);
+                st = p->tm_loop.run(2, "D: sc_detect_collect (wait)", [&] { return scal_sc_detect_collect(p->sc, &R.loop); });
                 R.have_loop = st == SCAL_OK;
             } else {
                 st = scal_sc_wait_descriptor(p->sc);
@@ -268,12 +304,21 @@ extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeli
     if (rc == SCAL_OK && p->sc_on()) {
         scal_sc_config sc{};
         sc.max_radius = cfg->sc_max_radius, sc.dist_thres = cfg->sc_dist_thres, sc.max_keyframes = cfg->sc_max_keyframes;
-        sc.float_math = cfg->float_math, sc.device = cfg->device, sc.n_shards = 1, sc.shard = 0, sc.side_stream = 0;
+        sc.float_math = cfg->float_math, sc.device = cfg->device, sc.n_shards = 1, sc.shard = 0, sc.side_stream = env_int("SCALOAM_PIPE_SC_LANE", 1, 0, 5);
+        // ScanContext entirely on the side stream it shares with stage C's surf filter (keyframe filter, descriptor, search: one in-order
+        // chain, no cross-stream wait).  With the descriptor + search behind stage B instead (scal_set_stream_mode(1)'s own split, lane 0
+        // here) stage B's chain queues behind a search that waits for the keyframe filter on the other stream: 3250-3360 scans/s against
+        // 3660 on one box (tools/gpu_pipe_knobs.sh).
         rc = scal_sc_create(&sc, &p->sc);
-        if (rc == SCAL_OK && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR &&
-            hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(double) * 1200 * ring) != hipSuccess) {
-            set_error("scal_pipeline_create: hipMalloc of the descriptor ring failed");
-            rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR) {
+            if (cfg->d_desc_ring) {
+                p->d_desc = cfg->d_desc_ring;
+            } else if (hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(double) * 1200 * ring) != hipSuccess) {
+                set_error("scal_pipeline_create: hipMalloc of the descriptor ring failed");
+                rc = SCAL_E_HIP;
+            } else {
+                p->own_desc = true;
+            }
         }
     }
     (void)scal_set_stream_mode(mode_before);  // the mode only matters while contexts are created
@@ -300,13 +345,14 @@ extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
     if (p->t_front.joinable()) p->t_front.join();
     if (p->t_pose.joinable()) p->t_pose.join();
     if (p->t_loop.joinable()) p->t_loop.join();
+    if (TIMING) p->tm_front.print("front"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
     (void)hipSetDevice(p->cfg.device);
     // consumers first: their destructors wait for the streams that still read the features contexts
     if (p->sc) scal_sc_destroy(p->sc);
     if (p->mp) scal_map_destroy(p->mp);
     if (p->od) scal_odom_destroy(p->od);
     for (auto* f : p->regs) scal_features_destroy(f);
-    if (p->d_desc) (void)hipFree(p->d_desc);
+    if (p->d_desc && p->own_desc) (void)hipFree(p->d_desc);
     delete p;
 }
 

@@ -29,6 +29,10 @@ struct RadixSort {
     DevBuf<int> vals_alt;
     DevBuf<int> hist;  // [nb][BINS_MAX] or [bins][nb]
     DevBuf<int> tile_sum;  // hierarchical scan of hist for large sorts
+    // names under which the launches are timed (scal_prof_*): a caller's stage tag is appended so that bench.py can charge the
+    // passes to the stage that ordered them (".C" stage C's stack filters, ".D" ScanContext's keyframe filter)
+    std::string n_hist = "k_rs_hist", n_scatter = "k_rs_scatter";
+    void set_tag(const char* tag) { n_hist = std::string("k_rs_hist") + tag, n_scatter = std::string("k_rs_scatter") + tag; }
 
     int init(int capacity);
     // Sorts the first *d_n pairs (*d_n <= n_bound, host-known) by bits [0, max_bits) of the key, ascending, stable.

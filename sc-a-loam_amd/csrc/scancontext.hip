@@ -885,6 +885,7 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
     }
     if (c->vf_cap < v.cap) {
         SCAL_TRY(c->vf.init(v.cap));
+        c->vf.set_tag(".D");
         SCAL_TRY(c->dsx.alloc(v.cap));
         SCAL_TRY(c->dsy.alloc(v.cap));
         SCAL_TRY(c->dsz.alloc(v.cap));

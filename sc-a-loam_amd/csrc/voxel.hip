@@ -197,31 +197,32 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
 
-// Whole filter for a cloud of <= VOX_SMALL points in ONE workgroup: bounding box, keys (14-bit voxel coordinates + arrival
-// index), LDS bitonic sort, run heads, ordered f32 centroids.  Replaces ~20 launches for the corner clouds.
+// Filter for a cloud of <= VOX_SMALL points in TWO launches (the general path takes ~12): the corner clouds of stage C.
+//   k_vox_small_sort    one workgroup per 512-chunk of the cloud (<= 16).  Every workgroup computes the bounding box and ALL keys
+//                       (14-bit voxel coordinates + arrival index) into LDS itself - 96 KB of L2-resident input, cheaper than a
+//                       launch that would hand them over - sorts the 512-chunks in registers (one wave each), then ranks the keys of
+//                       ITS chunk against the other chunks by binary search (the keys are distinct: they carry the arrival index)
+//                       and writes them to their sorted position.  No merge network across workgroups.
+//   k_vox_small_reduce  one workgroup per 256 sorted positions: run heads, ordered f32 centroids (the order PCL's accumulator sees),
+//                       the output offset of a workgroup = run heads in front of it, counted from the sorted keys directly.
+// Round 2 did all of this in ONE workgroup (58 us: an LDS bitonic sort of 8192 keys by 1024 threads is 30 us of it).
 constexpr int VOX_SMALL = 8192;
-__global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restrict__ d_n, float inv, SoA4 out, int* __restrict__ d_n_out, VoxMeta* m,
-                                                    VoxTail tail) {
+__global__ void __launch_bounds__(1024) k_vox_small_sort(CSoA4 in, const int* __restrict__ d_n, int n_cap, float inv, unsigned long long* __restrict__ sorted,
+                                                         VoxMeta* m, VoxTail tail) {
     extern __shared__ __align__(16) unsigned long long skeys[];
-    __shared__ int s_scan[17];
     __shared__ unsigned s_lo[3][16], s_hi[3][16];
     __shared__ int s_mb[4];
-    const int n = min(*d_n, VOX_SMALL);
+    const int n = min(*d_n, n_cap);
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if (tid == 0) SCAL_STAMP(0);
-    if (tid == 0) {
+    const int tile = blockIdx.x;
+    const int nc = (n + 511) >> 9;
+    if (tile == 0 && tid == 0) {
         m->error = (*d_n > VOX_SMALL) ? SCAL_E_CAPACITY : 0, m->guard = 0;
         if (m->error && tail.err_out) *tail.err_out = m->error;
     }
-    if (n == 0) {
-        if (tid == 0) {
-            *d_n_out = 0;
-            if (tail.slots_out) *tail.slots_out = min(*tail.other_n, tail.slots_cap);
-        }
-        return;
-    }
+    if (tile >= nc) return;  // uniform over the workgroup (n == 0: everybody leaves, the reduce kernel publishes the empty result)
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-    for (int i = tid; i < n; i += blockDim.x) {
+    for (int i = tid; i < n; i += 1024) {
         const unsigned a = float_to_ordered(in.x[i]), b = float_to_ordered(in.y[i]), c = float_to_ordered(in.z[i]);
         lo[0] = min(lo[0], a), hi[0] = max(hi[0], a);
         lo[1] = min(lo[1], b), hi[1] = max(hi[1], b);
@@ -248,19 +249,19 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
             s_mb[a] = static_cast<int>(floorf(mn * inv));
             if (static_cast<int>(floorf(mx * inv)) - s_mb[a] + 1 > 16383) wide = true;
         }
-        const bool guard = d[0] * d[1] * d[2] > 2147483647ll;
+        const bool guard = d[0] * d[1] * d[2] > 2147483647ll;  // PCL: "leaf size is too small", output = input
         s_mb[3] = guard ? 1 : 0;
-        m->guard = s_mb[3];
-        if (!guard && wide) {
-            m->error = SCAL_E_CAPACITY;
-            if (tail.err_out) *tail.err_out = SCAL_E_CAPACITY;
+        if (tile == 0) {
+            m->guard = s_mb[3];
+            if (!guard && wide) {
+                m->error = SCAL_E_CAPACITY;
+                if (tail.err_out) *tail.err_out = SCAL_E_CAPACITY;
+            }
         }
     }
     __syncthreads();
     const bool guard = s_mb[3] != 0;
-    if (tid == 0) SCAL_STAMP(1);
-    const int np2 = max(512, next_pow2(n));
-    for (int i = tid; i < np2; i += blockDim.x) {
+    for (int i = tid; i < nc * 512; i += 1024) {
         unsigned long long k = ~0ull;
         if (i < n) {
             if (guard) {
@@ -276,58 +277,93 @@ __global__ void __launch_bounds__(1024) k_vox_small(CSoA4 in, const int* __restr
         skeys[i] = k;
     }
     __syncthreads();
-    if (tid == 0) SCAL_STAMP(2);
-    block_sort_u64(skeys, np2, n);
-    if (tid == 0) SCAL_STAMP(3);
-    // every thread owns 8 consecutive sorted positions; their points are gathered up front (independent loads) so the
-    // ordered f32 sums below run on registers; a run that continues past the thread's window finishes from memory
-    constexpr int PER = VOX_SMALL / 1024;
-    const int c0 = min(n, tid * PER), c1 = min(n, c0 + PER);
-    float px[PER], py[PER], pz[PER], pw[PER];
-    unsigned long long kk[PER];
-    int heads = 0;
+    if (wv < nc) {
+        unsigned long long v[8];
+        chunk_load(skeys, wv, v);
+        wave_sort512(v);
+        chunk_store(skeys, wv, v);
+    }
+    __syncthreads();
+    // two threads per key of this workgroup's chunk: each searches half of the other chunks
+    const int j = tid >> 1, half = tid & 1;
+    const unsigned long long key = skeys[tile * 512 + j];
+    int rank = half == 0 ? j : 0;  // position inside the own chunk
+    for (int c = half; c < nc; c += 2) {
+        if (c == tile) continue;
+        const unsigned long long* ch = skeys + c * 512;
+        int l = 0, h = 512;  // lower bound: 513 possible answers, at most 10 probes
+        while (l < h) {
+            const int mid = (l + h) >> 1;
+            if (ch[mid] < key) l = mid + 1;
+            else h = mid;
+        }
+        rank += l;
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    if (half == 0 && key != ~0ull) sorted[rank] = key;
+}
+
+__global__ void __launch_bounds__(256) k_vox_small_reduce(const unsigned long long* __restrict__ sorted, const int* __restrict__ d_n, int n_cap, CSoA4 in,
+                                                          SoA4 out, int* __restrict__ d_n_out, VoxTail tail) {
+    const int n = min(*d_n, n_cap);
+    const int nb = (n + 255) / 256;
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        *d_n_out = 0;
+        if (tail.slots_out) *tail.slots_out = min(*tail.other_n, tail.slots_cap);
+    }
+    if (static_cast<int>(blockIdx.x) >= nb) return;
+    constexpr int SPAN = 512;
+    __shared__ int s[17];
+    __shared__ unsigned long long skey[SPAN];
+    __shared__ float sx[SPAN], sy[SPAN], sz[SPAN], sw[SPAN];
+    const int base = blockIdx.x * 256;
+    // run heads in front of this workgroup's positions: counted from the keys themselves (<= 7936 of them, L2-resident)
+    int before = 0;
+    for (int i = threadIdx.x; i < base; i += 256) before += (i == 0) || ((sorted[i] >> 14) != (sorted[i - 1] >> 14));
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int t = c0 + e;
-        kk[e] = t < c1 ? skeys[t] : ~0ull;
-        if (t < c1) {
-            const int g = static_cast<int>(kk[e] & 0x3fffu);
-            px[e] = in.x[g], py[e] = in.y[g], pz[e] = in.z[g], pw[e] = in.w[g];
-            heads += (t == 0) || ((kk[e] >> 14) != (skeys[t - 1] >> 14));
+    for (int h = 0; h < 2; ++h) {
+        const int t = h * 256 + threadIdx.x;
+        if (base + t < n) {
+            const unsigned long long k = sorted[base + t];
+            const int g = static_cast<int>(k & 0x3fffu);
+            skey[t] = k >> 14;
+            sx[t] = in.x[g], sy[t] = in.y[g], sz[t] = in.z[g], sw[t] = in.w[g];
         }
     }
-    int n_out = 0;
-    int opos = block_exclusive_scan(heads, s_scan, &n_out);
-    if (tid == 0) SCAL_STAMP(4);
-#pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const int t = c0 + e;
-        if (t < c1 && ((t == 0) || ((kk[e] >> 14) != (skeys[t - 1] >> 14)))) {
-            const unsigned long long vk = kk[e] >> 14;
-            float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-            int cntv = 0;
-#pragma unroll
-            for (int e2 = 0; e2 < PER; ++e2) {  // members inside this thread's window (registers)
-                if (e2 >= e && c0 + e2 < c1 && (kk[e2] >> 14) == vk) ax += px[e2], ay += py[e2], az += pz[e2], aw += pw[e2], ++cntv;
-            }
-            int u = c1;
-            if (c0 + e + cntv == c1) {  // the run reaches the end of the window: continue from memory
-                while (u < n && (skeys[u] >> 14) == vk) {
-                    const int g = static_cast<int>(skeys[u] & 0x3fffu);
-                    ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
-                    ++u, ++cntv;
-                }
-            }
-            const float cntf = static_cast<float>(cntv);
-            out.x[opos] = ax / cntf, out.y[opos] = ay / cntf, out.z[opos] = az / cntf, out.w[opos] = aw / cntf;
-            ++opos;
-        }
+    int block_off;
+    {
+        // block sum of `before`: the exclusive scan's total
+        block_exclusive_scan(before, s, &block_off);
     }
-    if (tid == 0) {
+    const int i = base + threadIdx.x;
+    const int head = (i < n) && (i == 0 || (sorted[i] >> 14) != (sorted[i - 1] >> 14));
+    int total;
+    const int rank = block_exclusive_scan(head, s, &total);  // contains the barrier that publishes the staged span
+    if (static_cast<int>(blockIdx.x) == nb - 1 && threadIdx.x == 0) {
+        const int n_out = block_off + total;
         *d_n_out = n_out;
         if (tail.slots_out) *tail.slots_out = min(*tail.other_n + n_out, tail.slots_cap);
     }
-    if (tid == 0) SCAL_STAMP(5);
+    if (!head) return;
+    const unsigned long long k = skey[threadIdx.x];
+    const int lim = min(n - base, SPAN);
+    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+    int t = threadIdx.x;
+    while (t < lim && skey[t] == k) {
+        ax += sx[t], ay += sy[t], az += sz[t], aw += sw[t];
+        ++t;
+    }
+    int u = base + t;
+    if (t == SPAN) {
+        while (u < n && (sorted[u] >> 14) == k) {
+            const int g = static_cast<int>(sorted[u] & 0x3fffu);
+            ax += in.x[g], ay += in.y[g], az += in.z[g], aw += in.w[g];
+            ++u;
+        }
+    }
+    const float c = static_cast<float>(u - i);
+    const int o = block_off + rank;
+    out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_voxel)
 
@@ -340,7 +376,7 @@ int VoxelFilter::init(int capacity) {
     SCAL_TRY(meta.alloc(1));
     SCAL_TRY(box_parts.alloc(6 * 128));
     // every caller has selected its device by now: the attribute is per device, not per process
-    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vox_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SCAL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_vox_small_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  static_cast<int>(sizeof(unsigned long long) * VOX_SMALL)));
     return SCAL_OK;
 }
@@ -351,9 +387,11 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
     const VoxTail tl = tail ? *tail : VoxTail();
     if (n_bound <= VOX_SMALL) {
         const int lds = sizeof(unsigned long long) * VOX_SMALL;  // attribute set per device in VoxelFilter::init
-        {
-            SCAL_LAUNCH_PROF("k_vox_small", k_vox_small, dim3(1), dim3(1024), lds, s, in, d_n, inv, out, d_n_out, meta.p, tl);
-        }
+        const int n_cap = min(VOX_SMALL, cap);
+        const int chunks = max(1, div_up(min(n_bound, n_cap), 512));  // workgroups beyond the cloud's chunks leave at once
+        SCAL_LAUNCH_PROF(n_small.c_str(), k_vox_small_sort, dim3(chunks), dim3(1024), lds, s, in, d_n, n_cap, inv, keys.p, meta.p, tl);
+        SCAL_LAUNCH_PROF(n_small_reduce.c_str(), k_vox_small_reduce, dim3(max(1, div_up(min(n_bound, n_cap), 256))), dim3(256), 0, s, keys.p, d_n, n_cap, in, out,
+                         d_n_out, tl);
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
     }
@@ -361,13 +399,13 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
     if (!ext_parts) {
         n_parts = min(nb, 128);
         ext_parts = box_parts.p;
-        SCAL_LAUNCH_PROF("k_vox_bbox", k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
+        SCAL_LAUNCH_PROF(n_bbox.c_str(), k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
     }
-    SCAL_LAUNCH_PROF("k_vox_keys", k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
+    SCAL_LAUNCH_PROF(n_keys.c_str(), k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
-    SCAL_LAUNCH_PROF("k_vox_heads", k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    SCAL_LAUNCH_PROF("k_vox_reduce", k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
+    SCAL_LAUNCH_PROF(n_heads.c_str(), k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
+    SCAL_LAUNCH_PROF(n_reduce.c_str(), k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }

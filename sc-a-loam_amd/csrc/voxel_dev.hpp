@@ -37,6 +37,14 @@ struct VoxelFilter {
     DevBuf<int> blockcnt;
     DevBuf<VoxMeta> meta;
     DevBuf<unsigned> box_parts;  // [128][6] per-block bounding boxes (k_vox_bbox)
+    std::string n_bbox = "k_vox_bbox", n_keys = "k_vox_keys", n_heads = "k_vox_heads", n_reduce = "k_vox_reduce", n_small = "k_vox_small",
+                n_small_reduce = "k_vox_small_reduce";
+    void set_tag(const char* tag) {  // stage tag of the timed launches, see RadixSort::set_tag
+        n_bbox = std::string("k_vox_bbox") + tag, n_keys = std::string("k_vox_keys") + tag, n_heads = std::string("k_vox_heads") + tag;
+        n_reduce = std::string("k_vox_reduce") + tag, n_small = std::string("k_vox_small") + tag;
+        n_small_reduce = std::string("k_vox_small_reduce") + tag;
+        sorter.set_tag(tag);
+    }
 
     int init(int capacity);
     // out must hold `cap` points.  The key packs the three voxel coordinates as tightly as the bounding box allows

@@ -132,7 +132,7 @@ struct Channel {  // a ROS topic between two nodes: FIFO, bounded like the refer
 
 struct Args {
     std::string scans, mode = "pipeline", poses;
-    int lidar = SCAL_HDL64, n_scans = 64, warmup = 5, sc_db = 0, resident = 0, max_points = 0, steps = 0, sc = 1;
+    int lidar = SCAL_HDL64, n_scans = 64, warmup = 5, sc_db = 0, resident = 0, max_points = 0, steps = 0, sc = 1, ahead = 4;
     double min_range = 5.0, sc_thres = 0.4;
     float line = 0.4f, plane = 0.8f;
 };
@@ -288,7 +288,7 @@ void make_pipeline(const Args& a, const std::vector<Scan>& scans) {
 std::vector<Pose> run_pipeline(const Args& a, const std::vector<Scan>& scans, int first, int last) {
     if (!g_pipe) make_pipeline(a, scans);
     std::vector<Pose> out(last - first);
-    const int ahead = 4;  // scans pushed beyond the one whose pose is awaited
+    const int ahead = a.ahead;  // scans pushed beyond the one whose pose is awaited
     int popped = first;
     auto pop_one = [&] {
         scal_pipeline_result r;
@@ -372,6 +372,7 @@ int main(int argc, char** argv) {
         else if (k == "--sc") a.sc = std::atoi(val());
         else if (k == "--sc-thres") a.sc_thres = std::atof(val());
         else if (k == "--resident") a.resident = std::atoi(val());
+        else if (k == "--ahead") a.ahead = std::max(0, std::min(24, std::atoi(val())));
         else if (k == "--min-range") a.min_range = std::atof(val());
         else if (k == "--line") a.line = static_cast<float>(std::atof(val()));
         else if (k == "--plane") a.plane = static_cast<float>(std::atof(val()));
@@ -387,7 +388,7 @@ int main(int argc, char** argv) {
             }
         } else {
             std::fprintf(stderr, "usage: replay_main --scans FILE [--mode pipeline|integrated|serial] [--lidar hdl64|vlp16|hdl32|os1] [--min-range m]\n"
-                                 "                   [--line m --plane m] [--sc 0|1] [--sc-db n] [--sc-thres d] [--warmup n] [--steps n] [--resident 0|1] [--poses FILE]\n");
+                                 "                   [--line m --plane m] [--sc 0|1] [--sc-db n] [--sc-thres d] [--warmup n] [--steps n] [--resident 0|1] [--ahead n] [--poses FILE]\n");
             return 2;
         }
     }

@@ -92,7 +92,7 @@ class PipelineConfig(C.Structure):
     _fields_ = [("lidar_type", C.c_int), ("n_scans", C.c_int), ("minimum_range", C.c_double), ("max_points", C.c_int),
                 ("float_math", C.c_int), ("check_finite", C.c_int), ("line_res", C.c_float), ("plane_res", C.c_float),
                 ("max_map_points", C.c_int), ("sc_max_radius", C.c_double), ("sc_dist_thres", C.c_double), ("sc_max_keyframes", C.c_int),
-                ("sc_mode", C.c_int), ("device", C.c_int), ("ring", C.c_int), ("depth", C.c_int)]
+                ("sc_mode", C.c_int), ("device", C.c_int), ("ring", C.c_int), ("depth", C.c_int), ("d_desc_ring", C.c_void_p)]
 
 
 class PipelineResult(C.Structure):
@@ -851,9 +851,9 @@ class Pipeline:
     ScanContext part) working on consecutive scans at the same time, scheduled inside the library.  push() a scan, pop() poses in order."""
 
     def __init__(self, lidar_type, minimum_range, max_points=400000, line_res=0.4, plane_res=0.8, max_map_points=4000000, sc_mode=SC_EVERY_SCAN,
-                 sc_max_radius=80.0, sc_dist_thres=0.2, sc_max_keyframes=8192, device=0, ring=0, depth=0, float_math=0, check_finite=1):
+                 sc_max_radius=80.0, sc_dist_thres=0.2, sc_max_keyframes=8192, device=0, ring=0, depth=0, float_math=0, check_finite=1, d_desc_ring=None):
         self.cfg = PipelineConfig(lidar_type, SCAN_LINES.get(lidar_type, 0), float(minimum_range), max_points, float_math, check_finite, line_res,
-                                  plane_res, max_map_points, sc_max_radius, sc_dist_thres, sc_max_keyframes, sc_mode, device, ring, depth)
+                                  plane_res, max_map_points, sc_max_radius, sc_dist_thres, sc_max_keyframes, sc_mode, device, ring, depth, d_desc_ring)
         self.h = C.c_void_p()
         _check(lib().scal_pipeline_create(C.byref(self.cfg), C.byref(self.h)))
         self.sc = _borrow(SCManager, lib().scal_pipeline_sc(self.h)) if sc_mode != SC_OFF else None

@@ -115,3 +115,29 @@ def sharded_downsample(points, leaf, group=None, local_filter=None):
             _filters[dev] = gpu_voxel_filter(dev)  # keeps its map-merge context (and its buffers) between calls
         local_filter = _filters[dev]
     return local_filter(recv, leaf)
+
+
+class TreePeriodBook:
+    """detectLoopClosureID's kd-tree bookkeeping (Scancontext.cpp:353-365: the ring-key tree is rebuilt when `tree_making_period_conter
+    % 30 == 0`, then the counter is incremented, so the tree is up to 29 queries stale) for a database that every scan step extends by
+    `world` descriptors - rank 0's, rank 1's, ... in that global order - and queries once per descriptor.  limits[q] = database size
+    the tree of query q was built from; a shard then considers keyframes with index < limits[q] - 30 (scal_sc_shard_query_batch_device).
+    The bookkeeping depends on the ORDER of the queries only, so an exchange that carries Q scan steps at once gives every query the
+    limit it would have had with one exchange per scan."""
+
+    def __init__(self, n_global=0, period=30):
+        self.n_global, self.period = int(n_global), int(period)
+        self.counter, self.size_at_rebuild = 0, 0
+
+    def step(self, world=1):
+        self.n_global += world  # the step's descriptors are all in the database before its first query is answered
+        limits = []
+        for _ in range(world):
+            if self.counter % self.period == 0:
+                self.size_at_rebuild = self.n_global
+            self.counter += 1
+            limits.append(self.size_at_rebuild)
+        return limits
+
+    def batch(self, q_steps, world=1):
+        return [v for _ in range(q_steps) for v in self.step(world)]

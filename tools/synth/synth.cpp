@@ -155,16 +155,63 @@ static int cast_scan(const World& w, const Quat& q, const V3& t, uint64_t noise_
         if (std::hypot(c.cx - t.x, c.cy - t.y) < w.max_range + c.r) cyls.push_back(c);
     std::vector<float> rng_out(static_cast<size_t>(n_rays), -1.f);
     const int threads = w.cfg.threads > 0 ? w.cfg.threads : omp_get_max_threads();
+    // Azimuth culling (pure speed-up, outputs unchanged): every object is a vertical prism over its footprint, so a ray can only
+    // meet it when the ray's world azimuth lies inside the azimuth interval the footprint subtends from the sensor.  Per object:
+    // centre and half-width of that interval (pi = always tested); per azimuth column: the interval its beams cover after the
+    // rotation by q.  Objects are still tested in their original order, with the original arithmetic.
+    auto wrap = [](double x) {
+        while (x > M_PI) x -= 2.0 * M_PI;
+        while (x <= -M_PI) x += 2.0 * M_PI;
+        return x;
+    };
+    const double cull_eps = 1e-6;
+    std::vector<double> box_c(boxes.size()), box_hw(boxes.size()), cyl_c(cyls.size()), cyl_hw(cyls.size());
+    for (size_t i = 0; i < boxes.size(); ++i) {
+        const Box& b = boxes[i];
+        const bool near = t.x > b.x0 - 0.01 && t.x < b.x1 + 0.01 && t.y > b.y0 - 0.01 && t.y < b.y1 + 0.01;
+        box_c[i] = std::atan2(0.5 * (b.y0 + b.y1) - t.y, 0.5 * (b.x0 + b.x1) - t.x);
+        double hw = 0.0;
+        const double cx[4] = {b.x0, b.x1, b.x0, b.x1}, cy[4] = {b.y0, b.y0, b.y1, b.y1};
+        for (int k = 0; k < 4; ++k) hw = std::max(hw, std::fabs(wrap(std::atan2(cy[k] - t.y, cx[k] - t.x) - box_c[i])));
+        box_hw[i] = near ? M_PI : hw + cull_eps;
+    }
+    for (size_t i = 0; i < cyls.size(); ++i) {
+        const Cyl& c = cyls[i];
+        const double dist = std::hypot(c.cx - t.x, c.cy - t.y);
+        cyl_c[i] = std::atan2(c.cy - t.y, c.cx - t.x);
+        cyl_hw[i] = dist <= 1.001 * c.r + 0.01 ? M_PI : std::asin(std::min(1.0, c.r / dist)) + cull_eps;
+    }
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int a = 0; a < w.n_az; ++a) {
         const double phi = -2.0 * M_PI * a / w.n_az;  // clockwise
+        // azimuth interval of this column's beams: reference + [lo, hi]; `all` = a beam points (almost) straight up or down
+        double ref = 0.0, lo = 0.0, hi = 0.0;
+        bool all = false;
+        for (int b = 0; b < B; ++b) {
+            const double e = w.elev[b];
+            V3 ds{std::cos(e) * std::cos(phi), std::cos(e) * std::sin(phi), std::sin(e)};
+            V3 d = rotate(q, ds);
+            if (d.x * d.x + d.y * d.y < 1e-6) all = true;
+            const double az = std::atan2(d.y, d.x);
+            if (b == 0) ref = az;
+            const double df = wrap(az - ref);
+            lo = std::min(lo, df), hi = std::max(hi, df);
+        }
+        if (hi - lo > M_PI) all = true;
+        const double mid = ref + 0.5 * (lo + hi), half = 0.5 * (hi - lo) + cull_eps;
+        std::vector<int> bsel, csel;
+        for (size_t i = 0; i < boxes.size(); ++i)
+            if (all || box_hw[i] >= M_PI || std::fabs(wrap(box_c[i] - mid)) <= box_hw[i] + half) bsel.push_back(static_cast<int>(i));
+        for (size_t i = 0; i < cyls.size(); ++i)
+            if (all || cyl_hw[i] >= M_PI || std::fabs(wrap(cyl_c[i] - mid)) <= cyl_hw[i] + half) csel.push_back(static_cast<int>(i));
         for (int b = 0; b < B; ++b) {
             const double e = w.elev[b];
             V3 ds{std::cos(e) * std::cos(phi), std::cos(e) * std::sin(phi), std::sin(e)};
             V3 d = rotate(q, ds);
             double best = 1e30;
             if (d.z < -1e-9) best = -t.z / d.z;  // ground z = 0
-            for (const Box& bx : boxes) {
+            for (const int bi : bsel) {
+                const Box& bx = boxes[bi];
                 double t0 = 0.0, t1 = best;
                 const double lo[3] = {bx.x0, bx.y0, 0.0}, hi[3] = {bx.x1, bx.y1, bx.h};
                 const double o[3] = {t.x, t.y, t.z}, dd[3] = {d.x, d.y, d.z};
@@ -182,7 +229,8 @@ static int cast_scan(const World& w, const Quat& q, const V3& t, uint64_t noise_
                 }
                 if (hit && t0 > 0.05 && t0 < best) best = t0;
             }
-            for (const Cyl& c : cyls) {
+            for (const int ci : csel) {
+                const Cyl& c = cyls[ci];
                 const double ox = t.x - c.cx, oy = t.y - c.cy;
                 const double A = d.x * d.x + d.y * d.y;
                 if (A < 1e-12) continue;
