@@ -1,0 +1,215 @@
+// In-launch batching of independent sequences ("report batched/streamed numbers - several independent
+// scans or sequences in flight - separately").
+//
+// One scan's kernels run on 1 to ~50 workgroups of a 256-CU part and are latency-bound, and the device advances no more than four
+// dependent chains at full rate, so several sequences only go faster when their kernels share a LAUNCH.
+// Two pieces, both in this header:
+//
+//  * Every hot-path kernel takes its arguments as Batch<Pack>: up to BATCH_MAX argument sets by value in the kernarg segment,
+//    blockIdx.z selects the set (a scalar load with a uniform offset; the kernel body is the unchanged __device__ function
+//    `<kernel>_body`).  A launch for one sequence is a batch of one.
+//
+//  * A thread-local Recorder.  While one is installed, SCAL_LAUNCH and the stream-operation wrappers below (event record / wait,
+//    async copies) do not touch the device: they append to the recorder's list.  The per-stage entry points of the C-ABI are run
+//    once per sequence under a recorder each; zip_and_launch() then walks the S lists position by position: launches of the same
+//    kernel with the same shape become ONE launch with gridDim.z = S, everything else (events, copies) is replayed per sequence
+//    in list order.  All sequences use the same per-stage streams, so list order is stream order.  An operation that has to
+//    wait for the device while recording (a fallback path inside an entry point) first flushes its own list - that sequence then
+//    simply runs unbatched for this step.  Results are bit-identical to running every sequence on its own: the kernel bodies and
+//    their per-sequence arguments are the same, only the launch that carries them differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace scal {
+
+constexpr int BATCH_MAX = 4;
+
+// ---- argument sets ------------------------------------------------------------------------------------------------------------
+template <size_t I, class T>
+struct PackLeaf {
+    T v;
+};
+template <class Seq, class... T>
+struct PackImpl;
+template <size_t... I, class... T>
+struct PackImpl<std::index_sequence<I...>, T...> : PackLeaf<I, T>... {};
+template <class... T>
+using Pack = PackImpl<std::index_sequence_for<T...>, T...>;
+
+template <size_t I, class T>
+__host__ __device__ __forceinline__ const T& pack_get(const PackLeaf<I, T>& l) {
+    return l.v;
+}
+
+template <class P>
+struct Batch {
+    P p[BATCH_MAX];
+};
+
+template <class F>
+struct KernelTraits;
+template <class... A>
+struct KernelTraits<void (*)(A...)> {
+    using pack = Pack<A...>;
+    static constexpr size_t n = sizeof...(A);
+    template <class... U>
+    static pack make(U&&... u) {
+        return make_impl(std::index_sequence_for<A...>(), std::forward<U>(u)...);
+    }
+    template <size_t... I, class... U>
+    static pack make_impl(std::index_sequence<I...>, U&&... u) {
+        static_assert(sizeof...(U) == sizeof...(A), "wrong number of kernel arguments");
+        return pack{PackLeaf<I, A>{static_cast<A>(std::forward<U>(u))}...};
+    }
+};
+
+// ---- recorder -----------------------------------------------------------------------------------------------------------------
+using BatchLaunchFn = hipError_t (*)(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs);
+
+struct RecOp {
+    // launch
+    BatchLaunchFn fn = nullptr;
+    std::string name;
+    dim3 grid, block;
+    int lds = 0;
+    hipStream_t stream = nullptr;
+    std::vector<unsigned char> pack;
+    // anything else, replayed per sequence
+    std::function<hipError_t()> other;
+};
+
+struct Recorder {
+    std::vector<RecOp> ops;
+    bool broken = false;  // this sequence had to flush in the middle of its list: it runs unbatched for the rest of the step
+    hipError_t flush();   // launches / replays everything recorded so far, in order, as batches of one
+};
+
+extern thread_local Recorder* g_recorder;
+
+// launches the lists of n recorders (all recorded on this thread for the same per-stage entry point of n sequences): same-shaped
+// launches of the same kernel are merged, the rest is replayed in order.  Clears the lists.  Returns the first HIP error.
+hipError_t zip_and_launch(Recorder* const* recs, int n);
+
+bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);  // common.cpp
+
+// ---- stream operations that may be recorded -------------------------------------------------------------------------------------
+inline hipError_t op_event_record(hipEvent_t ev, hipStream_t s) {
+    if (Recorder* r = g_recorder) {
+        RecOp o;
+        o.other = [ev, s] { return hipEventRecord(ev, s); };
+        r->ops.push_back(std::move(o));
+        return hipSuccess;
+    }
+    return hipEventRecord(ev, s);
+}
+inline hipError_t op_stream_wait_event(hipStream_t s, hipEvent_t ev, unsigned flags) {
+    if (Recorder* r = g_recorder) {
+        RecOp o;
+        o.other = [ev, s, flags] { return hipStreamWaitEvent(s, ev, flags); };
+        r->ops.push_back(std::move(o));
+        return hipSuccess;
+    }
+    return hipStreamWaitEvent(s, ev, flags);
+}
+inline hipError_t op_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
+    if (Recorder* r = g_recorder) {
+        RecOp o;
+        o.other = [dst, src, bytes, kind, s] { return hipMemcpyAsync(dst, src, bytes, kind, s); };
+        r->ops.push_back(std::move(o));
+        return hipSuccess;
+    }
+    return hipMemcpyAsync(dst, src, bytes, kind, s);
+}
+inline hipError_t op_memset_async(void* dst, int value, size_t bytes, hipStream_t s) {
+    if (Recorder* r = g_recorder) {
+        RecOp o;
+        o.other = [dst, value, bytes, s] { return hipMemsetAsync(dst, value, bytes, s); };
+        r->ops.push_back(std::move(o));
+        return hipSuccess;
+    }
+    return hipMemsetAsync(dst, value, bytes, s);
+}
+// operations that wait for (or look at) the device: whatever this thread recorded so far has to be on the device first
+inline hipError_t op_flush_for_wait() {
+    if (Recorder* r = g_recorder) {
+        r->broken = true;
+        return r->flush();
+    }
+    return hipSuccess;
+}
+inline hipError_t op_event_synchronize(hipEvent_t ev) {
+    hipError_t e = op_flush_for_wait();
+    return e != hipSuccess ? e : hipEventSynchronize(ev);
+}
+inline hipError_t op_stream_synchronize(hipStream_t s) {
+    hipError_t e = op_flush_for_wait();
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+}
+inline hipError_t op_event_query(hipEvent_t ev) {
+    hipError_t e = op_flush_for_wait();
+    return e != hipSuccess ? e : hipEventQuery(ev);
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------------------------
+// SCAL_KERNEL(bounds, k_name) behind the definition of `__device__ void k_name_body(args...)` defines
+//   __global__ k_name(Batch<pack>)          the kernel: argument set blockIdx.z, body unchanged
+//   k_name_launch(...)                      BatchLaunchFn: n argument sets in one launch (gridDim.z = n), with the optional timing
+//                                           events of scal_prof_* attached to the dispatch
+template <class Tag, class P, size_t... I>
+__device__ __forceinline__ void batch_call(const P& p, std::index_sequence<I...>) {
+    Tag::call(pack_get<I>(p)...);
+}
+
+template <class P, class K>
+inline hipError_t batch_launch_impl(K kernel, const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) {
+    Batch<P> b;
+    for (int i = 0; i < n && i < BATCH_MAX; ++i) std::memcpy(static_cast<void*>(&b.p[i]), packs[i], sizeof(P));
+    grid.z = static_cast<unsigned>(n);
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (prof_begin(name, s, &pe0, &pe1))
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, pe0, pe1, 0, b);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, b);
+    return hipSuccess;
+}
+
+#define SCAL_KERNEL(bounds, kname)                                                                                                       \
+    using kname##_traits = ::scal::KernelTraits<decltype(&kname##_body)>;                                                                \
+    struct kname##_tag {                                                                                                                 \
+        template <class... T>                                                                                                            \
+        __device__ __forceinline__ static void call(const T&... t) {                                                                     \
+            kname##_body(t...);                                                                                                          \
+        }                                                                                                                                \
+    };                                                                                                                                   \
+    static __global__ void __launch_bounds__(bounds) kname(::scal::Batch<kname##_traits::pack> b) {                                      \
+        ::scal::batch_call<kname##_tag>(b.p[blockIdx.z], std::make_index_sequence<kname##_traits::n>());                                 \
+    }                                                                                                                                    \
+    static hipError_t kname##_launch(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) { \
+        return ::scal::batch_launch_impl<kname##_traits::pack>(kname, name, grid, block, lds, s, n, packs);                              \
+    }
+
+// one sequence's launch: recorded when a recorder is installed on this thread, a batch of one otherwise
+template <class Traits, class... U>
+inline void launch_or_record(BatchLaunchFn fn, const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, U&&... u) {
+    const typename Traits::pack p = Traits::make(std::forward<U>(u)...);
+    if (Recorder* r = g_recorder) {
+        RecOp o;
+        o.fn = fn, o.name = name, o.grid = grid, o.block = block, o.lds = lds, o.stream = s;
+        o.pack.resize(sizeof(p));
+        std::memcpy(o.pack.data(), static_cast<const void*>(&p), sizeof(p));
+        r->ops.push_back(std::move(o));
+        return;
+    }
+    const void* one = &p;
+    (void)fn(name, grid, block, lds, s, 1, &one);
+}
+#define SCAL_LAUNCH(name, kname, grid, block, lds, stream, ...) \
+    ::scal::launch_or_record<kname##_traits>(kname##_launch, name, grid, block, lds, stream, __VA_ARGS__)
+
+}  // namespace scal

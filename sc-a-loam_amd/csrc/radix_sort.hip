@@ -82,6 +82,8 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     __shared__ int sbase[RS_BINS_MAX];
     __shared__ int smem[17];
     const int w = wave_id(), l = lane_id();
+    const bool stamp = blockIdx.x == static_cast<unsigned>(nb / 2) && threadIdx.x == 0 && pass == 0;
+    if (stamp) SCAL_STAMP(0);
     // scatter base of digit d for this block = (exclusive prefix of the digit totals)[d] + sum_{b < block} hist[d][b]
     if (scanned) {  // large sorts: the histogram matrix has been turned into scatter bases by the hierarchical scan
         for (int d = threadIdx.x; d < bins; d += 256) sbase[d] = hist[d * nb + blockIdx.x];
@@ -146,8 +148,10 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
             }
         }
     }
+    if (stamp) SCAL_STAMP(1);
     for (int d = threadIdx.x; d < bins; d += 256) cnt[0][d] = 0, cnt[1][d] = 0, cnt[2][d] = 0, cnt[3][d] = 0;
     __syncthreads();
+    if (stamp) SCAL_STAMP(2);
     const int base = blockIdx.x * RS_TILE + w * (RS_ITEMS * 64);
     unsigned long long k[RS_ITEMS];
     int rk[RS_ITEMS];
@@ -165,7 +169,9 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
         if (valid && (m & lanemask_lt()) == 0) cnt[w][d] = static_cast<unsigned short>(prev + __popcll(m));
         __builtin_amdgcn_wave_barrier();
     }
+    if (stamp) SCAL_STAMP(3);
     __syncthreads();
+    if (stamp) SCAL_STAMP(4);
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int e = base + j * 64 + l;
@@ -178,7 +184,9 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
             ovals[pos] = vals[e];
         }
     }
+    if (stamp) SCAL_STAMP(5);
 }
+SCAL_DEFINE_STAMP_READER(scal_debug_stamps_radix)
 
 // ---- hierarchical exclusive scan of the flattened histogram matrix (digit-major: exactly the scatter base of (digit, block)),
 // used when the sort has too many blocks for every scatter workgroup to sum the matrix rows itself.  m = bins * nb.
