@@ -491,6 +491,19 @@ scal_map_t* scal_pipeline_map(scal_pipeline_t* p);
 scal_odom_t* scal_pipeline_odom(scal_pipeline_t* p);
 scal_features_t* scal_pipeline_features(scal_pipeline_t* p, int i);
 
+/* ---- several independent sequences (sensor streams) on ONE GPU, their kernels sharing launches ("batched /
+ * streamed numbers - several independent scans or sequences in flight").  One scan's kernels run on 1..50 workgroups of a 256-CU part
+ * and the device advances only four dependent chains at full rate, so S sequences go faster only when their kernels share a launch:
+ * every hot-path kernel takes up to 4 argument sets (blockIdx.z selects one), the per-stage calls of the S sequences are recorded and
+ * merged position by position (csrc/batch.hpp).  The sequences step together: push one scan of EVERY sequence, pop their S results.
+ * Each sequence has its own contexts (map, poses, ScanContext database), and its poses are bit-identical to running it alone. */
+int scal_pipeline_create_multi(const scal_pipeline_config* cfg, int n_seqs /* 1..4 */, scal_pipeline_t** p);
+int scal_pipeline_seqs(scal_pipeline_t* p);
+int scal_pipeline_push_device_multi(scal_pipeline_t* p, const float* const* d_xyz /* [n_seqs] */, const int* n /* [n_seqs] */, int stride_floats);
+int scal_pipeline_pop_multi(scal_pipeline_t* p, scal_pipeline_result* out /* [n_seqs] */);
+scal_sc_t* scal_pipeline_sc_of(scal_pipeline_t* p, int seq);
+scal_map_t* scal_pipeline_map_of(scal_pipeline_t* p, int seq);
+
 /* ------------------------------------------------------------------ factor evaluation (Ceres adapter mode)
  * Batched residual / Jacobian / normal-equation evaluation of lidarFactor.hpp:12-138 blocks at a pose,
  * for a host that keeps ceres::Problem orchestration.  kind: 0 LidarEdgeFactor(a,b),

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -54,8 +55,10 @@ struct Batch {
 
 template <class F>
 struct KernelTraits;
+template <class... B>
+struct KernelTraits<void (*)(B...)> : KernelTraits<void(std::decay_t<B>...)> {};
 template <class... A>
-struct KernelTraits<void (*)(A...)> {
+struct KernelTraits<void(A...)> {
     using pack = Pack<A...>;
     static constexpr size_t n = sizeof...(A);
     template <class... U>

@@ -5,6 +5,70 @@
 
 namespace scal {
 
+// ---------------------------------------------------------------------------------------------- in-launch batching (batch.hpp)
+thread_local Recorder* g_recorder = nullptr;
+
+static hipError_t run_op(const RecOp& o) {
+    if (!o.fn) return o.other();
+    const void* one = o.pack.data();
+    return o.fn(o.name.c_str(), o.grid, o.block, o.lds, o.stream, 1, &one);
+}
+
+hipError_t Recorder::flush() {
+    Recorder* keep = g_recorder;
+    g_recorder = nullptr;  // the replayed operations go to the device
+    hipError_t first = hipSuccess;
+    for (const RecOp& o : ops) {
+        const hipError_t e = run_op(o);
+        if (first == hipSuccess) first = e;
+    }
+    ops.clear();
+    g_recorder = keep;
+    return first;
+}
+
+hipError_t zip_and_launch(Recorder* const* recs, int n) {
+    Recorder* keep = g_recorder;
+    g_recorder = nullptr;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) { if (first == hipSuccess) first = e; };
+    // lists with the same structure (same kernels and shapes at the same positions) are merged; a list that differs - a sequence
+    // that took another path through its entry point, or had to flush on the way - is replayed on its own
+    auto same = [](const RecOp& a, const RecOp& b) {
+        if ((a.fn == nullptr) != (b.fn == nullptr)) return false;
+        if (!a.fn) return true;
+        return a.fn == b.fn && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.block.x == b.block.x && a.lds == b.lds && a.stream == b.stream &&
+               a.pack.size() == b.pack.size();
+    };
+    std::vector<bool> done(n, false);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        Recorder* lead = recs[i];
+        std::vector<Recorder*> group{lead};
+        done[i] = true;
+        if (!lead->broken)
+            for (int j = i + 1; j < n && static_cast<int>(group.size()) < BATCH_MAX; ++j) {
+                if (done[j] || recs[j]->broken || recs[j]->ops.size() != lead->ops.size()) continue;
+                bool ok = true;
+                for (size_t k = 0; k < lead->ops.size() && ok; ++k) ok = same(lead->ops[k], recs[j]->ops[k]);
+                if (ok) group.push_back(recs[j]), done[j] = true;
+            }
+        for (size_t k = 0; k < lead->ops.size(); ++k) {
+            const RecOp& o = lead->ops[k];
+            if (o.fn) {
+                const void* packs[BATCH_MAX];
+                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->ops[k].pack.data();
+                note(o.fn(o.name.c_str(), o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
+            } else {
+                for (Recorder* r : group) note(r->ops[k].other());
+            }
+        }
+        for (Recorder* r : group) r->ops.clear(), r->broken = false;
+    }
+    g_recorder = keep;
+    return first;
+}
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {

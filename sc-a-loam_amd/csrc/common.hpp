@@ -9,6 +9,7 @@
 #include <vector>
 #include <mutex>
 #include "../../include/scaloam_hip.h"
+#include "batch.hpp"
 
 namespace scal {
 
@@ -70,7 +71,7 @@ struct DevBuf {
         return SCAL_OK;
     }
     int zero(hipStream_t s) {
-        hipError_t e = hipMemsetAsync(p, 0, n * sizeof(T), s);
+        hipError_t e = op_memset_async(p, 0, n * sizeof(T), s);
         if (e != hipSuccess) {
             set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
             return SCAL_E_HIP;

@@ -61,7 +61,7 @@ extern "C" int scal_factors_eval(int device, int n, const int* kind, const doubl
     SCAL_HIP(hipMemset(dpart.p, 0, sizeof(double) * LM_NACC * nb));
     hipLaunchKernelGGL(k_factors_arm, dim3(1), dim3(64), 0, 0, dst.p, dx.p);
     FactorSoA F{dvalid.p, dkind.p, dcp.p, dpa.p, dpb.p, cap};
-    hipLaunchKernelGGL(k_lm_eval, dim3(nb), dim3(256), 0, 0, F, static_cast<const int*>(nullptr), dst.p, 0, dpart.p);
+    SCAL_LAUNCH("k_lm_eval", k_lm_eval, dim3(nb), dim3(256), 0, static_cast<hipStream_t>(nullptr), F, static_cast<const int*>(nullptr), dst.p, 0, dpart.p);
     SCAL_HIP(hipGetLastError());
     std::vector<double> part((size_t)LM_NACC * nb);
     SCAL_HIP(hipMemcpy(part.data(), dpart.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost));

@@ -74,7 +74,7 @@ struct KCfg {
     float thres2;
 };
 
-__global__ void k_pre(const float* __restrict__ in, int n, int stride, KCfg c, FeatParams* P) {
+__device__ __forceinline__ void k_pre_body(const float* __restrict__ in, int n, int stride, const KCfg& c, FeatParams* P) {
     __shared__ int s_first, s_last;
     if (threadIdx.x == 0) s_first = INT_MAX, s_last = -1;
     __syncthreads();
@@ -116,9 +116,10 @@ __global__ void k_pre(const float* __restrict__ in, int n, int stride, KCfg c, F
         }
     }
 }
+SCAL_KERNEL(1024, k_pre)
 
 // element handled by (wave w, item j, lane l) of a block: base + w*256 + j*64 + l  => (j,l) order is arrival order
-__global__ void __launch_bounds__(256) k_classify(const float* __restrict__ in, int n, int stride, KCfg c, FeatParams* P,
+__device__ __forceinline__ void k_classify_body(const float* __restrict__ in, int n, int stride, const KCfg& c, FeatParams* P,
                                                   signed char* __restrict__ ring, float* __restrict__ ori, int* __restrict__ block_hist,
                                                   int nb) {
     __shared__ int hist[64];
@@ -157,8 +158,9 @@ __global__ void __launch_bounds__(256) k_classify(const float* __restrict__ in, 
     __syncthreads();
     if (threadIdx.x < 64) block_hist[threadIdx.x * nb + blockIdx.x] = hist[threadIdx.x];
 }
+SCAL_KERNEL(256, k_classify)
 
-__global__ void __launch_bounds__(1024) k_ringscan(int* __restrict__ block_hist, int nb, int n_scans, FeatParams* P) {
+__device__ __forceinline__ void k_ringscan_body(int* __restrict__ block_hist, int nb, int n_scans, FeatParams* P) {
     __shared__ int cnt[64];
     const int w = wave_id(), l = lane_id();
     for (int r = w; r < 64; r += 16) {
@@ -189,8 +191,9 @@ __global__ void __launch_bounds__(1024) k_ringscan(int* __restrict__ block_hist,
         }
     }
 }
+SCAL_KERNEL(1024, k_ringscan)
 
-__global__ void __launch_bounds__(256) k_scatter(const float* __restrict__ in, int n, int stride, const FeatParams* __restrict__ P,
+__device__ __forceinline__ void k_scatter_body(const float* __restrict__ in, int n, int stride, const FeatParams* __restrict__ P,
                                                  const signed char* __restrict__ ring, const float* __restrict__ ori,
                                                  const int* __restrict__ block_off, int nb, float* __restrict__ ox, float* __restrict__ oy,
                                                  float* __restrict__ oz, float* __restrict__ oi, int* __restrict__ src) {
@@ -247,8 +250,9 @@ __global__ void __launch_bounds__(256) k_scatter(const float* __restrict__ in, i
         src[pos] = e;
     }
 }
+SCAL_KERNEL(256, k_scatter)
 
-__global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
+__device__ __forceinline__ void k_curv_body(const FeatParams* __restrict__ P, const float* __restrict__ x, const float* __restrict__ y,
                                               const float* __restrict__ z, float* __restrict__ curv, int* __restrict__ label,
                                               unsigned char* __restrict__ gap, unsigned* __restrict__ box_parts) {
     const int n = P->n_kept;
@@ -273,6 +277,7 @@ __global__ void __launch_bounds__(256) k_curv(const FeatParams* __restrict__ P, 
     }
     gap[i] = g;
 }
+SCAL_KERNEL(256, k_curv)
 
 // Greedy picks of one segment (:304-403), executed by ONE wave.  `keys` = the segment's (curvature, ring-relative index)
 // keys sorted ascending, flags[] = per-point LDS bytes: bit 0 = cloudNeighborPicked, bit 1 = "the squared gap to the NEXT
@@ -402,7 +407,7 @@ __device__ __forceinline__ void pick_segment(const unsigned long long* keys, int
     }
 }
 
-__global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const float* __restrict__ x, const float* __restrict__ y,
+__device__ __forceinline__ void k_ring_body(FeatParams* P, const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ z, const float* __restrict__ inten,
                                                        const float* __restrict__ curv, int* __restrict__ label,
                                                        const unsigned char* __restrict__ gap, int* __restrict__ seg_sharp,
@@ -598,11 +603,12 @@ __global__ void __launch_bounds__(RING_THREADS) k_ring(FeatParams* P, const floa
     if (tid == 0) P->lf_ring_cnt[r] = n_out;
     if (r == 32 && tid == 0) SCAL_STAMP(6);
 }
+SCAL_KERNEL(RING_THREADS, k_ring)
 
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_features)
 
 // one block: turn per-segment pick slots into the reference's emission order (segments in (ring, sixth) order)
-__global__ void __launch_bounds__(1024) k_finalize(FeatParams* P, int n_scans, const int* __restrict__ seg_sharp,
+__device__ __forceinline__ void k_finalize_body(FeatParams* P, int n_scans, const int* __restrict__ seg_sharp,
                                                    const int* __restrict__ seg_less, const int* __restrict__ seg_flat,
                                                    const int* __restrict__ seg_cnt, int* __restrict__ sharp, int* __restrict__ less,
                                                    int* __restrict__ flat) {
@@ -626,8 +632,9 @@ __global__ void __launch_bounds__(1024) k_finalize(FeatParams* P, int n_scans, c
         P->lf_ring_off[64] = tl;
     }
 }
+SCAL_KERNEL(1024, k_finalize)
 
-__global__ void __launch_bounds__(256) k_compact(const FeatParams* __restrict__ P, const float* __restrict__ sx, const float* __restrict__ sy,
+__device__ __forceinline__ void k_compact_body(const FeatParams* __restrict__ P, const float* __restrict__ sx, const float* __restrict__ sy,
                                                  const float* __restrict__ sz, const float* __restrict__ si, float* __restrict__ lx,
                                                  float* __restrict__ ly, float* __restrict__ lz, float* __restrict__ li,
                                                  const int* __restrict__ sharp, const int* __restrict__ less, const int* __restrict__ flat,
@@ -662,12 +669,14 @@ __global__ void __launch_bounds__(256) k_compact(const FeatParams* __restrict__ 
         fflat[i * 4 + 0] = x[g], fflat[i * 4 + 1] = y[g], fflat[i * 4 + 2] = z[g], fflat[i * 4 + 3] = inten[g];
     }
 }
+SCAL_KERNEL(256, k_compact)
 
-__global__ void k_interleave(const int* __restrict__ d_n, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+__device__ __forceinline__ void k_interleave_body(const int* __restrict__ d_n, const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                              const float* __restrict__ w, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < *d_n) reinterpret_cast<float4*>(out)[i] = make_float4(x[i], y[i], z[i], w[i]);
 }
+SCAL_KERNEL(1024, k_interleave)
 
 }  // namespace scal
 
@@ -740,10 +749,10 @@ int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
     c->cross_stream_consumers = true;
     if (!c->done_recorded) {
-        SCAL_HIP(hipEventRecord(c->done_ev, c->stream));
+        SCAL_HIP(op_event_record(c->done_ev, c->stream));
         c->done_recorded = true;
     }
-    SCAL_HIP(hipStreamWaitEvent(consumer_stream, c->done_ev, 0));
+    SCAL_HIP(op_stream_wait_event(consumer_stream, c->done_ev, 0));
     return SCAL_OK;
 }
 int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
@@ -758,7 +767,7 @@ int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
     }
     c->reader_stream[slot] = consumer_stream;
     if (!c->reader_ev[slot]) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev[slot], hipEventDisableTiming));
-    SCAL_HIP(hipEventRecord(c->reader_ev[slot], consumer_stream));
+    SCAL_HIP(op_event_record(c->reader_ev[slot], consumer_stream));
     c->reader_pending[slot] = true;
     return SCAL_OK;
 }
@@ -819,7 +828,7 @@ extern "C" int scal_features_create(const scal_features_config* cfg, scal_featur
     // Initialisation goes through the context's own stream.  hipMemset on the legacy null stream returns before the fill has
     // run and is not ordered against a hipStreamNonBlocking stream: a fill landing after the first k_pre cleared
     // FeatParams::empty again (the E_EMPTY that test_errors once missed).
-    if (rc == SCAL_OK && (hipMemsetAsync(c->d_P.p, 0, sizeof(FeatParams), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+    if (rc == SCAL_OK && (op_memset_async(c->d_P.p, 0, sizeof(FeatParams), c->stream) != hipSuccess || op_stream_synchronize(c->stream) != hipSuccess))
         rc = SCAL_E_HIP;
     for (int k = 0; k < 2 && rc == SCAL_OK; ++k)
         if (hipEventCreateWithFlags(&c->up_ev[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
@@ -843,14 +852,14 @@ extern "C" void scal_features_destroy(scal_features_t* c) {
     (void)hipSetDevice(c->cfg.device);
     for (int i = 0; i < scal_features::MAX_READERS; ++i)
         if (c->reader_ev[i]) {  // consumers on other streams must be done with the buffers
-            (void)hipEventSynchronize(c->reader_ev[i]);
+            (void)op_event_synchronize(c->reader_ev[i]);
             (void)hipEventDestroy(c->reader_ev[i]);
         }
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     for (int k = 0; k < 2; ++k)
         if (c->up_ev[k]) (void)hipEventDestroy(c->up_ev[k]);
     if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         release_stream(c->cfg.device);
     }
     delete c;
@@ -868,33 +877,33 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     std::unique_lock<std::mutex> ev_lk(c->ev_mu);
     for (int i = 0; i < scal_features::MAX_READERS; ++i)
         if (c->reader_pending[i]) {  // a consumer on another stream may still be reading the previous scan's outputs
-            SCAL_HIP(hipStreamWaitEvent(s, c->reader_ev[i], 0));
+            SCAL_HIP(op_stream_wait_event(s, c->reader_ev[i], 0));
             c->reader_pending[i] = false;
         }
     c->done_recorded = false;
     c->generation++;
     ev_lk.unlock();
-    SCAL_LAUNCH_PROF("k_pre", k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
-    SCAL_LAUNCH_PROF("k_classify", k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
-    SCAL_LAUNCH_PROF("k_ringscan", k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
-    SCAL_LAUNCH_PROF("k_scatter", k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
+    SCAL_LAUNCH("k_pre", k_pre, dim3(1), dim3(256), 0, s, d_xyz, n, stride, k, P);
+    SCAL_LAUNCH("k_classify", k_classify, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, k, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb);
+    SCAL_LAUNCH("k_ringscan", k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
+    SCAL_LAUNCH("k_scatter", k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
                        c->oz.p, c->oi.p, c->d_src.p);
     const int nb256 = max(1, div_up(n, 256));
-    SCAL_LAUNCH_PROF("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p, c->d_boxparts.p);
+    SCAL_LAUNCH("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p, c->d_boxparts.p);
     c->n_box_parts = nb256;
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;
     {
-        SCAL_LAUNCH_PROF("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
+        SCAL_LAUNCH("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
                        c->d_gap.p, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->sx.p, c->sy.p, c->sz.p, c->si.p);
     }
-    SCAL_LAUNCH_PROF("k_finalize", k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
+    SCAL_LAUNCH("k_finalize", k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p);
-    SCAL_LAUNCH_PROF("k_compact", k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
+    SCAL_LAUNCH("k_compact", k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
                        c->d_sharp.p, c->d_less.p, c->d_flat.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->f_sharp.p, c->f_less.p, c->f_flat.p);
     SCAL_HIP(hipGetLastError());
     ev_lk.lock();
     if (c->cross_stream_consumers) {  // the event must sit right behind stage A, not behind whatever the stream gets next
-        SCAL_HIP(hipEventRecord(c->done_ev, s));
+        SCAL_HIP(op_event_record(c->done_ev, s));
         c->done_recorded = true;
     }
     ev_lk.unlock();
@@ -919,7 +928,7 @@ extern "C" int scal_features_run_device(scal_features_t* c, const float* d_xyz, 
 extern "C" int scal_features_sync(scal_features_t* c) {
     if (!c) return SCAL_E_ARG;
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return SCAL_OK;
 }
 
@@ -934,8 +943,8 @@ extern "C" int scal_features_fetch(scal_features_t* c, scal_features_out* o) {
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->h_P.p, c->d_P.p, sizeof(FeatParams), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_P.p, c->d_P.p, sizeof(FeatParams), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     const FeatParams& P = *c->h_P.p;
     o->n_kept = o->n_sharp = o->n_less_sharp = o->n_flat = o->n_less_flat = 0;
     o->n_tied_segments = 0;
@@ -952,23 +961,23 @@ extern "C" int scal_features_fetch(scal_features_t* c, scal_features_out* o) {
     const int nk = P.n_kept;
     const int nb = max(1, div_up(nk, 256));
     if (o->cloud && nk) {
-        SCAL_LAUNCH_PROF("k_interleave", k_interleave, dim3(nb), dim3(256), 0, s, &c->d_P.p->n_kept, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_aos.p);
-        SCAL_HIP(hipMemcpyAsync(o->cloud, c->d_aos.p, sizeof(float) * 4 * nk, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_LAUNCH("k_interleave", k_interleave, dim3(nb), dim3(256), 0, s, &c->d_P.p->n_kept, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_aos.p);
+        SCAL_HIP(op_memcpy_async(o->cloud, c->d_aos.p, sizeof(float) * 4 * nk, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     if (o->less_flat && P.n_less_flat) {
-        SCAL_LAUNCH_PROF("k_interleave", k_interleave, dim3(max(1, div_up(P.n_less_flat, 256))), dim3(256), 0, s, &c->d_P.p->n_less_flat, c->lx.p, c->ly.p,
+        SCAL_LAUNCH("k_interleave", k_interleave, dim3(max(1, div_up(P.n_less_flat, 256))), dim3(256), 0, s, &c->d_P.p->n_less_flat, c->lx.p, c->ly.p,
                            c->lz.p, c->li.p, c->d_aos.p);
-        SCAL_HIP(hipMemcpyAsync(o->less_flat, c->d_aos.p, sizeof(float) * 4 * P.n_less_flat, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(o->less_flat, c->d_aos.p, sizeof(float) * 4 * P.n_less_flat, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
-    if (o->src_index && nk) SCAL_HIP(hipMemcpyAsync(o->src_index, c->d_src.p, sizeof(int) * nk, hipMemcpyDeviceToHost, s));
-    if (o->curvature && nk) SCAL_HIP(hipMemcpyAsync(o->curvature, c->d_curv.p, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
-    if (o->label && nk) SCAL_HIP(hipMemcpyAsync(o->label, c->d_label.p, sizeof(int) * nk, hipMemcpyDeviceToHost, s));
-    if (o->sharp && P.n_sharp) SCAL_HIP(hipMemcpyAsync(o->sharp, c->d_sharp.p, sizeof(int) * P.n_sharp, hipMemcpyDeviceToHost, s));
-    if (o->less_sharp && P.n_less_sharp) SCAL_HIP(hipMemcpyAsync(o->less_sharp, c->d_less.p, sizeof(int) * P.n_less_sharp, hipMemcpyDeviceToHost, s));
-    if (o->flat && P.n_flat) SCAL_HIP(hipMemcpyAsync(o->flat, c->d_flat.p, sizeof(int) * P.n_flat, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    if (o->src_index && nk) SCAL_HIP(op_memcpy_async(o->src_index, c->d_src.p, sizeof(int) * nk, hipMemcpyDeviceToHost, s));
+    if (o->curvature && nk) SCAL_HIP(op_memcpy_async(o->curvature, c->d_curv.p, sizeof(float) * nk, hipMemcpyDeviceToHost, s));
+    if (o->label && nk) SCAL_HIP(op_memcpy_async(o->label, c->d_label.p, sizeof(int) * nk, hipMemcpyDeviceToHost, s));
+    if (o->sharp && P.n_sharp) SCAL_HIP(op_memcpy_async(o->sharp, c->d_sharp.p, sizeof(int) * P.n_sharp, hipMemcpyDeviceToHost, s));
+    if (o->less_sharp && P.n_less_sharp) SCAL_HIP(op_memcpy_async(o->less_sharp, c->d_less.p, sizeof(int) * P.n_less_sharp, hipMemcpyDeviceToHost, s));
+    if (o->flat && P.n_flat) SCAL_HIP(op_memcpy_async(o->flat, c->d_flat.p, sizeof(int) * P.n_flat, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     if (o->ring_start) std::memcpy(o->ring_start, P.scan_start, sizeof(int) * c->cfg.n_scans);
     if (o->ring_end) std::memcpy(o->ring_end, P.scan_end, sizeof(int) * c->cfg.n_scans);
     return SCAL_OK;
@@ -989,10 +998,10 @@ static int features_run_host(scal_features_t* c, const void* xyz, int n, int str
         // copy.  Two slots: the only wait is for the upload issued two calls ago, never for the work queued on the stream.
         const int slot = c->up_next;
         c->up_next ^= 1;
-        if (c->up_used[slot]) SCAL_HIP(hipEventSynchronize(c->up_ev[slot]));
+        if (c->up_used[slot]) SCAL_HIP(op_event_synchronize(c->up_ev[slot]));
         std::memcpy(c->h_in[slot].p, xyz, (size_t)n * stride_bytes);
-        SCAL_HIP(hipMemcpyAsync(c->d_in.p, c->h_in[slot].p, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
-        SCAL_HIP(hipEventRecord(c->up_ev[slot], c->stream));
+        SCAL_HIP(op_memcpy_async(c->d_in.p, c->h_in[slot].p, (size_t)n * stride_bytes, hipMemcpyHostToDevice, c->stream));
+        SCAL_HIP(op_event_record(c->up_ev[slot], c->stream));
         c->up_used[slot] = true;
     }
     SCAL_TRY(launch_chain(c, c->d_in.p, n, stride_bytes / 4));

@@ -249,7 +249,7 @@ struct BlockList {
     int* counts;    // [0] live blocks, [1] residual rows
 };
 // one workgroup: stable compaction of the valid slots (slot order = the order the reference adds its residual blocks in)
-static __global__ void __launch_bounds__(1024) k_blocks_compact(FactorSoA f, const int* __restrict__ d_nslots, BlockList bl) {
+__device__ __forceinline__ void k_blocks_compact_body(const FactorSoA& f, const int* __restrict__ d_nslots, const BlockList& bl) {
     __shared__ int s_scan[17];
     __shared__ int s_run[2];
     const int n = min(*d_nslots, f.cap);
@@ -275,8 +275,9 @@ static __global__ void __launch_bounds__(1024) k_blocks_compact(FactorSoA f, con
         bl.counts[0] = s_run[0], bl.counts[1] = s_run[1];
     }
 }
+SCAL_KERNEL(1024, k_blocks_compact)
 // one thread per live block: residual rows (and, if wanted, their 7 ambient Jacobian columns, row-major) at the pose x7
-static __global__ void __launch_bounds__(256) k_blocks_eval(FactorSoA f, BlockList bl, const double* __restrict__ x7, int want_jac,
+__device__ __forceinline__ void k_blocks_eval_body(const FactorSoA& f, const BlockList& bl, const double* __restrict__ x7, int want_jac,
                                                            double* __restrict__ residuals, double* __restrict__ jac) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= bl.counts[0]) return;
@@ -297,8 +298,9 @@ static __global__ void __launch_bounds__(256) k_blocks_eval(FactorSoA f, BlockLi
             for (int c = 0; c < 7; ++c) jac[static_cast<size_t>(r0 + q) * 7 + c] = J[q][c];
     }
 }
+SCAL_KERNEL(256, k_blocks_eval)
 // blocks as records for the host (struct scal_block of the C-ABI: int kind, int pad, double cp[3], pa[3], pb[3] = 80 bytes)
-static __global__ void __launch_bounds__(256) k_blocks_export(FactorSoA f, BlockList bl, double* __restrict__ out10) {
+__device__ __forceinline__ void k_blocks_export_body(const FactorSoA& f, const BlockList& bl, double* __restrict__ out10) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= bl.counts[0]) return;
     const int i = bl.live[b];
@@ -307,11 +309,12 @@ static __global__ void __launch_bounds__(256) k_blocks_export(FactorSoA f, Block
 #pragma unroll
     for (int a = 0; a < 3; ++a) o[1 + a] = f.cp[a * f.cap + i], o[4 + a] = f.pa[a * f.cap + i], o[7 + a] = f.pb[a * f.cap + i];
 }
+SCAL_KERNEL(256, k_blocks_export)
 
 constexpr int LM_NACC = 30;  // cost, g[6], upper H[21], number of live edge blocks, number of live plane blocks
 
 // which = 0: evaluate at st->x (iteration zero), 1: at st->cand
-static __global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
+__device__ __forceinline__ void k_lm_eval_body(const FactorSoA& f, const int* __restrict__ d_nslots, const LMState* __restrict__ st, int which,
                                                  double* __restrict__ partials) {
     __shared__ double red[4][LM_NACC];
     const int n = d_nslots ? min(*d_nslots, f.cap) : f.cap;
@@ -342,6 +345,7 @@ static __global__ void __launch_bounds__(256) k_lm_eval(FactorSoA f, const int* 
     __syncthreads();
     if (threadIdx.x < LM_NACC) partials[blockIdx.x * LM_NACC + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
+SCAL_KERNEL(256, k_lm_eval)
 
 __device__ __forceinline__ int hidx(int a, int b) {  // index into upper-triangular row-major H[21], a <= b
     return a * 6 - a * (a - 1) / 2 + (b - a);
@@ -561,9 +565,9 @@ constexpr int LM_EPOCH_STEP = 8;   // sequence numbers reserved per solve (it us
 constexpr int LM_ABORT_CODE = 4;   // written to the caller's abort word by a workgroup that gives up (stage C: MAP_ABORT_LM)
 
 template <class Pre, class Post>
-static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, const int* __restrict__ d_nslots, LMState* st, int outer,
-                                                         const int* __restrict__ d_enable, double* partials, LMSync* sync,
-                                                         int* d_abort, Pre pre, Post post) {
+__device__ __forceinline__ void k_lm_solve_body(const FactorSoA& f, const int* __restrict__ d_nslots, LMState* st, int outer,
+                                                 const int* __restrict__ d_enable, double* partials, LMSync* sync,
+                                                 int* d_abort, const Pre& pre, const Post& post) {
     // uniform over the grid (both words are written by earlier kernels only): a stopped chain leaves the state alone, and so does
     // every solve queued behind an abandoned one - its exchange words may hold tags of workgroups that gave up at different rounds
     if ((d_abort && *d_abort) || sync->abandoned) {
@@ -748,9 +752,30 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(FactorSoA f, con
     post(L.x, blockIdx.x * LM_THREADS + tid, G * LM_THREADS, L.termination == 5);
 }
 
+// the kernel proper: argument set blockIdx.z of a batch (batch.hpp); a sequence's workgroups are its own gridDim.x of them, with
+// its own exchange words, so the solves of several sequences share a launch without knowing of each other
+template <class Pre, class Post>
+struct LMSolveKernel {
+    using traits = KernelTraits<decltype(&k_lm_solve_body<Pre, Post>)>;
+    struct tag {
+        template <class... T>
+        __device__ __forceinline__ static void call(const T&... t) {
+            k_lm_solve_body<Pre, Post>(t...);
+        }
+    };
+};
+template <class Pre, class Post>
+static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(Batch<typename LMSolveKernel<Pre, Post>::traits::pack> b) {
+    batch_call<typename LMSolveKernel<Pre, Post>::tag>(b.p[blockIdx.z], std::make_index_sequence<LMSolveKernel<Pre, Post>::traits::n>());
+}
+template <class Pre, class Post>
+static hipError_t k_lm_solve_launch(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) {
+    return batch_launch_impl<typename LMSolveKernel<Pre, Post>::traits::pack>(k_lm_solve<Pre, Post>, name, grid, block, lds, s, n, packs);
+}
+
 // Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
 // memory instead of one blit kernel per hipMemcpyAsync.  The host reads them after waiting on an event recorded behind this.
-static __global__ void __launch_bounds__(256) k_publish(const void* a, void* host_a, int words_a, const void* b, void* host_b, int words_b) {
+__device__ __forceinline__ void k_publish_body(const void* a, void* host_a, int words_a, const void* b, void* host_b, int words_b) {
     const unsigned* sa = static_cast<const unsigned*>(a);
     unsigned* da = static_cast<unsigned*>(host_a);
     for (int i = threadIdx.x; i < words_a; i += blockDim.x) da[i] = sa[i];
@@ -758,10 +783,11 @@ static __global__ void __launch_bounds__(256) k_publish(const void* a, void* hos
     unsigned* db = static_cast<unsigned*>(host_b);
     for (int i = threadIdx.x; i < words_b; i += blockDim.x) db[i] = sb[i];
 }
+SCAL_KERNEL(256, k_publish)
 template <class A, class B>
 inline void launch_publish(hipStream_t s, const A* a, A* host_a, const B* b, B* host_b) {
     static_assert(sizeof(A) % 4 == 0 && sizeof(B) % 4 == 0, "word copies");
-    SCAL_LAUNCH_PROF("k_publish", k_publish, dim3(1), dim3(256), 0, s, static_cast<const void*>(a), static_cast<void*>(host_a),
+    SCAL_LAUNCH("k_publish", k_publish, dim3(1), dim3(256), 0, s, static_cast<const void*>(a), static_cast<void*>(host_a),
                        a ? static_cast<int>(sizeof(A) / 4) : 0, static_cast<const void*>(b), static_cast<void*>(host_b),
                        b ? static_cast<int>(sizeof(B) / 4) : 0);
 }
@@ -797,7 +823,8 @@ inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMS
                             int outer, int* d_abort = nullptr, Pre pre = Pre(), Post post = Post(), const char* prof_name = "k_lm_solve") {
     int g = (f.cap + LM_THREADS - 1) / LM_THREADS;
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
-    SCAL_LAUNCH_PROF(prof_name, (k_lm_solve<Pre, Post>), dim3(g), dim3(LM_THREADS), LM_LDS_BYTES, s, f, d_nslots, st, outer, d_enable, partials, sync, d_abort, pre, post);
+    launch_or_record<typename LMSolveKernel<Pre, Post>::traits>(k_lm_solve_launch<Pre, Post>, prof_name, dim3(g), dim3(LM_THREADS), LM_LDS_BYTES, s, f, d_nslots, st,
+                                                                 outer, d_enable, partials, sync, d_abort, pre, post);
 }
 
 }  // namespace scal

@@ -127,7 +127,7 @@ __device__ __forceinline__ void grid_part(int& cls, int& first, int& stride) {
     stride = (cls ? static_cast<int>(gridDim.x) - nb0 : nb0) * 256;
 }
 
-__global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* __restrict__ S, MapCounters* C) {
+__device__ __forceinline__ void k_grid_count_body(const GridArgs& a, const MapState* __restrict__ S, MapCounters* C) {
     if (S->abort) return;
     __shared__ int s_valid;
     if (threadIdx.x == 0) s_valid = 0;
@@ -154,6 +154,7 @@ __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* 
     __syncthreads();
     if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
 }
+SCAL_KERNEL(256, k_grid_count)
 
 // The cell grid in ONE launch for the speculative chain: every cell owns a fixed slice of `cap` entries of a (large, sparsely
 // touched) pool, so a point's place is known as soon as it has its rank in the cell - no allocation pass, no second walk over the
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(256) k_grid_count(GridArgs a, const MapState* 
 // not move, so every binned point is the only one of its voxel (the re-filter of the previous scan, :775-791).  A centroid rounded
 // across a cell face could still make a full cell overflow: that stops the chain (MAP_ABORT_GRID), the host clears the counters
 // and redoes the step with the three general launches below.
-__global__ void __launch_bounds__(256) k_grid_build(GridArgs a, int cap0, int cap1, MapState* S, MapCounters* C) {
+__device__ __forceinline__ void k_grid_build_body(const GridArgs& a, int cap0, int cap1, MapState* S, MapCounters* C) {
     if (S->abort) return;
     __shared__ int s_valid;
     if (threadIdx.x == 0) s_valid = 0;
@@ -199,10 +200,11 @@ __global__ void __launch_bounds__(256) k_grid_build(GridArgs a, int cap0, int ca
     __syncthreads();
     if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
 }
+SCAL_KERNEL(256, k_grid_build)
 
 // every non-empty cell gets a slice of the point pool: the cells' sizes are summed per workgroup (the point with rank 0
 // speaks for its cell), one cursor atomic per workgroup and tile
-__global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, const MapState* __restrict__ S, MapCounters* C) {
+__device__ __forceinline__ void k_grid_alloc_body(const GridArgs& a, const MapState* __restrict__ S, MapCounters* C) {
     if (S->abort) return;
     __shared__ int s_scan[17];
     __shared__ int s_base;
@@ -227,8 +229,9 @@ __global__ void __launch_bounds__(256) k_grid_alloc(GridArgs a, const MapState* 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = (C->n_valid[0] > 10 && C->n_valid[1] > 50) ? 1 : 0;  // :555
 }
+SCAL_KERNEL(256, k_grid_alloc)
 
-__global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, const MapState* __restrict__ S) {
+__device__ __forceinline__ void k_grid_fill_body(const GridArgs& a, const MapState* __restrict__ S) {
     if (S->abort) return;
     int cls, first, stride;
     grid_part(cls, first, stride);
@@ -244,8 +247,9 @@ __global__ void __launch_bounds__(256) k_grid_fill(GridArgs a, const MapState* _
         }
     }
 }
+SCAL_KERNEL(256, k_grid_fill)
 
-__global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* __restrict__ S) {
+__device__ __forceinline__ void k_grid_clear_body(const GridArgs& a, const MapState* __restrict__ S) {
     int cls, first, stride;
     grid_part(cls, first, stride);
     const MapParams mp = S->mp;
@@ -254,6 +258,7 @@ __global__ void __launch_bounds__(256) k_grid_clear(GridArgs a, const MapState* 
     for (int i = first + threadIdx.x; i < n; i += stride)
         if (a.rank[cls][i] >= 0) a.cell[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])].x = 0;
 }
+SCAL_KERNEL(256, k_grid_clear)
 
 // ---------------------------------------------------------------------------------------------- association
 
@@ -464,9 +469,9 @@ struct NNBuf {
 // k_assoc_knn: one WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
 // many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
 // so it wants every lane busy with a different point).
-__global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, GridPts cg,
-                                                   const int2* __restrict__ scell, GridPts sg, const LMState* __restrict__ st,
-                                                   MapCounters* C, NNBuf nb) {
+__device__ __forceinline__ void k_assoc_knn_body(const CSoA4& cs, const CSoA4& ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, const GridPts& cg,
+                                                   const int2* __restrict__ scell, const GridPts& sg, const LMState* __restrict__ st,
+                                                   MapCounters* C, const NNBuf& nb) {
     if (S->abort) return;
     // :555 - evaluated here (the map counts are complete once the grid launches are): the one-launch grid build has no later
     // launch of its own that could do it; workgroup 0 publishes the decision for the fit, the solve and the host
@@ -506,6 +511,7 @@ __global__ void __launch_bounds__(256) k_assoc_knn(CSoA4 cs, CSoA4 ss, const Map
         if (lane == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
     }
 }
+SCAL_KERNEL(256, k_assoc_knn)
 
 // The neighbours of a residual-block slot become factor parameters: PCA of the five neighbours for an edge candidate (:594-622),
 // plane fit for a surf candidate (:651-687).  ~3k dependent f64 operations per slot.
@@ -580,12 +586,13 @@ struct AssocFit {
 
 // one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations, so it wants every lane busy with a different
 // point and many small workgroups spread over the machine; inside the solve kernel's 64 workgroups it ran slower)
-__global__ void __launch_bounds__(64) k_assoc_fit(AssocFit fit, const MapState* __restrict__ S) {
+__device__ __forceinline__ void k_assoc_fit_body(const AssocFit& fit, const MapState* __restrict__ S) {
     if (S->abort || !fit.C->solve_on) return;
     const int nc = fit.C->n_corner_stack, ns = fit.C->n_surf_stack;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nc + ns && i < fit.f.cap) fit.fit(i, nc);
 }
+SCAL_KERNEL(64, k_assoc_fit)
 
 // ---------------------------------------------------------------------------------------------- insert + re-filter
 // sort key of a map point: [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; ~0 = outside the cube window
@@ -612,7 +619,7 @@ __device__ __forceinline__ unsigned long long map_key(const MapParams& mp, float
 
 // appends the stack points (map frame, final pose) behind the old map points and builds the sort keys
 //   key layout (36 sorted bits = 3 passes of 12): [slot 9: 0..74 valid cube, 127 = not re-filtered][vz 9][vy 9][vx 9]; dropped points get ~0
-__global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, const MapState* __restrict__ S, CSoA4 stack, const int* __restrict__ d_nstack,
+__device__ __forceinline__ void k_insert_keys_body(const MapCloud& m, const MapState* __restrict__ S, const CSoA4& stack, const int* __restrict__ d_nstack,
                                                      const LMState* __restrict__ st, float inv_leaf, int cap, unsigned long long* __restrict__ keys,
                                                      int* __restrict__ vals, MapCounters* C, int cls) {
     const MapParams mp = S->mp;
@@ -644,8 +651,9 @@ __global__ void __launch_bounds__(256) k_insert_keys(MapCloud m, const MapState*
     keys[i] = k;
     vals[i] = i;
 }
+SCAL_KERNEL(256, k_insert_keys)
 
-__global__ void __launch_bounds__(256) k_map_heads(SortedPairs sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
+__device__ __forceinline__ void k_map_heads_body(const SortedPairs& sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
     const unsigned long long* keys = sp.keys[sorted_sel(sp)];
     const int n = *d_n;
     const int nb = (n + 255) / 256;
@@ -661,9 +669,10 @@ __global__ void __launch_bounds__(256) k_map_heads(SortedPairs sp, const int* __
     block_exclusive_scan(head, s, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
+SCAL_KERNEL(256, k_map_heads)
 
-__global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, MapCloud in,
-                                                    MapCloud out) {
+__device__ __forceinline__ void k_map_reduce_body(const SortedPairs& sp, const int* __restrict__ d_n, const int* __restrict__ blockoff, const MapCloud& in,
+                                                    const MapCloud& out) {
     const unsigned long long* keys = sp.keys[sorted_sel(sp)];
     const int* vals = sp.vals[sorted_sel(sp)];
     const int n = *d_n;
@@ -697,6 +706,7 @@ __global__ void __launch_bounds__(256) k_map_reduce(SortedPairs sp, const int* _
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
     out.cube[o] = in.cube[vals[i]];
 }
+SCAL_KERNEL(256, k_map_reduce)
 
 // ---------------------------------------------------------------------------------------------- merge insert
 // The re-filter of :738-802 without sorting the map.  After a re-filter every valid cube holds one point per voxel in key
@@ -751,7 +761,7 @@ __device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >>
 // new keys of its class in LDS (written by k_map_pose_done), sorts the 512-chunks in registers (one wave each), then ranks the
 // keys of ITS chunk against the other chunks with binary searches - rank = sorted position, the keys are distinct because they
 // carry the arrival index - and scatters them.  No merge network across workgroups, no second launch.
-__global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
+__device__ __forceinline__ void k_merge_keys_body(const MergeArgs& a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
     if (S->abort) return;
     extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX packed keys
     __shared__ int s_scan[17];
@@ -820,11 +830,12 @@ __global__ void __launch_bounds__(1024) k_merge_keys(MergeArgs a, const LMState*
     rank += __shfl_xor(rank, 1, 64);
     if (half == 0 && key != ~0ull) nw.sorted[rank] = key;
 }
+SCAL_KERNEL(1024, k_merge_keys)
 
 // Run heads of the sorted new keys, each head looked up among the old keys, inserted runs counted per 512-block.
 // Two-level lower bound: every `stride`-th old key is staged in LDS (one pass), the search over the samples runs at LDS
 // latency and leaves a window of <= stride old keys for the last few global steps.
-__global__ void __launch_bounds__(512) k_merge_lookup(MergeArgs a, const MapState* __restrict__ S, const MapCounters* __restrict__ C) {
+__device__ __forceinline__ void k_merge_lookup_body(const MergeArgs& a, const MapState* __restrict__ S, const MapCounters* __restrict__ C) {
     if (S->abort) return;
     __shared__ unsigned long long s_samp[MERGE_SAMPLES];
     __shared__ int s_scan[17];
@@ -881,6 +892,7 @@ __global__ void __launch_bounds__(512) k_merge_lookup(MergeArgs a, const MapStat
     }
     if (threadIdx.x == 0) nw.blocktot[blk] = total;
 }
+SCAL_KERNEL(512, k_merge_lookup)
 
 // A merge that cannot be done (merge_fail, map pool full) stops the speculative chain here: nothing has been committed yet, the
 // host redoes this insertion with the full sort and replays the steps queued behind it.
@@ -999,7 +1011,7 @@ struct MergeTail {
     const LMState* st;
     SoA4 full_out;
 };
-__global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, MapCounters* C, MergeTail t) {
+__device__ __forceinline__ void k_merge_write_body(const MergeArgs& a, MapState* S, MapCounters* C, const MergeTail& t) {
     merge_write_body(a, S, C);
     if (!t.fused) return;
     if (static_cast<int>(blockIdx.x) >= MERGE_WRITE_GRID && !S->abort) {
@@ -1014,9 +1026,10 @@ __global__ void __launch_bounds__(256) k_merge_write(MergeArgs a, MapState* S, M
         }
     }
 }
+SCAL_KERNEL(256, k_merge_write)
 
-__global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st,
-                                                         const MapState* __restrict__ S, SoA4 out) {
+__device__ __forceinline__ void k_transform_cloud_body(const CSoA4& in, const int* __restrict__ d_n, int cap, const LMState* __restrict__ st,
+                                                         const MapState* __restrict__ S, const SoA4& out) {
     if (S->abort) return;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*d_n, cap)) return;
@@ -1027,12 +1040,13 @@ __global__ void __launch_bounds__(256) k_transform_cloud(CSoA4 in, const int* __
     associate_to_map(x7, in.x[i], in.y[i], in.z[i], sel);
     out.x[i] = sel[0], out.y[i] = sel[1], out.z[i] = sel[2], out.w[i] = in.w[i];
 }
+SCAL_KERNEL(256, k_transform_cloud)
 
 // Start of a device-resident step in ONE launch: clears the per-scan counters and copies the lessSharp cloud (xyzi records)
 // and the lessFlat cloud (SoA) of a features context into corner_in / surf_in.  Blocks [0,nbc) corner, the rest surf.
 // surf_parts != null: every surf block stores the bounding box of its points there (stands in for k_vox_bbox, see VoxelFilter::run).
-__global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ less_aos, const int* __restrict__ d_n_less, CSoA4 less_flat,
-                                                    const int* __restrict__ d_n_less_flat, SoA4 corner_in, SoA4 surf_in, MapCounters* C, int cap,
+__device__ __forceinline__ void k_map_gather_body(const float* __restrict__ less_aos, const int* __restrict__ d_n_less, const CSoA4& less_flat,
+                                                    const int* __restrict__ d_n_less_flat, const SoA4& corner_in, const SoA4& surf_in, MapCounters* C, int cap,
                                                     int nbc, unsigned* surf_parts) {
     const bool corner = static_cast<int>(blockIdx.x) < nbc;
     const int b = corner ? blockIdx.x : blockIdx.x - nbc;
@@ -1056,8 +1070,9 @@ __global__ void __launch_bounds__(256) k_map_gather(const float* __restrict__ le
         if (surf_parts) vox_bbox_block_store(surf_parts, b, i < n, x, y, z);
     }
 }
+SCAL_KERNEL(256, k_map_gather)
 
-__global__ void __launch_bounds__(256) k_export_valid(MapCloud m, const MapState* __restrict__ S, int cls, int* __restrict__ counter,
+__device__ __forceinline__ void k_export_valid_body(const MapCloud& m, const MapState* __restrict__ S, int cls, int* __restrict__ counter,
                                                       float* __restrict__ out, int cap) {
     const MapParams mp = S->mp;
     const int n = S->n_map[cls];
@@ -1067,6 +1082,7 @@ __global__ void __launch_bounds__(256) k_export_valid(MapCloud m, const MapState
             if (p < cap) reinterpret_cast<float4*>(out)[p] = make_float4(m.x[i], m.y[i], m.z[i], m.w[i]);
         }
 }
+SCAL_KERNEL(256, k_export_valid)
 
 // Eigen-equivalent quaternion helpers, storage (x,y,z,w); the same code on both sides of the launch
 __host__ __device__ inline void m_qmul(const double* a, const double* b, double* o) {
@@ -1090,7 +1106,7 @@ struct MapPoseIn {
 // The pointer shuffles of :324-508 are offset updates; the slabs they clear are dropped by the next re-filter.
 // allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
 // raises the sticky abort flag instead - the host then redoes this step on the general path and replays what was queued behind.
-__global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_window_change, float inv_line, float inv_plane, MapCounters* C,
+__device__ __forceinline__ void k_map_begin_body(MapState* S, const MapPoseIn& in, LMState* st, int allow_window_change, float inv_line, float inv_plane, MapCounters* C,
                             int slot_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (S->abort) return;
@@ -1134,6 +1150,7 @@ __global__ void k_map_begin(MapState* S, MapPoseIn in, LMState* st, int allow_wi
 #pragma unroll
     for (int k = 0; k < 7; ++k) st->x[k] = x0[k];
 }
+SCAL_KERNEL(1024, k_map_begin)
 
 __device__ __forceinline__ void copy_words(void* dst, const void* src, int bytes) {
     const unsigned* s = static_cast<const unsigned*>(src);
@@ -1205,17 +1222,19 @@ struct MapPoseDone {
 };
 
 // the same work as a launch of its own (Ceres-adapter mode: the caller's solver produced the pose)
-__global__ void __launch_bounds__(256) k_map_pose_done(MapPoseDone pd) {
+__device__ __forceinline__ void k_map_pose_done_body(const MapPoseDone& pd) {
     pd(pd.st->x, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, false);
 }
+SCAL_KERNEL(256, k_map_pose_done)
 
 // End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
-__global__ void __launch_bounds__(256) k_map_end(MapState* S, const MapCounters* C, MapResult* host) {
+__device__ __forceinline__ void k_map_end_body(MapState* S, const MapCounters* C, MapResult* host) {
     if (threadIdx.x == 0 && !S->abort) S->n_map[0] = C->n_map_new[0], S->n_map[1] = C->n_map_new[1];
     __syncthreads();
     copy_words(&host->C2, C, sizeof(MapCounters));
     copy_words(&host->S2, S, sizeof(MapState));
 }
+SCAL_KERNEL(256, k_map_end)
 
 struct SoAStore {
     DevBuf<float> x, y, z, w;
@@ -1467,16 +1486,16 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         // Everything is initialised on the context's own stream (the legacy null stream is not ordered against it).
         // The cell counters obey a zero invariant: every step clears exactly the cells it touched.
         for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cell.zero(c->stream);
-        if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        if (rc == SCAL_OK && hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_memset_async(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_memset_async(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
         if (rc == SCAL_OK) rc = c->d_done.zero(c->stream);
         MapState& H = *c->h_S.p;
         std::memset(&H, 0, sizeof H);
         H.q_wmap_wodom[3] = 1.0;
         H.mp.cenW = 10, H.mp.cenH = 10, H.mp.cenD = 5;  // :74-76
-        if (rc == SCAL_OK && hipMemcpyAsync(c->d_S.p, c->h_S.p, sizeof(MapState), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_memcpy_async(c->d_S.p, c->h_S.p, sizeof(MapState), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_stream_synchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
     if (rc != SCAL_OK) {
         if (rc == SCAL_E_HIP) set_error("scal_map_create: HIP resource creation failed");
@@ -1491,11 +1510,11 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         release_stream(c->cfg.device, c->lane);
     }
     if (c->side) {
-        (void)hipStreamSynchronize(c->side);
+        (void)op_stream_synchronize(c->side);
         release_stream(c->cfg.device, c->side_lane);
     }
     for (int k = 0; k < scal_map::NSETS; ++k) {
@@ -1560,13 +1579,13 @@ int insert_full_sort(scal_map* c, const MapStep& e, const int* n_map) {
         MapCloud in = M.cloud(e.par), outc = M.cloud(e.par ^ 1);
         const CSoA4 stack = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
         const int* d_ns = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
-        SCAL_LAUNCH_PROF("k_insert_keys", k_insert_keys, dim3(nb), dim3(256), 0, s, in, c->d_S.p, stack, d_ns, st, 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res),
+        SCAL_LAUNCH("k_insert_keys", k_insert_keys, dim3(nb), dim3(256), 0, s, in, c->d_S.p, stack, d_ns, st, 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res),
                            c->map_cap, c->keys.p, c->vals.p, C, k);
         SortedPairs sp;
         SCAL_TRY(c->sorter.sort(s, c->keys.p, c->vals.p, &C->n_total[k], n_tot_max, 36, nullptr, &sp));
-        SCAL_LAUNCH_PROF("k_map_heads", k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
+        SCAL_LAUNCH("k_map_heads", k_map_heads, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p);
         launch_scan_inplace(s, c->blockcnt.p, &C->n_total[k], 256, 1, &C->n_map_new[k]);
-        SCAL_LAUNCH_PROF("k_map_reduce", k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
+        SCAL_LAUNCH("k_map_reduce", k_map_reduce, dim3(nb), dim3(256), 0, s, sp, &C->n_total[k], c->blockcnt.p, in, outc);
     }
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
@@ -1590,8 +1609,8 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
     }
     a.cap = c->map_cap;
     const int lds = sizeof(unsigned long long) * MERGE_MAX;  // attribute set per device in scal_map_create
-    SCAL_LAUNCH_PROF("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
-    SCAL_LAUNCH_PROF("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
+    SCAL_LAUNCH("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
+    SCAL_LAUNCH("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
     MergeTail t{};
     int grid = MERGE_WRITE_GRID;
     if (fused) {
@@ -1607,7 +1626,7 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
             t.full = c->full_in.cv(), t.d_nfull = c->d_nfull.p, t.full_cap = 0;
         }
     }
-    SCAL_LAUNCH_PROF("k_merge_write", k_merge_write, dim3(grid), dim3(256), 0, s, a, c->d_S.p, C, t);
+    SCAL_LAUNCH("k_merge_write", k_merge_write, dim3(grid), dim3(256), 0, s, a, c->d_S.p, C, t);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
@@ -1619,16 +1638,16 @@ int launch_tail(scal_map* c, const MapStep& e) {
         const int nb = std::max(1, div_up(c->scan_cap, 256));
         if (e.feat) {
             FeatDeviceView v = features_view(e.feat);
-            SCAL_LAUNCH_PROF("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->scan_cap, c->d_st.p, c->d_S.p,
+            SCAL_LAUNCH("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, c->scan_cap, c->d_st.p, c->d_S.p,
                                c->full_out.v());
         } else {
-            SCAL_LAUNCH_PROF("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, c->scan_cap, c->d_st.p, c->d_S.p,
+            SCAL_LAUNCH("k_transform_cloud", k_transform_cloud, dim3(nb), dim3(256), 0, s, c->full_in.cv(), c->d_nfull.p, c->scan_cap, c->d_st.p, c->d_S.p,
                                c->full_out.v());
         }
     }
-    SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_done[e.slot], s));
+    SCAL_HIP(op_event_record(c->ev_done[e.slot], s));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, s));  // the registration transform reads the full-resolution cloud last
     return SCAL_OK;
 }
@@ -1658,29 +1677,29 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     MapState* S = c->d_S.p;
     if (e.feat) {
         if (e.prefetched) {
-            SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled: the surf cloud on the side stream ...
-            if (c->pre_a_used[st_]) SCAL_HIP(hipStreamWaitEvent(s, c->ev_pre_a[st_], 0));  // ... the corner cloud behind stage A
+            SCAL_HIP(op_stream_wait_event(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled: the surf cloud on the side stream ...
+            if (c->pre_a_used[st_]) SCAL_HIP(op_stream_wait_event(s, c->ev_pre_a[st_], 0));  // ... the corner cloud behind stage A
         } else {
             FeatDeviceView v = features_view(e.feat);
             SCAL_TRY(features_wait_done(e.feat, s));
             const int nbc = std::max(1, div_up(e.n_corner_bound, 256));
-            SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
+            SCAL_LAUNCH("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(e.n_surf_bound, 256))), dim3(256), 0, s, v.less_xyzi, &v.P->n_less_sharp,
                                CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(st_).v(), c->surf_in(st_).v(), C, c->scan_cap, nbc,
                                static_cast<unsigned*>(nullptr));
         }
     }
     if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
-    SCAL_LAUNCH_PROF("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
+    SCAL_LAUNCH("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
                      c->slot_cap);
     // cell grids over the valid cubes (both classes per launch): one launch on the speculative chain, three in general
     const bool fixed_pool = e.fast && c->grid_fixed && !prepare_only;
     const GridArgs ga = grid_args(c, e.par, fixed_pool);
     if (fixed_pool) {
-        SCAL_LAUNCH_PROF("k_grid_build", k_grid_build, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, c->grid_cap_now[0], c->grid_cap_now[1], S, C);
+        SCAL_LAUNCH("k_grid_build", k_grid_build, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, c->grid_cap_now[0], c->grid_cap_now[1], S, C);
     } else {
-        SCAL_LAUNCH_PROF("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-        SCAL_LAUNCH_PROF("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
-        SCAL_LAUNCH_PROF("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
+        SCAL_LAUNCH("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+        SCAL_LAUNCH("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
+        SCAL_LAUNCH("k_grid_fill", k_grid_fill, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S);
     }
     if (prepare_only) {  // Ceres-adapter mode: the caller drives association and solve (scal_map_associate / scal_map_eval_blocks)
         SCAL_HIP(hipGetLastError());
@@ -1693,16 +1712,16 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     const AssocFit fit{c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), c->nnbuf(), C, F};
     for (int outer = 0; outer < 2; ++outer) {
         {
-            SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
+            SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
                              c->grid[0].cell.p, c->grid[0].pts(fixed_pool), c->grid[1].cell.p, c->grid[1].pts(fixed_pool), st, C, c->nnbuf());
         }
-        SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
+        SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
         // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
         pd.active = outer == 1;
         launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, LMNoHook(), pd, "k_lm_solve_map");
     }
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
+    SCAL_HIP(op_event_record(c->ev_pose[e.slot], s));
     return SCAL_OK;
 }
 
@@ -1720,18 +1739,18 @@ constexpr int MAP_RC_LM = 1000;  // internal: launch sequence fine, solve abando
 bool lm_gave_up(const MapResult& R) { return R.st.termination == 5 || R.S1.abort == MAP_ABORT_LM; }
 int lm_reset(scal_map* c, bool restore_pose) {
     hipStream_t s = c->stream;
-    SCAL_HIP(hipStreamSynchronize(s));
-    SCAL_HIP(hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), s));
+    SCAL_HIP(op_stream_synchronize(s));
+    SCAL_HIP(op_memset_async(c->lm_sync.p, 0, sizeof(LMSync), s));
     SCAL_TRY(c->partials.zero(s));
-    SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+    SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
     if (restore_pose) {
         double* h = reinterpret_cast<double*>(c->h_S.p);  // pinned scratch
         for (int i = 0; i < 4; ++i) h[i] = c->good_q[i];
         for (int i = 0; i < 3; ++i) h[4 + i] = c->good_t[i];
         static_assert(offsetof(MapState, t_wmap_wodom) == offsetof(MapState, q_wmap_wodom) + 4 * sizeof(double), "pose fields are contiguous");
-        SCAL_HIP(hipMemcpyAsync(c->d_S.p->q_wmap_wodom, h, 7 * sizeof(double), hipMemcpyHostToDevice, s));
+        SCAL_HIP(op_memcpy_async(c->d_S.p->q_wmap_wodom, h, 7 * sizeof(double), hipMemcpyHostToDevice, s));
     }
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -1743,7 +1762,7 @@ int run_general_once(scal_map* c, MapStep& e) {
     e.par = c->cur;
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e));
-    SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    SCAL_HIP(op_event_synchronize(c->ev_pose[e.slot]));
     if (lm_gave_up(c->res.p[e.slot])) return MAP_RC_LM;
     return general_insert(c, e);
 }
@@ -1752,9 +1771,9 @@ int run_general(scal_map* c, MapStep& e) {
     for (int attempt = 0; rc == MAP_RC_LM; ++attempt) {
         SCAL_TRY(lm_reset(c, true));
         // a full cell grid was left behind by the stopped pose part: restore the zero invariant before the grid is built again
-        SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, c->stream, grid_args(c, e.par), c->d_S.p);
+        SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, c->stream, grid_args(c, e.par), c->d_S.p);
         if (attempt == 1) {
-            SCAL_HIP(hipStreamSynchronize(c->stream));
+            SCAL_HIP(op_stream_synchronize(c->stream));
             e.failed = true;
             set_error("LM solve abandoned: grid barrier timed out");
             return SCAL_E_HIP;
@@ -1775,24 +1794,24 @@ int general_insert(scal_map* c, MapStep& e) {
     e.insert_path = 1;
     if (try_merge) {
         SCAL_TRY(launch_insert_merge(c, e));
-        SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
+        SCAL_HIP(op_stream_synchronize(s));
         if (R.S2.abort) {  // a case the merge does not cover: redo with the full sort
-            SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+            SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
             try_merge = false;
         } else if (R.C2.error) {
             return report_device_error(c, R.C2.error);
         }
     } else {
         // restore the zero invariant of the cell counters (the merge insert does it in its key kernel)
-        SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+        SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
     }
     if (!try_merge) {
         e.insert_path = 0;
         SCAL_TRY(insert_full_sort(c, e, n_map));
     }
     SCAL_TRY(launch_tail(c, e));
-    SCAL_HIP(hipEventSynchronize(c->ev_done[e.slot]));
+    SCAL_HIP(op_event_synchronize(c->ev_done[e.slot]));
     if (R.C2.error) return report_device_error(c, R.C2.error);
     c->cur = e.par ^ 1;
     c->initialised = true;
@@ -1807,9 +1826,9 @@ int launch_fast(scal_map* c, MapStep& e) {
     c->n_fast++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_TRY(launch_insert_merge(c, e, true));
-    SCAL_LAUNCH_PROF("k_map_end", k_map_end, dim3(1), dim3(256), 0, c->stream, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, c->stream, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_done[e.slot], c->stream));
+    SCAL_HIP(op_event_record(c->ev_done[e.slot], c->stream));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, c->stream));  // the registration transform reads the full-resolution cloud last
     c->cur = e.par ^ 1;
     return SCAL_OK;
@@ -1839,7 +1858,7 @@ void pop_done(scal_map* c) {
 // flag is redone on the general path (from its start, or only its insertion), the steps behind it are queued again.
 int recover(scal_map* c) {
     hipStream_t s = c->stream;
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     size_t origin = c->steps.size();
     bool at_pose = false;
     for (size_t i = 0; i < c->steps.size(); ++i) {
@@ -1860,9 +1879,9 @@ int recover(scal_map* c) {
         const MapResult& R0 = c->res.p[e.slot];
         const bool lm = lm_gave_up(R0);
         if (lm) SCAL_TRY(lm_reset(c, true));  // clears the abort word too
-        else SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+        else SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
         if (lm || R0.S1.abort == MAP_ABORT_GRID)  // the grid was built and the kernel that clears its counters never ran
-            SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+            SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
         SCAL_TRY(check_generation(e, !e.prefetched));
         const int rc = run_general(c, e);
         if (rc != SCAL_OK && !e.failed) return rc;
@@ -1870,16 +1889,16 @@ int recover(scal_map* c) {
     } else {
         c->n_recover_insert++;  // the pose of this step stands; only its insertion is redone, with the full sort
         if (c->res.p[e.slot].S2.abort == MAP_ABORT_LM) SCAL_TRY(lm_reset(c, false));  // a workgroup gave up in the last round, after workgroup 0 had finished
-        else SCAL_HIP(hipMemsetAsync(&c->d_S.p->abort, 0, sizeof(int), s));
+        else SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
         if (c->res.p[e.slot].S2.abort == MAP_ABORT_LM)
-            SCAL_LAUNCH_PROF("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
+            SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
         SCAL_TRY(check_generation(e, false));
         const MapResult& R = c->res.p[e.slot];
         const int n_map[2] = {R.S2.n_map[0], R.S2.n_map[1]};  // not committed: still the sizes before the insertion
         e.fast = false, e.insert_path = 0;
         SCAL_TRY(insert_full_sort(c, e, n_map));
         SCAL_TRY(launch_tail(c, e));
-        SCAL_HIP(hipEventSynchronize(c->ev_done[e.slot]));
+        SCAL_HIP(op_event_synchronize(c->ev_done[e.slot]));
         if (R.C2.error) return report_device_error(c, R.C2.error);
         c->cur = e.par ^ 1;
     }
@@ -1898,8 +1917,8 @@ int confirm_steps(scal_map* c, bool wait) {
         if (c->steps[i].confirmed) continue;
         const int slot = c->steps[i].slot;
         if (wait) {
-            SCAL_HIP(hipEventSynchronize(c->ev_done[slot]));
-        } else if (hipEventQuery(c->ev_done[slot]) != hipSuccess) {
+            SCAL_HIP(op_event_synchronize(c->ev_done[slot]));
+        } else if (op_event_query(c->ev_done[slot]) != hipSuccess) {
             break;
         }
         const MapResult& R = c->res.p[slot];
@@ -1939,7 +1958,7 @@ int map_make_room(scal_map* c) {
             return SCAL_E_STATE;
         }
         const int slot = c->steps.front().slot;
-        SCAL_HIP(hipEventSynchronize(c->ev_done[slot]));
+        SCAL_HIP(op_event_synchronize(c->ev_done[slot]));
         SCAL_TRY(map_poll(c));
     }
     return SCAL_OK;
@@ -1985,7 +2004,7 @@ int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* 
     }
     const int slot = pe->slot;
     for (int round = 0;; ++round) {
-        SCAL_HIP(hipEventSynchronize(c->ev_pose[slot]));
+        SCAL_HIP(op_event_synchronize(c->ev_pose[slot]));
         if (pe->failed || (!c->res.p[slot].S1.abort && c->res.p[slot].st.termination != 5)) break;
         if (round > scal_map::MAX_STEPS + 1) {
             set_error("scal_map_collect: internal error (recovery does not converge)");
@@ -2060,14 +2079,14 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     std::memset(&z, 0, sizeof z);
     z.n_corner_in = n_corner, z.n_surf_in = n_surf;
     *c->h_C.p = z;
-    SCAL_HIP(hipMemcpyAsync(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
     c->h_misc.p[0] = have_full ? n_full : 0;
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, SoAStore& dst) -> int {
         if (n > 0) {
-            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            SCAL_HIP(op_memcpy_async(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
             launch_deinterleave(s, c->aos.p, n, dst.v());
-            SCAL_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next upload
+            SCAL_HIP(op_stream_synchronize(s));  // the staging buffer is reused by the next upload
         }
         return SCAL_OK;
     };
@@ -2088,8 +2107,8 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     }
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
-        SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     return SCAL_OK;
 }
@@ -2126,16 +2145,16 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     hipStream_t sa = v.stream;
     const int nbc = std::max(1, div_up(ls_cap, 256));
     c->pre_a_used[nset] = true;
-    SCAL_LAUNCH_PROF("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, sa, v.less_xyzi, &v.P->n_less_sharp,
+    SCAL_LAUNCH("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, sa, v.less_xyzi, &v.P->n_less_sharp,
                      CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc,
                      c->surf_parts[nset].p);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_gather[nset], sa));
+    SCAL_HIP(op_event_record(c->ev_gather[nset], sa));
     SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, sa, ls_cap, nset));
-    SCAL_HIP(hipEventRecord(c->ev_pre_a[nset], sa));
-    SCAL_HIP(hipStreamWaitEvent(c->side, c->ev_gather[nset], 0));
+    SCAL_HIP(op_event_record(c->ev_pre_a[nset], sa));
+    SCAL_HIP(op_stream_wait_event(c->side, c->ev_gather[nset], 0));
     SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, true));
-    SCAL_HIP(hipEventRecord(c->ev_pre[nset], c->side));
+    SCAL_HIP(op_event_record(c->ev_pre[nset], c->side));
     c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset, c->pf[c->n_pf].generation = v.generation;
     c->n_pf++;
     return SCAL_OK;
@@ -2230,17 +2249,17 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
     hipStream_t s = c->stream;
     MapStore& M = c->map[which];
     c->h_misc.p[1] = 0;
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
     const int room = std::min(cap, c->scan_cap);
-    SCAL_LAUNCH_PROF("k_export_valid", k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
+    SCAL_LAUNCH("k_export_valid", k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
                        c->d_nfull.p + 1, c->aos.p, out_xyzi ? room : 0);
-    SCAL_HIP(hipMemcpyAsync(c->h_misc.p + 2, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_misc.p + 2, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     const int n = c->h_misc.p[2];
     if (out_xyzi && room > 0) {
         const int m = std::min(n, room);
-        SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
         return m;
     }
     return n;
@@ -2280,14 +2299,14 @@ static int upload_step_inputs(scal_map* c, MapStep& e, const float* corner_last,
     std::memset(&z, 0, sizeof z);
     z.n_corner_in = n_corner, z.n_surf_in = n_surf;
     *c->h_C.p = z;
-    SCAL_HIP(hipMemcpyAsync(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_C(e.set).p, c->h_C.p, sizeof(MapCounters), hipMemcpyHostToDevice, s));
     c->h_misc.p[0] = n_full;
-    SCAL_HIP(hipMemcpyAsync(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_nfull.p, c->h_misc.p, sizeof(int), hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, SoAStore& dst) -> int {
         if (n > 0) {
-            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            SCAL_HIP(op_memcpy_async(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
             launch_deinterleave(s, c->aos.p, n, dst.v());
-            SCAL_HIP(hipStreamSynchronize(s));  // the staging buffer is reused by the next upload
+            SCAL_HIP(op_stream_synchronize(s));  // the staging buffer is reused by the next upload
         }
         return SCAL_OK;
     };
@@ -2329,9 +2348,9 @@ extern "C" int scal_map_adapter_begin(scal_map_t* c, const float* corner_last, i
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e, true));  // stack filters, transformAssociateToMap + window, cell grids
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->h_S.p, c->d_S.p, sizeof(MapState), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(c->res.p + e.slot, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));  // MapResult::st is its first member
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_S.p, c->d_S.p, sizeof(MapState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_memcpy_async(c->res.p + e.slot, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));  // MapResult::st is its first member
+    SCAL_HIP(op_stream_synchronize(s));
     const double* x = c->res.p[e.slot].st.x;
     for (int i = 0; i < 4; ++i) q_w_curr[i] = x[i];
     for (int i = 0; i < 3; ++i) t_w_curr[i] = x[4 + i];
@@ -2344,7 +2363,7 @@ static int adapter_set_pose(scal_map* c, const double* q, const double* t) {
     double* h = reinterpret_cast<double*>(c->h_S.p);  // pinned scratch (MapState is larger than 7 doubles)
     for (int i = 0; i < 4; ++i) h[i] = q[i];
     for (int i = 0; i < 3; ++i) h[4 + i] = t[i];
-    SCAL_HIP(hipMemcpyAsync(c->d_st.p->x, h, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
+    SCAL_HIP(op_memcpy_async(c->d_st.p->x, h, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
     return SCAL_OK;
 }
 
@@ -2362,18 +2381,18 @@ extern "C" int scal_map_associate(scal_map_t* c, const double* q_w_curr, const d
     const MapStep& e = c->adapter_step;
     MapCounters* C = c->d_C(e.set).p;
     SCAL_TRY(adapter_set_pose(c, q_w_curr, t_w_curr));
-    SCAL_HIP(hipStreamSynchronize(s));  // the pinned scratch is reused
+    SCAL_HIP(op_stream_synchronize(s));  // the pinned scratch is reused
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
-    SCAL_LAUNCH_PROF("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
+    SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
                      c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), c->d_st.p, C, c->nnbuf());
     const AssocFit fit{c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->nnbuf(), C, F};
-    SCAL_LAUNCH_PROF("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, c->d_S.p);
-    SCAL_LAUNCH_PROF("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
+    SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, c->d_S.p);
+    SCAL_LAUNCH("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_memcpy_async(c->h_C.p, C, sizeof(MapCounters), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     if (!c->h_C.p->solve_on) c->h_counts.p[0] = c->h_counts.p[1] = 0;  // map too small (:555): no residual blocks, the caller skips the solve
     *n_blocks = c->h_counts.p[0], *n_residuals = c->h_counts.p[1];
     return SCAL_OK;
@@ -2393,9 +2412,9 @@ extern "C" int scal_map_get_blocks(scal_map_t* c, scal_block* out, int cap) {
     const int n = std::min(cap, c->h_counts.p[0]);
     if (n <= 0) return 0;
     hipStream_t s = c->stream;
-    SCAL_LAUNCH_PROF("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
-    SCAL_HIP(hipMemcpyAsync(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_LAUNCH("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
+    SCAL_HIP(op_memcpy_async(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return n;
 }
 
@@ -2412,13 +2431,13 @@ extern "C" int scal_map_eval_blocks(scal_map_t* c, const double* x7, int want_ja
     const int nb = c->h_counts.p[0], nr = c->h_counts.p[1];
     if (nb == 0) return SCAL_OK;
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->d_x7.p, x7, sizeof(double) * 7, hipMemcpyHostToDevice, s));
-    SCAL_LAUNCH_PROF("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
+    SCAL_HIP(op_memcpy_async(c->d_x7.p, x7, sizeof(double) * 7, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
                      c->d_res.p, c->d_jac.p);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
-    if (want_jac) SCAL_HIP(hipMemcpyAsync(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
+    if (want_jac) SCAL_HIP(op_memcpy_async(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -2437,10 +2456,10 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
     c->adapter_active = false;
     SCAL_TRY(adapter_set_pose(c, q_w_curr, t_w_curr));
     // transformUpdate (:735), host copy, insertion keys: what the second solve's launch does on the all-device path
-    SCAL_LAUNCH_PROF("k_map_pose_done", k_map_pose_done, dim3(64), dim3(256), 0, s, make_pose_done(c, e));
+    SCAL_LAUNCH("k_map_pose_done", k_map_pose_done, dim3(64), dim3(256), 0, s, make_pose_done(c, e));
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipEventRecord(c->ev_pose[e.slot], s));
-    SCAL_HIP(hipEventSynchronize(c->ev_pose[e.slot]));
+    SCAL_HIP(op_event_record(c->ev_pose[e.slot], s));
+    SCAL_HIP(op_event_synchronize(c->ev_pose[e.slot]));
     SCAL_TRY(general_insert(c, e));
     const MapResult& R = c->res.p[e.slot];
     for (int i = 0; i < 4; ++i) c->q_wmap_wodom[i] = R.S1.q_wmap_wodom[i];
@@ -2459,8 +2478,8 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
     if (e.have_full && registered) {
         const int n_full = c->h_misc.p[0];
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
-        SCAL_HIP(hipMemcpyAsync(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     return SCAL_OK;
 }
@@ -2482,6 +2501,6 @@ extern "C" int scal_map_debug_set_grid_cap(scal_map_t* c, int cap_corner, int ca
 extern "C" int scal_map_debug_set_lm_polls(scal_map_t* c, int polls) {
     if (!c || polls < 0) return SCAL_E_ARG;
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return lm_set_poll_budget(polls);
 }

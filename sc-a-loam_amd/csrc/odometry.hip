@@ -57,7 +57,7 @@ __device__ __forceinline__ void transform_to_start(const double* x7, float ox, f
 // Exact NN(1), tiled: block (qt, ch) scans target chunk ch (2048 points staged in LDS, read as wave-wide broadcasts)
 // for 64 queries; thread (q = tid % 64, part = tid / 64) covers a quarter of the chunk.  The per-(query, chunk) minima
 // are (f32 distance bits, target index) keys; k_odom_assoc takes the minimum over chunks.
-__global__ void __launch_bounds__(64 * NN_PARTS) k_odom_nn(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st,
+__device__ __forceinline__ void k_odom_nn_body(const CSoA4& sharp, const CSoA4& flat, const CSoA4& CL, const CSoA4& SL, const LMState* __restrict__ st,
                                                  const OdomCounters* __restrict__ C, int slot_cap, int nch, unsigned long long* __restrict__ part) {
     __shared__ float tx[NN_TC], ty[NN_TC], tz[NN_TC];
     __shared__ unsigned long long red[NN_PARTS][NN_QT];
@@ -109,10 +109,11 @@ __global__ void __launch_bounds__(64 * NN_PARTS) k_odom_nn(CSoA4 sharp, CSoA4 fl
         if (slot < slot_cap) part[(size_t)slot * nch + blockIdx.y] = b;
     }
 }
+SCAL_KERNEL(64 * NN_PARTS, k_odom_nn)
 
 // one wave per query
-__global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSoA4 CL, CSoA4 SL, const LMState* __restrict__ st, OdomCounters* C,
-                                                    int outer, FactorSoA f, int nch, const unsigned long long* __restrict__ part,
+__device__ __forceinline__ void k_odom_assoc_body(const CSoA4& sharp, const CSoA4& flat, const CSoA4& CL, const CSoA4& SL, const LMState* __restrict__ st, OdomCounters* C,
+                                                    int outer, const FactorSoA& f, int nch, const unsigned long long* __restrict__ part,
                                                     const int* __restrict__ ring_tab) {
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
@@ -257,14 +258,16 @@ __global__ void __launch_bounds__(256) k_odom_assoc(CSoA4 sharp, CSoA4 flat, CSo
         f.pb[q] = pb[0], f.pb[f.cap + q] = pb[1], f.pb[2 * f.cap + q] = pb[2];
     }
 }
+SCAL_KERNEL(256, k_odom_assoc)
 
-__global__ void k_odom_init_pose(LMState* st, int* ring_tab) {
+__device__ __forceinline__ void k_odom_init_pose_body(LMState* st, int* ring_tab) {
     if (threadIdx.x == 0) {
         st->x[0] = st->x[1] = st->x[2] = 0.0, st->x[3] = 1.0;  // para_q = {0,0,0,1}, para_t = {0,0,0} (:97-98)
         st->x[4] = st->x[5] = st->x[6] = 0.0;
     }
     for (int t = threadIdx.x; t < 8 * RING_TAB; t += blockDim.x) ring_tab[t] = ((t / RING_TAB) & 1) ? -1 : 0x7f7f7f7f;
 }
+SCAL_KERNEL(1024, k_odom_init_pose)
 // hand-over copy of both target clouds that also records, per ring id r = int(intensity), the first and last index holding r.
 // The tables are double-buffered: first_idx must be pre-filled with a value >= n (0x7f7f7f7f), last_idx with -1, which the
 // previous hand-over did for the set written now.  The walks of :312-361 / :402-455 stop at
@@ -283,7 +286,7 @@ struct HandoverArgs {
     LMState* host_st;
     const LMSync* sync; // an abandoned solve (any workgroup, this step or one queued in front of it) reaches the host as termination 5
 };
-__global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
+__device__ __forceinline__ void k_odom_handover_body(const HandoverArgs& a) {
     int b = blockIdx.x;
     const int k = b < a.nb0 ? 0 : 1;
     if (k) b -= a.nb0;
@@ -314,6 +317,7 @@ __global__ void __launch_bounds__(256) k_odom_handover(HandoverArgs a) {
         if (lane == 63 || rn != r || i == n - 1) atomicMax(&last_idx[r], i);
     }
 }
+SCAL_KERNEL(256, k_odom_handover)
 // Start of a device-resident step in ONE launch: refreshes the per-scan counters and copies the four feature clouds of a
 // features context (sharp / flat / lessSharp as xyzi records, lessFlat as SoA) into this context's SoA clouds.
 // Block ranges: [0,nbs) sharp, [nbs,2nbs) flat, [2nbs,2nbs+nbf) lessSharp, the rest lessFlat.
@@ -324,7 +328,7 @@ struct OdomGatherArgs {
     SoA4 o_sharp, o_flat, o_less, o_less_flat;
     int slot_cap, feat_cap, cap, nbs, nbf;
 };
-__global__ void __launch_bounds__(256) k_odom_gather(OdomGatherArgs a, OdomCounters* C) {
+__device__ __forceinline__ void k_odom_gather_body(const OdomGatherArgs& a, OdomCounters* C) {
     int b = blockIdx.x;
     const float* aos = nullptr;
     const int* d_n;
@@ -355,6 +359,7 @@ __global__ void __launch_bounds__(256) k_odom_gather(OdomGatherArgs a, OdomCount
         out.x[i] = a.less_flat.x[i], out.y[i] = a.less_flat.y[i], out.z[i] = a.less_flat.z[i], out.w[i] = a.less_flat.w[i];
     }
 }
+SCAL_KERNEL(256, k_odom_gather)
 
 struct OSoA {
     DevBuf<float> x, y, z, w;
@@ -449,12 +454,12 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
         if (hipEventCreateWithFlags(&c->ev[k], hipEventDisableTiming) != hipSuccess) rc = SCAL_E_HIP;
     if (rc == SCAL_OK) {
         // everything is initialised on the context's own stream (the legacy null stream is not ordered against it)
-        if (hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (op_memset_async(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
-        if (rc == SCAL_OK && hipMemsetAsync(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        if (rc == SCAL_OK && hipMemsetAsync(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
-        SCAL_LAUNCH_PROF("k_odom_init_pose", k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
-        if (rc == SCAL_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_memset_async(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK && op_memset_async(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        SCAL_LAUNCH("k_odom_init_pose", k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
+        if (rc == SCAL_OK && op_stream_synchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
     if (rc != SCAL_OK) {
         if (rc == SCAL_E_HIP) set_error("scal_odom_create: HIP resource creation failed");
@@ -469,7 +474,7 @@ extern "C" void scal_odom_destroy(scal_odom_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         release_stream(c->cfg.device, c->lane);
     }
     for (int k = 0; k < scal_odom::MAX_STEPS; ++k)
@@ -507,11 +512,11 @@ int odom_enqueue(scal_odom* c) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
             {
                 // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
-                SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
+                SCAL_LAUNCH("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
             }
             {
-                SCAL_LAUNCH_PROF("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
+                SCAL_LAUNCH("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
                                    c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
             }
             {
@@ -520,7 +525,7 @@ int odom_enqueue(scal_odom* c) {
         }
     }
     SCAL_TRY(launch_handover(c, slot));
-    SCAL_HIP(hipEventRecord(c->ev[slot], s));
+    SCAL_HIP(op_event_record(c->ev[slot], s));
     c->pending.push_back({slot, solve});
     return SCAL_OK;
 }
@@ -541,7 +546,7 @@ int launch_handover(scal_odom* c, int slot) {
         h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
         h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
         h.st = st, h.host_st = c->h_st.p + slot, h.sync = c->lm_sync.p;
-        SCAL_LAUNCH_PROF("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
+        SCAL_LAUNCH("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
         c->tab_cur ^= 1;
     }
     SCAL_HIP(hipGetLastError());
@@ -557,16 +562,16 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
     const int slot = c->pending.front().slot;
     const bool solve = c->pending.front().solve;
     c->pending.pop_front();
-    SCAL_HIP(hipEventSynchronize(c->ev[slot]));
+    SCAL_HIP(op_event_synchronize(c->ev[slot]));
     const LMState& L = c->h_st.p[slot];
     if (L.termination == 5) {
         // A workgroup of this step's solve - or of a step queued in front of it: the flag is sticky on the device and every solve
         // behind it returned at once - ran out of polls.  Never seen outside the test hook, but the pose cannot be trusted: the step
         // is reported as failed (the pose keeps its last good value), and the exchange is cleared once everything queued has drained.
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipMemsetAsync(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
+        (void)op_stream_synchronize(c->stream);
+        (void)op_memset_async(c->lm_sync.p, 0, sizeof(LMSync), c->stream);
         (void)c->partials.zero(c->stream);
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         set_error("LM solve abandoned: grid barrier timed out");
         return SCAL_E_HIP;
     }
@@ -599,7 +604,7 @@ int odom_collect(scal_odom* c, double* q_lc, double* t_lc, double* q_w, double* 
 static int odom_upload(scal_odom* c, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp, const float* flat, int n_flat,
                        const float* less_flat, int n_less_flat) {
     hipStream_t s = c->stream;
-    SCAL_HIP(hipStreamSynchronize(s));  // the upload staging may still feed the previous call's copy
+    SCAL_HIP(op_stream_synchronize(s));  // the upload staging may still feed the previous call's copy
     OdomCounters& H = *c->h_up.p;
     // keep the device-resident n_corner_last / n_surf_last, refresh the per-scan part from pinned memory
     OdomCounters fresh;
@@ -607,11 +612,11 @@ static int odom_upload(scal_odom* c, const float* sharp, int n_sharp, const floa
     fresh.n_sharp = n_sharp, fresh.n_flat = n_flat, fresh.n_less_sharp = n_less_sharp, fresh.n_less_flat = n_less_flat, fresh.enable = 1;
     H = fresh;
     const size_t off = offsetof(OdomCounters, n_sharp);
-    SCAL_HIP(hipMemcpyAsync(reinterpret_cast<char*>(c->d_C.p) + off, reinterpret_cast<char*>(&H) + off, sizeof(OdomCounters) - off,
+    SCAL_HIP(op_memcpy_async(reinterpret_cast<char*>(c->d_C.p) + off, reinterpret_cast<char*>(&H) + off, sizeof(OdomCounters) - off,
                             hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, OSoA& dst) -> int {
         if (n > 0) {
-            SCAL_HIP(hipMemcpyAsync(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            SCAL_HIP(op_memcpy_async(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
             launch_deinterleave(s, c->aos.p, n, dst.v());
         }
         return SCAL_OK;
@@ -670,7 +675,7 @@ extern "C" int scal_odom_enqueue_features(scal_odom_t* c, scal_features_t* feat)
     a.slot_cap = c->slot_cap, a.feat_cap = c->feat_cap, a.cap = std::min(c->cap, v.cap);
     a.nbs = std::max(1, div_up(c->slot_cap, 256)), a.nbf = std::max(1, div_up(c->feat_cap, 256));
     SCAL_TRY(features_wait_done(feat, s));
-    SCAL_LAUNCH_PROF("k_odom_gather", k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
+    SCAL_LAUNCH("k_odom_gather", k_odom_gather, dim3(2 * a.nbs + a.nbf + std::max(1, div_up(a.cap, 256))), dim3(256), 0, s, a, c->d_C.p);
     SCAL_TRY(features_note_reader(feat, s));  // everything stage B needs has been copied out of the features context
     return odom_enqueue(c);
 }
@@ -714,10 +719,10 @@ extern "C" int scal_odom_adapter_begin(scal_odom_t* c, const float* sharp, int n
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     SCAL_TRY(odom_upload(c, sharp, n_sharp, less_sharp, n_less_sharp, flat, n_flat, less_flat, n_less_flat));
-    SCAL_HIP(hipMemcpyAsync(c->h_st.p, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_st.p, c->d_st.p, sizeof(LMState), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     for (int i = 0; i < 4; ++i) q_last_curr[i] = c->h_st.p->x[i];   // para_q / para_t persist across scans (:97-101)
     for (int i = 0; i < 3; ++i) t_last_curr[i] = c->h_st.p->x[4 + i];
     c->adapter_solve = c->systemInited;  // first frame: no optimisation (:267-271)
@@ -729,10 +734,10 @@ extern "C" int scal_odom_adapter_begin(scal_odom_t* c, const float* sharp, int n
 }
 
 static int odom_set_pose(scal_odom* c, const double* q, const double* t) {
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     for (int i = 0; i < 4; ++i) c->h_x7.p[i] = q[i];
     for (int i = 0; i < 3; ++i) c->h_x7.p[4 + i] = t[i];
-    SCAL_HIP(hipMemcpyAsync(c->d_st.p->x, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
+    SCAL_HIP(op_memcpy_async(c->d_st.p->x, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, c->stream));
     return SCAL_OK;
 }
 
@@ -751,15 +756,15 @@ extern "C" int scal_odom_associate(scal_odom_t* c, const double* q_last_curr, co
     LMState* st = c->d_st.p;
     FactorSoA F = c->factors();
     SCAL_TRY(odom_set_pose(c, q_last_curr, t_last_curr));
-    SCAL_LAUNCH_PROF("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
+    SCAL_LAUNCH("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
                      c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
-    SCAL_LAUNCH_PROF("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
+    SCAL_LAUNCH("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
                      c->surf_last.cv(), st, C, std::min(c->outer_next, 1), F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
     c->outer_next++;
-    SCAL_LAUNCH_PROF("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
+    SCAL_LAUNCH("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(c->h_counts.p, c->bl_counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     *n_blocks = c->h_counts.p[0], *n_residuals = c->h_counts.p[1];
     return SCAL_OK;
 }
@@ -777,9 +782,9 @@ extern "C" int scal_odom_get_blocks(scal_odom_t* c, scal_block* out, int cap) {
     const int n = std::min(cap, c->h_counts.p[0]);
     if (n <= 0) return 0;
     hipStream_t s = c->stream;
-    SCAL_LAUNCH_PROF("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
-    SCAL_HIP(hipMemcpyAsync(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_LAUNCH("k_blocks_export", k_blocks_export, dim3(div_up(c->h_counts.p[0], 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_blocks.p);
+    SCAL_HIP(op_memcpy_async(out, c->d_blocks.p, sizeof(scal_block) * n, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return n;
 }
 
@@ -796,15 +801,15 @@ extern "C" int scal_odom_eval_blocks(scal_odom_t* c, const double* x7, int want_
     const int nb = c->h_counts.p[0], nr = c->h_counts.p[1];
     if (nb == 0) return SCAL_OK;
     hipStream_t s = c->stream;
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     for (int i = 0; i < 7; ++i) c->h_x7.p[i] = x7[i];
-    SCAL_HIP(hipMemcpyAsync(c->d_x7.p, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));
-    SCAL_LAUNCH_PROF("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
+    SCAL_HIP(op_memcpy_async(c->d_x7.p, c->h_x7.p, sizeof(double) * 7, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH("k_blocks_eval", k_blocks_eval, dim3(div_up(nb, 256)), dim3(256), 0, s, c->factors(), c->block_list(), c->d_x7.p, want_jac ? 1 : 0,
                      c->d_res.p, c->d_jac.p);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
-    if (want_jac) SCAL_HIP(hipMemcpyAsync(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(residuals, c->d_res.p, sizeof(double) * nr, hipMemcpyDeviceToHost, s));
+    if (want_jac) SCAL_HIP(op_memcpy_async(jacobians, c->d_jac.p, sizeof(double) * 7 * nr, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -823,7 +828,7 @@ extern "C" int scal_odom_adapter_finish(scal_odom_t* c, const double* q_last_cur
     const int slot = c->next_slot;
     c->next_slot = (c->next_slot + 1) % scal_odom::MAX_STEPS;
     SCAL_TRY(launch_handover(c, slot));
-    SCAL_HIP(hipEventRecord(c->ev[slot], c->stream));
+    SCAL_HIP(op_event_record(c->ev[slot], c->stream));
     c->pending.push_back({slot, c->adapter_solve});
     double q_lc[4], t_lc[3];
     return odom_collect(c, q_lc, t_lc, q_w_curr, t_w_curr, nullptr);  // pose integration (:504-505)

@@ -53,23 +53,26 @@ struct HostTimer {
     }
 };
 
+constexpr int SMAX = scal::BATCH_MAX;  // sequences that share launches
 struct Rec {
-    const float* d_xyz = nullptr;
-    const void* h_xyz = nullptr;
-    int n = 0, stride = 0;
+    const float* d_xyz[SMAX] = {};
+    const void* h_xyz[SMAX] = {};
+    int n[SMAX] = {};
+    int stride = 0;
     bool host = false;
-    scal_pipeline_result res{};
+    scal_pipeline_result res[SMAX] = {};
 };
 }  // namespace
 
 struct scal_pipeline {
     scal_pipeline_config cfg{};
     int ring = 6, depth = 2;
-    std::vector<scal_features_t*> regs;
-    scal_odom_t* od = nullptr;
-    scal_map_t* mp = nullptr;
-    scal_sc_t* sc = nullptr;
-    double* d_desc = nullptr;  // sc_mode 2: ring x 1200 doubles
+    int S = 1;  // independent sequences stepping together; S > 1: their per-stage calls are recorded and zipped (batch.hpp)
+    std::vector<scal_features_t*> regs[SMAX];
+    scal_odom_t* od[SMAX] = {};
+    scal_map_t* mp[SMAX] = {};
+    scal_sc_t* sc[SMAX] = {};
+    double* d_desc = nullptr;  // sc_mode 2: ring x 1200 doubles (S = 1 only)
     bool own_desc = false;
     Rec rec[REC_N];
     std::mutex mu;
@@ -86,6 +89,36 @@ struct scal_pipeline {
 
     bool sc_on() const { return cfg.sc_mode != SCAL_PIPE_SC_OFF; }
     Rec& r(long long k) { return rec[k % REC_N]; }
+    // one per-stage call for every sequence.  S = 1: the call itself.  S > 1: each sequence's call runs under a recorder (nothing
+    // reaches the device), then the S lists are zipped: same kernel, same shape -> one launch with gridDim.z = S.
+    template <class F>
+    int for_all(F&& f) {
+        if (S == 1) return f(0);
+        Recorder recs[SMAX];
+        Recorder* ptr[SMAX];
+        int rc = SCAL_OK;
+        for (int q = 0; q < S && rc == SCAL_OK; ++q) {
+            ptr[q] = &recs[q];
+            g_recorder = &recs[q];
+            rc = f(q);
+            g_recorder = nullptr;
+        }
+        if (rc != SCAL_OK) {  // what the earlier sequences queued still has to run: their host state already counts on it
+            for (int q = 0; q < S; ++q) (void)recs[q].flush();
+            return rc;
+        }
+        if (zip_and_launch(ptr, S) != hipSuccess) {
+            set_error("scal_pipeline: a batched launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return SCAL_E_HIP;
+        }
+        return SCAL_OK;
+    }
+    // calls that wait for the device: one after the other
+    template <class F>
+    int for_each(F&& f) {
+        for (int q = 0; q < S; ++q) SCAL_TRY(f(q));
+        return SCAL_OK;
+    }
     void fail(int rc) {  // called with mu held, from the thread whose stage call failed
         if (err == SCAL_OK) {
             err = rc;
@@ -109,13 +142,17 @@ void front_thread(scal_pipeline* p) {
             return k - p->c_enq < PF_AHEAD;     // prefetches queued ahead of their stage-C steps
         });
         if (p->stop || p->err) return;
-        Rec rc = p->r(k);
-        scal_features_t* reg = p->regs[k % p->ring];
+        const Rec& rc = p->r(k);
+        const int slot = static_cast<int>(k % p->ring);
         lk.unlock();
         int st = p->tm_front.run(0, "A: features_run", [&] {
-            return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz, rc.n, rc.stride) : scal_features_run_device(reg, rc.d_xyz, rc.n, rc.stride);
+            return p->for_all([&](int q) {
+                scal_features_t* reg = p->regs[q][slot];
+                return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz[q], rc.n[q], rc.stride) : scal_features_run_device(reg, rc.d_xyz[q], rc.n[q], rc.stride);
+            });
         });
-        if (st == SCAL_OK) st = p->tm_front.run(1, "C: map_prefetch_features", [&] { return scal_map_prefetch_features(p->mp, reg); });
+        if (st == SCAL_OK)
+            st = p->tm_front.run(1, "C: map_prefetch_features", [&] { return p->for_all([&](int q) { return scal_map_prefetch_features(p->mp[q], p->regs[q][slot]); }); });
         lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
@@ -146,32 +183,40 @@ void pose_thread(scal_pipeline* p) {
         int st = SCAL_OK;
         if (what == B_ENQ) {
             const long long k = p->b_enq;
-            scal_features_t* reg = p->regs[k % p->ring];
+            const int slot = static_cast<int>(k % p->ring);
             lk.unlock();
-            st = p->tm_pose.run(0, "B: odom_enqueue_features", [&] { return scal_odom_enqueue_features(p->od, reg); });
+            st = p->tm_pose.run(0, "B: odom_enqueue_features", [&] { return p->for_all([&](int q) { return scal_odom_enqueue_features(p->od[q], p->regs[q][slot]); }); });
             lk.lock();
             if (st == SCAL_OK) p->b_enq = k + 1;
         } else if (what == B_COLL) {
             const long long k = p->b_coll;
-            scal_features_t* reg = p->regs[k % p->ring];
-            scal_pipeline_result& R = p->r(k).res;
+            const int slot = static_cast<int>(k % p->ring);
+            scal_pipeline_result* R = p->r(k).res;
             lk.unlock();
-            double qlc[4], tlc[3];
-            st = p->tm_pose.run(1, "B: odom_collect (wait)", [&] { return scal_odom_collect(p->od, qlc, tlc, R.q_odom, R.t_odom, &R.odom); });
+            st = p->tm_pose.run(1, "B: odom_collect (wait)", [&] {
+                return p->for_each([&](int q) {
+                    double qlc[4], tlc[3];
+                    return scal_odom_collect(p->od[q], qlc, tlc, R[q].q_odom, R[q].t_odom, &R[q].odom);
+                });
+            });
             if (st == SCAL_OK)  // the pose goes straight into stage C
-                st = p->tm_pose.run(2, "C: map_enqueue_features", [&] { return scal_map_enqueue_features(p->mp, reg, R.q_odom, R.t_odom); });
+                st = p->tm_pose.run(2, "C: map_enqueue_features", [&] {
+                    return p->for_all([&](int q) { return scal_map_enqueue_features(p->mp[q], p->regs[q][slot], R[q].q_odom, R[q].t_odom); });
+                });
             lk.lock();
             if (st == SCAL_OK) p->b_coll = k + 1, p->c_enq = k + 1;
         } else if (what == C_COLL) {
             const long long k = p->c_coll;
-            scal_pipeline_result& R = p->r(k).res;
+            scal_pipeline_result* R = p->r(k).res;
             lk.unlock();
-            st = p->tm_pose.run(3, "C: map_collect (wait)", [&] { return scal_map_collect(p->mp, R.q_w_curr, R.t_w_curr, &R.map); });
+            st = p->tm_pose.run(3, "C: map_collect (wait)", [&] {
+                return p->for_each([&](int q) { return scal_map_collect(p->mp[q], R[q].q_w_curr, R[q].t_w_curr, &R[q].map); });
+            });
             lk.lock();
             if (st == SCAL_OK) p->c_coll = k + 1;
         } else if (what == FINISH) {
             lk.unlock();
-            st = scal_map_finish(p->mp);  // the last scan's map insertion (:738-802) belongs to the work
+            st = p->for_each([&](int q) { return scal_map_finish(p->mp[q]); });  // the last scan's map insertion (:738-802) belongs to the work
             lk.lock();
             if (st == SCAL_OK) p->drain_req = false, p->drained = true;
         }
@@ -201,29 +246,34 @@ void loop_thread(scal_pipeline* p) {
         int st = SCAL_OK;
         if (what == INS) {
             const long long k = p->d_ins;
-            scal_features_t* reg = p->regs[k % p->ring];
-            double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(k % p->ring) * 1200 : nullptr;
+            const int slot = static_cast<int>(k % p->ring);
+            double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(slot) * 1200 : nullptr;
             lk.unlock();
             if (search) {
-                st = p->tm_loop.run(0, "D: sc_insert_features", [&] { return scal_sc_insert_features(p->sc, reg); });
-                if (st == SCAL_OK) st = p->tm_loop.run(1, "D: sc_detect_enqueue", [&] { return scal_sc_detect_enqueue(p->sc); });
+                st = p->tm_loop.run(0, "D: sc_insert_features", [&] { return p->for_all([&](int q) { return scal_sc_insert_features(p->sc[q], p->regs[q][slot]); }); });
+                if (st == SCAL_OK) st = p->tm_loop.run(1, "D: sc_detect_enqueue", [&] { return p->for_all([&](int q) { return scal_sc_detect_enqueue(p->sc[q]); }); });
             } else {
-                st = scal_sc_make_features_enqueue(p->sc, reg, dd);
+                st = scal_sc_make_features_enqueue(p->sc[0], p->regs[0][slot], dd);
             }
             lk.lock();
             if (st == SCAL_OK) {
-                p->r(k).res.d_descriptor = dd;
+                p->r(k).res[0].d_descriptor = dd;
                 p->d_ins = k + 1;
             }
         } else {
             const long long k = p->d_coll;
-            scal_pipeline_result& R = p->r(k).res;
+            scal_pipeline_result* R = p->r(k).res;
             lk.unlock();
             if (search) {
-                st = p->tm_loop.run(2, "D: sc_detect_collect (wait)", [&] { return scal_sc_detect_collect(p->sc, &R.loop); });
-                R.have_loop = st == SCAL_OK;
+                st = p->tm_loop.run(2, "D: sc_detect_collect (wait)", [&] {
+                    return p->for_each([&](int q) {
+                        const int rc = scal_sc_detect_collect(p->sc[q], &R[q].loop);
+                        R[q].have_loop = rc == SCAL_OK;
+                        return rc;
+                    });
+                });
             } else {
-                st = scal_sc_wait_descriptor(p->sc);
+                st = scal_sc_wait_descriptor(p->sc[0]);
             }
             lk.lock();
             if (st == SCAL_OK) p->d_coll = k + 1;
@@ -241,7 +291,7 @@ int report(scal_pipeline* p) {  // mu held
     return p->err;
 }
 
-int push(scal_pipeline* p, const float* d_xyz, const void* h_xyz, int n, int stride, bool host) {
+int push(scal_pipeline* p, const float* const* d_xyz, const void* const* h_xyz, const int* n, int stride, bool host) {
     std::unique_lock<std::mutex> lk(p->mu);
     if (p->err) return report(p);
     if (p->pushed - p->popped >= MAX_UNPOPPED) {
@@ -251,8 +301,11 @@ int push(scal_pipeline* p, const float* d_xyz, const void* h_xyz, int n, int str
     const long long k = p->pushed;
     Rec& rc = p->r(k);
     rc = Rec();
-    rc.d_xyz = d_xyz, rc.h_xyz = h_xyz, rc.n = n, rc.stride = stride, rc.host = host;
-    rc.res.seq = k;
+    for (int q = 0; q < p->S; ++q) {
+        rc.d_xyz[q] = d_xyz ? d_xyz[q] : nullptr, rc.h_xyz[q] = h_xyz ? h_xyz[q] : nullptr, rc.n[q] = n[q];
+        rc.res[q].seq = k;
+    }
+    rc.stride = stride, rc.host = host;
     p->pushed = k + 1;
     p->drained = false;
     p->cv.notify_all();
@@ -263,9 +316,25 @@ int push(scal_pipeline* p, const float* d_xyz, const void* h_xyz, int n, int str
     return SCAL_OK;
 }
 
-}  // namespace
+int pop(scal_pipeline* p, scal_pipeline_result* out) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    if (p->popped >= p->pushed && !p->err) {
+        set_error("scal_pipeline_pop: nothing pushed");
+        return SCAL_E_STATE;
+    }
+    const long long k = p->popped;
+    p->pop_waiting++;
+    p->cv.notify_all();
+    p->cv.wait(lk, [&] { return p->err || (p->c_coll > k && (!p->sc_on() || p->d_coll > k)); });
+    p->pop_waiting--;
+    if (p->err) return report(p);
+    for (int q = 0; q < p->S; ++q) out[q] = p->r(k).res[q];
+    p->popped = k + 1;
+    p->cv.notify_all();
+    return SCAL_OK;
+}
 
-extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeline_t** out) {
+int create(const scal_pipeline_config* cfg, int n_seqs, scal_pipeline_t** out) {
     if (!cfg || !out) {
         set_error("scal_pipeline_create: null argument");
         return SCAL_E_ARG;
@@ -276,48 +345,54 @@ extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeli
         set_error("scal_pipeline_create: ring must be 4..16, depth 1..3, sc_mode 0..2");
         return SCAL_E_ARG;
     }
+    if (n_seqs < 1 || n_seqs > SMAX || (n_seqs > 1 && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR)) {
+        set_error("scal_pipeline_create_multi: 1..%d sequences (sc_mode 2 only with one)", SMAX);
+        return SCAL_E_ARG;
+    }
     SCAL_TRY(select_device(cfg->device));
     const int mode_before = stream_mode();
     SCAL_TRY(scal_set_stream_mode(1));  // one stream per stage; the contexts created below pick their lanes from it
     auto* p = new scal_pipeline();
-    p->cfg = *cfg, p->ring = ring, p->depth = depth;
+    p->cfg = *cfg, p->ring = ring, p->depth = depth, p->S = n_seqs;
     int rc = SCAL_OK;
     scal_features_config fc{};
     fc.lidar_type = cfg->lidar_type, fc.n_scans = cfg->n_scans, fc.minimum_range = cfg->minimum_range, fc.max_points = cfg->max_points;
     fc.float_math = cfg->float_math, fc.check_finite = cfg->check_finite, fc.device = cfg->device;
-    for (int i = 0; i < ring && rc == SCAL_OK; ++i) {
-        scal_features_t* f = nullptr;
-        rc = scal_features_create(&fc, &f);
-        if (rc == SCAL_OK) p->regs.push_back(f);
-    }
-    if (rc == SCAL_OK) {
-        scal_odom_config oc{};
-        oc.max_points = cfg->max_points, oc.device = cfg->device;
-        rc = scal_odom_create(&oc, &p->od);
-    }
-    if (rc == SCAL_OK) {
-        scal_map_config mc{};
-        mc.line_res = cfg->line_res, mc.plane_res = cfg->plane_res, mc.max_scan_points = cfg->max_points, mc.max_map_points = cfg->max_map_points;
-        mc.device = cfg->device;
-        rc = scal_map_create(&mc, &p->mp);
-    }
-    if (rc == SCAL_OK && p->sc_on()) {
-        scal_sc_config sc{};
-        sc.max_radius = cfg->sc_max_radius, sc.dist_thres = cfg->sc_dist_thres, sc.max_keyframes = cfg->sc_max_keyframes;
-        sc.float_math = cfg->float_math, sc.device = cfg->device, sc.n_shards = 1, sc.shard = 0, sc.side_stream = env_int("SCALOAM_PIPE_SC_LANE", 1, 0, 5);
-        // ScanContext entirely on the side stream it shares with stage C's surf filter (keyframe filter, descriptor, search: one in-order
-        // chain, no cross-stream wait).  With the descriptor + search behind stage B instead (scal_set_stream_mode(1)'s own split, lane 0
-        // here) stage B's chain queues behind a search that waits for the keyframe filter on the other stream: 3250-3360 scans/s against
-        // 3660 on one box (tools/gpu_pipe_knobs.sh).
-        rc = scal_sc_create(&sc, &p->sc);
-        if (rc == SCAL_OK && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR) {
-            if (cfg->d_desc_ring) {
-                p->d_desc = cfg->d_desc_ring;
-            } else if (hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(double) * 1200 * ring) != hipSuccess) {
-                set_error("scal_pipeline_create: hipMalloc of the descriptor ring failed");
-                rc = SCAL_E_HIP;
-            } else {
-                p->own_desc = true;
+    for (int q = 0; q < n_seqs && rc == SCAL_OK; ++q) {
+        for (int i = 0; i < ring && rc == SCAL_OK; ++i) {
+            scal_features_t* f = nullptr;
+            rc = scal_features_create(&fc, &f);
+            if (rc == SCAL_OK) p->regs[q].push_back(f);
+        }
+        if (rc == SCAL_OK) {
+            scal_odom_config oc{};
+            oc.max_points = cfg->max_points, oc.device = cfg->device;
+            rc = scal_odom_create(&oc, &p->od[q]);
+        }
+        if (rc == SCAL_OK) {
+            scal_map_config mc{};
+            mc.line_res = cfg->line_res, mc.plane_res = cfg->plane_res, mc.max_scan_points = cfg->max_points, mc.max_map_points = cfg->max_map_points;
+            mc.device = cfg->device;
+            rc = scal_map_create(&mc, &p->mp[q]);
+        }
+        if (rc == SCAL_OK && p->sc_on()) {
+            scal_sc_config sc{};
+            sc.max_radius = cfg->sc_max_radius, sc.dist_thres = cfg->sc_dist_thres, sc.max_keyframes = cfg->sc_max_keyframes;
+            sc.float_math = cfg->float_math, sc.device = cfg->device, sc.n_shards = 1, sc.shard = 0, sc.side_stream = env_int("SCALOAM_PIPE_SC_LANE", 1, 0, 5);
+            // ScanContext entirely on the side stream it shares with stage C's surf filter (keyframe filter, descriptor, search: one in-order
+            // chain, no cross-stream wait).  With the descriptor + search behind stage B instead (scal_set_stream_mode(1)'s own split, lane 0
+            // here) stage B's chain queues behind a search that waits for the keyframe filter on the other stream: 3250-3360 scans/s against
+            // 3660 on one box (tools/gpu_pipe_knobs.sh).
+            rc = scal_sc_create(&sc, &p->sc[q]);
+            if (rc == SCAL_OK && cfg->sc_mode == SCAL_PIPE_SC_DESCRIPTOR) {
+                if (cfg->d_desc_ring) {
+                    p->d_desc = cfg->d_desc_ring;
+                } else if (hipMalloc(reinterpret_cast<void**>(&p->d_desc), sizeof(double) * 1200 * ring) != hipSuccess) {
+                    set_error("scal_pipeline_create: hipMalloc of the descriptor ring failed");
+                    rc = SCAL_E_HIP;
+                } else {
+                    p->own_desc = true;
+                }
             }
         }
     }
@@ -335,6 +410,12 @@ extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeli
     return SCAL_OK;
 }
 
+}  // namespace
+
+extern "C" int scal_pipeline_create(const scal_pipeline_config* cfg, scal_pipeline_t** out) { return create(cfg, 1, out); }
+extern "C" int scal_pipeline_create_multi(const scal_pipeline_config* cfg, int n_seqs, scal_pipeline_t** out) { return create(cfg, n_seqs, out); }
+extern "C" int scal_pipeline_seqs(scal_pipeline_t* p) { return p ? p->S : 0; }
+
 extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
     if (!p) return;
     {
@@ -348,58 +429,70 @@ extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
     if (TIMING) p->tm_front.print("front"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
     (void)hipSetDevice(p->cfg.device);
     // consumers first: their destructors wait for the streams that still read the features contexts
-    if (p->sc) scal_sc_destroy(p->sc);
-    if (p->mp) scal_map_destroy(p->mp);
-    if (p->od) scal_odom_destroy(p->od);
-    for (auto* f : p->regs) scal_features_destroy(f);
+    for (int q = 0; q < SMAX; ++q) {
+        if (p->sc[q]) scal_sc_destroy(p->sc[q]);
+        if (p->mp[q]) scal_map_destroy(p->mp[q]);
+        if (p->od[q]) scal_odom_destroy(p->od[q]);
+    }
+    for (int q = 0; q < SMAX; ++q)
+        for (auto* f : p->regs[q]) scal_features_destroy(f);
     if (p->d_desc && p->own_desc) (void)hipFree(p->d_desc);
     delete p;
 }
 
-extern "C" int scal_pipeline_push_device(scal_pipeline_t* p, const float* d_xyz, int n, int stride_floats) {
-    if (!p || (!d_xyz && n > 0) || n < 0 || stride_floats < 3) {
-        set_error("scal_pipeline_push_device: bad argument");
+static int check_scan(scal_pipeline_t* p, const void* ptr, int n) {
+    if ((!ptr && n > 0) || n < 0) {
+        set_error("scal_pipeline_push: bad argument");
         return SCAL_E_ARG;
     }
     if (n > p->cfg.max_points) {
         set_error("scan has %d points, capacity is %d", n, p->cfg.max_points);
         return SCAL_E_TOO_MANY;
     }
+    return SCAL_OK;
+}
+
+extern "C" int scal_pipeline_push_device(scal_pipeline_t* p, const float* d_xyz, int n, int stride_floats) {
+    if (!p || stride_floats < 3 || p->S != 1) {
+        set_error("scal_pipeline_push_device: bad argument (a pipeline of several sequences takes scal_pipeline_push_device_multi)");
+        return SCAL_E_ARG;
+    }
+    SCAL_TRY(check_scan(p, d_xyz, n));
+    return push(p, &d_xyz, nullptr, &n, stride_floats, false);
+}
+
+extern "C" int scal_pipeline_push_device_multi(scal_pipeline_t* p, const float* const* d_xyz, const int* n, int stride_floats) {
+    if (!p || !d_xyz || !n || stride_floats < 3) {
+        set_error("scal_pipeline_push_device_multi: bad argument");
+        return SCAL_E_ARG;
+    }
+    for (int q = 0; q < p->S; ++q) SCAL_TRY(check_scan(p, d_xyz[q], n[q]));
     return push(p, d_xyz, nullptr, n, stride_floats, false);
 }
 
 extern "C" int scal_pipeline_push_host(scal_pipeline_t* p, const void* xyz, int n, int stride_bytes) {
-    if (!p || (!xyz && n > 0) || n < 0 || stride_bytes < 12 || (stride_bytes % 4) != 0 || stride_bytes > 32) {
-        set_error("scal_pipeline_push_host: bad argument (stride_bytes must be a multiple of 4 in [12, 32])");
+    if (!p || stride_bytes < 12 || (stride_bytes % 4) != 0 || stride_bytes > 32 || p->S != 1) {
+        set_error("scal_pipeline_push_host: bad argument (stride_bytes must be a multiple of 4 in [12, 32]; one sequence)");
         return SCAL_E_ARG;
     }
-    if (n > p->cfg.max_points) {
-        set_error("scan has %d points, capacity is %d", n, p->cfg.max_points);
-        return SCAL_E_TOO_MANY;
-    }
-    return push(p, nullptr, xyz, n, stride_bytes, true);
+    SCAL_TRY(check_scan(p, xyz, n));
+    return push(p, nullptr, &xyz, &n, stride_bytes, true);
 }
 
 extern "C" int scal_pipeline_pop(scal_pipeline_t* p, scal_pipeline_result* out) {
-    if (!p || !out) {
-        set_error("scal_pipeline_pop: null argument");
+    if (!p || !out || p->S != 1) {
+        set_error("scal_pipeline_pop: bad argument (a pipeline of several sequences takes scal_pipeline_pop_multi)");
         return SCAL_E_ARG;
     }
-    std::unique_lock<std::mutex> lk(p->mu);
-    if (p->popped >= p->pushed && !p->err) {
-        set_error("scal_pipeline_pop: nothing pushed");
-        return SCAL_E_STATE;
+    return pop(p, out);
+}
+
+extern "C" int scal_pipeline_pop_multi(scal_pipeline_t* p, scal_pipeline_result* out) {
+    if (!p || !out) {
+        set_error("scal_pipeline_pop_multi: null argument");
+        return SCAL_E_ARG;
     }
-    const long long k = p->popped;
-    p->pop_waiting++;
-    p->cv.notify_all();
-    p->cv.wait(lk, [&] { return p->err || (p->c_coll > k && (!p->sc_on() || p->d_coll > k)); });
-    p->pop_waiting--;
-    if (p->err) return report(p);
-    *out = p->r(k).res;
-    p->popped = k + 1;
-    p->cv.notify_all();
-    return SCAL_OK;
+    return pop(p, out);
 }
 
 extern "C" int scal_pipeline_drain(scal_pipeline_t* p) {
@@ -422,9 +515,12 @@ extern "C" int scal_pipeline_in_flight(scal_pipeline_t* p) {
     return static_cast<int>(p->pushed - p->popped);
 }
 
-extern "C" scal_sc_t* scal_pipeline_sc(scal_pipeline_t* p) { return p ? p->sc : nullptr; }
-extern "C" scal_map_t* scal_pipeline_map(scal_pipeline_t* p) { return p ? p->mp : nullptr; }
-extern "C" scal_odom_t* scal_pipeline_odom(scal_pipeline_t* p) { return p ? p->od : nullptr; }
+static bool seq_ok(scal_pipeline_t* p, int q) { return p && q >= 0 && q < p->S; }
+extern "C" scal_sc_t* scal_pipeline_sc(scal_pipeline_t* p) { return p ? p->sc[0] : nullptr; }
+extern "C" scal_map_t* scal_pipeline_map(scal_pipeline_t* p) { return p ? p->mp[0] : nullptr; }
+extern "C" scal_odom_t* scal_pipeline_odom(scal_pipeline_t* p) { return p ? p->od[0] : nullptr; }
 extern "C" scal_features_t* scal_pipeline_features(scal_pipeline_t* p, int i) {
-    return (p && i >= 0 && i < static_cast<int>(p->regs.size())) ? p->regs[i] : nullptr;
+    return (p && i >= 0 && i < static_cast<int>(p->regs[0].size())) ? p->regs[0][i] : nullptr;
 }
+extern "C" scal_sc_t* scal_pipeline_sc_of(scal_pipeline_t* p, int seq) { return seq_ok(p, seq) ? p->sc[seq] : nullptr; }
+extern "C" scal_map_t* scal_pipeline_map_of(scal_pipeline_t* p, int seq) { return seq_ok(p, seq) ? p->mp[seq] : nullptr; }

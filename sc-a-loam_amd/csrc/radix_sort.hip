@@ -29,7 +29,7 @@ __device__ __forceinline__ bool pass_plan(const int* d_used_bits, int max_bits, 
 // Histogram matrix layout: [block][digit] for ordinary sorts (a wave of the scatter kernel then reads 64 consecutive digits of
 // one block = one or two cache lines per load), [digit][block] for sorts that go through the hierarchical scan (its flattened
 // order must be digit-major).
-__global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int pass, int max_bits,
+__device__ __forceinline__ void k_rs_hist_body(const unsigned long long* __restrict__ keys, const int* __restrict__ d_n, int pass, int max_bits,
                                                  const int* __restrict__ d_used_bits, int* __restrict__ hist, int digit_major) {
     int shift, width;
     if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
@@ -49,8 +49,9 @@ __global__ void __launch_bounds__(256) k_rs_hist(const unsigned long long* __res
     __syncthreads();
     for (int i = threadIdx.x; i < bins; i += 256) hist[digit_major ? i * nb + blockIdx.x : blockIdx.x * RS_BINS_MAX + i] = h[i];
 }
+SCAL_KERNEL(256, k_rs_hist)
 
-__global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int* __restrict__ d_n, int tile, int bins, int* __restrict__ d_total) {
+__device__ __forceinline__ void k_scan_body(int* __restrict__ data, const int* __restrict__ d_n, int tile, int bins, int* __restrict__ d_total) {
     __shared__ int smem[17];
     const int n = *d_n;
     const int m = bins * ((n + tile - 1) / tile);
@@ -67,8 +68,9 @@ __global__ void __launch_bounds__(1024) k_scan(int* __restrict__ data, const int
     }
     if (d_total && threadIdx.x == 0) *d_total = total;
 }
+SCAL_KERNEL(1024, k_scan)
 
-__global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
+__device__ __forceinline__ void k_rs_scatter_body(const unsigned long long* __restrict__ keys, const int* __restrict__ vals,
                                                     const int* __restrict__ d_n, int pass, int max_bits, const int* __restrict__ d_used_bits,
                                                     const int* __restrict__ hist, unsigned long long* __restrict__ okeys, int* __restrict__ ovals,
                                                     int scanned) {
@@ -186,12 +188,13 @@ __global__ void __launch_bounds__(256) k_rs_scatter(const unsigned long long* __
     }
     if (stamp) SCAL_STAMP(5);
 }
+SCAL_KERNEL(256, k_rs_scatter)
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_radix)
 
 // ---- hierarchical exclusive scan of the flattened histogram matrix (digit-major: exactly the scatter base of (digit, block)),
 // used when the sort has too many blocks for every scatter workgroup to sum the matrix rows itself.  m = bins * nb.
 constexpr int HS_TILE = 4096;
-__global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
+__device__ __forceinline__ void k_hs_reduce_body(const int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
                                                      const int* __restrict__ d_used_bits, int* __restrict__ tile_sum) {
     int shift, width;
     if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
@@ -210,7 +213,8 @@ __global__ void __launch_bounds__(1024) k_hs_reduce(const int* __restrict__ data
     block_exclusive_scan(sum, smem, &total);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, const int* __restrict__ d_n, int pass, int max_bits,
+SCAL_KERNEL(1024, k_hs_reduce)
+__device__ __forceinline__ void k_hs_tiles_body(int* __restrict__ tile_sum, const int* __restrict__ d_n, int pass, int max_bits,
                                                     const int* __restrict__ d_used_bits) {
     int shift, width;
     if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
@@ -229,7 +233,8 @@ __global__ void __launch_bounds__(1024) k_hs_tiles(int* __restrict__ tile_sum, c
         run += v;
     }
 }
-__global__ void __launch_bounds__(1024) k_hs_apply(int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
+SCAL_KERNEL(1024, k_hs_tiles)
+__device__ __forceinline__ void k_hs_apply_body(int* __restrict__ data, const int* __restrict__ d_n, int pass, int max_bits,
                                                     const int* __restrict__ d_used_bits, const int* __restrict__ tile_off) {
     int shift, width;
     if (!pass_plan(d_used_bits, max_bits, pass, shift, width)) return;
@@ -255,6 +260,7 @@ __global__ void __launch_bounds__(1024) k_hs_apply(int* __restrict__ data, const
         run += v[q];
     }
 }
+SCAL_KERNEL(1024, k_hs_apply)
 
 int RadixSort::init(int capacity) {
     cap = capacity;
@@ -275,13 +281,13 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
     const int passes = rs_passes(max_bits);
     for (int pass = 0; pass < passes; ++pass) {
         const int in = pass & 1, o = in ^ 1;
-        SCAL_LAUNCH_PROF(n_hist.c_str(), k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, pass, max_bits, d_used_bits, hist.p, big ? 1 : 0);
+        SCAL_LAUNCH(n_hist.c_str(), k_rs_hist, dim3(nb), dim3(256), 0, s, kb[in], d_n, pass, max_bits, d_used_bits, hist.p, big ? 1 : 0);
         if (big) {
-            SCAL_LAUNCH_PROF("k_hs_reduce", k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
-            SCAL_LAUNCH_PROF("k_hs_tiles", k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, pass, max_bits, d_used_bits);
-            SCAL_LAUNCH_PROF("k_hs_apply", k_hs_apply, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
+            SCAL_LAUNCH("k_hs_reduce", k_hs_reduce, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
+            SCAL_LAUNCH("k_hs_tiles", k_hs_tiles, dim3(1), dim3(1024), 0, s, tile_sum.p, d_n, pass, max_bits, d_used_bits);
+            SCAL_LAUNCH("k_hs_apply", k_hs_apply, dim3(nt), dim3(1024), 0, s, hist.p, d_n, pass, max_bits, d_used_bits, tile_sum.p);
         }
-        SCAL_LAUNCH_PROF(n_scatter.c_str(), k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, pass, max_bits, d_used_bits, hist.p, kb[o],
+        SCAL_LAUNCH(n_scatter.c_str(), k_rs_scatter, dim3(nb), dim3(256), 0, s, kb[in], vb[in], d_n, pass, max_bits, d_used_bits, hist.p, kb[o],
                          vb[o], big ? 1 : 0);
     }
     out->keys[0] = kb[0], out->keys[1] = kb[1];
@@ -293,7 +299,7 @@ int RadixSort::sort(hipStream_t s, unsigned long long* keys, int* vals, const in
 }
 
 void launch_scan_inplace(hipStream_t s, int* data, const int* d_n, int tile, int bins, int* d_total) {
-    SCAL_LAUNCH_PROF("k_scan", k_scan, dim3(1), dim3(1024), 0, s, data, d_n, tile, bins, d_total);
+    SCAL_LAUNCH("k_scan", k_scan, dim3(1), dim3(1024), 0, s, data, d_n, tile, bins, d_total);
 }
 
 }  // namespace scal

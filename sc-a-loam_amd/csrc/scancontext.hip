@@ -66,7 +66,7 @@ __device__ __forceinline__ int ceil_to_int(double v) {  // int(ceil(v)); NaN -> 
 // points may be AoS xyzi (stride 4, y=z=null) or SoA.  Two launches: k_sc_bin (many workgroups: LDS atomic-max polar
 // binning on an order-preserving integer image of the f32 height, merged into a global 1200-cell image) and k_sc_finish
 // (one workgroup: descriptor, keys, column norms; clears the global image again so it is always zero between scans).
-__global__ void __launch_bounds__(256) k_sc_bin(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int stride,
+__device__ __forceinline__ void k_sc_bin_body(const float* __restrict__ px, const float* __restrict__ py, const float* __restrict__ pz, int stride,
                                                 const int* __restrict__ d_n, int n_host, double max_radius, int float_math,
                                                 unsigned* __restrict__ gcell) {
     __shared__ unsigned cell[DESC];
@@ -94,6 +94,7 @@ __global__ void __launch_bounds__(256) k_sc_bin(const float* __restrict__ px, co
     for (int i = threadIdx.x; i < DESC; i += blockDim.x)
         if (cell[i]) atomicMax(&gcell[i], cell[i]);
 }
+SCAL_KERNEL(256, k_sc_bin)
 
 struct SCSlot {  // one keyframe's record: descriptor (column-major 20x60), ring key, sector key, column norms
     double* desc;
@@ -103,7 +104,7 @@ struct SCSlot {  // one keyframe's record: descriptor (column-major 20x60), ring
 };
 
 // writes the record to slot a and, when b.desc != null, to slot b as well (query staging + database slot in one pass)
-__global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell, SCSlot a, SCSlot b) {
+__device__ __forceinline__ void k_sc_finish_body(unsigned* __restrict__ gcell, const SCSlot& a, const SCSlot& b) {
     __shared__ double d[DESC];
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) {
         const unsigned c = gcell[i];
@@ -131,16 +132,18 @@ __global__ void __launch_bounds__(256) k_sc_finish(unsigned* __restrict__ gcell,
         if (b.desc) b.skey[c] = sk, b.cnorm[c] = cn;
     }
 }
+SCAL_KERNEL(256, k_sc_finish)
 
 // copies one record (saveScancontextAndKeys path: the staged descriptor becomes a database slot)
-__global__ void __launch_bounds__(256) k_sc_store(SCSlot from, SCSlot to) {
+__device__ __forceinline__ void k_sc_store_body(const SCSlot& from, const SCSlot& to) {
     for (int i = threadIdx.x; i < DESC; i += blockDim.x) to.desc[i] = from.desc[i];
     if (threadIdx.x < NR) to.rkey[threadIdx.x] = from.rkey[threadIdx.x];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + NS) to.skey[threadIdx.x - 64] = from.skey[threadIdx.x - 64], to.cnorm[threadIdx.x - 64] = from.cnorm[threadIdx.x - 64];
 }
+SCAL_KERNEL(256, k_sc_store)
 
 // keys / norms of a descriptor supplied by the caller (saveScancontextAndKeys, :236-246)
-__global__ void __launch_bounds__(128) k_sc_keys(const double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
+__device__ __forceinline__ void k_sc_keys_body(const double* __restrict__ desc, float* __restrict__ rkey, double* __restrict__ skey,
                                                  double* __restrict__ cnorm) {
     desc += static_cast<size_t>(blockIdx.x) * DESC, rkey += blockIdx.x * NR, skey += blockIdx.x * NS, cnorm += blockIdx.x * NS;  // one descriptor per block
     if (threadIdx.x < NR) {
@@ -152,12 +155,13 @@ __global__ void __launch_bounds__(128) k_sc_keys(const double* __restrict__ desc
         cnorm[c] = sqrt(eigen_sum4(NR, [&](int r) { return desc[r + NR * c] * desc[r + NR * c]; }));
     }
 }
+SCAL_KERNEL(128, k_sc_keys)
 
 // batch of descriptors (one per block): keys as in k_sc_keys, stored straight into the database slot slots[b] (< 0: not owned)
 struct SCSlotList {
     int slot[64];
 };
-__global__ void __launch_bounds__(128) k_sc_store_batch(const double* __restrict__ descs, SCSlotList sl, SCSlot db /* slot 0 */) {
+__device__ __forceinline__ void k_sc_store_batch_body(const double* __restrict__ descs, const SCSlotList& sl, SCSlot db /* slot 0 */) {
     const int s = sl.slot[blockIdx.x];
     if (s < 0) return;
     const double* desc = descs + static_cast<size_t>(blockIdx.x) * DESC;
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(128) k_sc_store_batch(const double* __restrict
         db.cnorm[static_cast<size_t>(s) * NS + c] = sqrt(eigen_sum4(NR, [&](int r) { return desc[r + NR * c] * desc[r + NR * c]; }));
     }
 }
+SCAL_KERNEL(128, k_sc_store_batch)
 
 // nanoflann L2_Adaptor<float>::evalMetric (nanoflann.hpp:383-408): five groups of four, f32
 __device__ __forceinline__ float key_dist(const float* __restrict__ a, const float* __restrict__ b) {
@@ -200,7 +205,7 @@ __device__ __forceinline__ void block_top3(unsigned long long mine, unsigned lon
 }
 
 // local slot s holds global keyframe index s * n_shards + shard
-__global__ void __launch_bounds__(256) k_sc_topk(const float* __restrict__ rkey, const float* __restrict__ query, int n_local, int n_shards,
+__device__ __forceinline__ void k_sc_topk_body(const float* __restrict__ rkey, const float* __restrict__ query, int n_local, int n_shards,
                                                  int shard, int global_limit, unsigned long long* __restrict__ block_best,
                                                  const int* __restrict__ limits = nullptr) {
     __shared__ unsigned long long smem[16];
@@ -227,6 +232,7 @@ __global__ void __launch_bounds__(256) k_sc_topk(const float* __restrict__ rkey,
         block_best[blockIdx.x * 3 + 2] = best[2];
     }
 }
+SCAL_KERNEL(256, k_sc_topk)
 
 // distanceBtnScanContext (:116-148) for one pair, executed by ONE wave.  scratch: 7*60 doubles of LDS per wave.
 __device__ __forceinline__ void wave_pair_distance(const double* __restrict__ d1, const double* __restrict__ n1, const double* __restrict__ v1,
@@ -318,7 +324,7 @@ struct SCDb {
 };
 
 // one block of 256 threads: merge per-block top-3, then waves 0..2 evaluate the three candidates (:385-400)
-__global__ void __launch_bounds__(256) k_sc_detect(const unsigned long long* __restrict__ block_best, int n_blocks, SCDb db, int n_shards,
+__device__ __forceinline__ void k_sc_detect_body(const unsigned long long* __restrict__ block_best, int n_blocks, const SCDb& db, int n_shards,
                                                    int shard, const double* __restrict__ qdesc, const double* __restrict__ qskey,
                                                    const double* __restrict__ qnorm, int fill_missing_with_zero, SCRec* __restrict__ out) {
     __shared__ unsigned long long smem[16];
@@ -375,8 +381,9 @@ __global__ void __launch_bounds__(256) k_sc_detect(const unsigned long long* __r
         if (lane_id() == 0) out[w] = r;
     }
 }
+SCAL_KERNEL(256, k_sc_detect)
 
-__global__ void __launch_bounds__(256) k_sc_pairs(SCDb db, const int* __restrict__ ia, const int* __restrict__ ib, int n_pairs,
+__device__ __forceinline__ void k_sc_pairs_body(const SCDb& db, const int* __restrict__ ia, const int* __restrict__ ib, int n_pairs,
                                                   double* __restrict__ dist, int* __restrict__ shift) {
     __shared__ double scratch[4][7 * NS];
     const int w = wave_id();
@@ -389,10 +396,11 @@ __global__ void __launch_bounds__(256) k_sc_pairs(SCDb db, const int* __restrict
                        db.cnorm + (size_t)b * NS, db.skey + (size_t)b * NS, scratch[w], &d, &s);
     if (lane_id() == 0) dist[p] = d, shift[p] = s;
 }
+SCAL_KERNEL(256, k_sc_pairs)
 
 // dense block of the pair grid, one wave per (query, database) pair.
 // mode 0: the reference's 7-shift search; mode 1: exhaustive over all 60 shifts (first strict minimum).
-__global__ void __launch_bounds__(256) k_sc_matrix(SCDb db, int q0, int nq, int d0, int nd, int mode, double* __restrict__ dist,
+__device__ __forceinline__ void k_sc_matrix_body(const SCDb& db, int q0, int nq, int d0, int nd, int mode, double* __restrict__ dist,
                                                    int* __restrict__ shift) {
     __shared__ double scratch[4][7 * NS];
     const int w = wave_id(), lane = lane_id();
@@ -437,6 +445,7 @@ __global__ void __launch_bounds__(256) k_sc_matrix(SCDb db, int q0, int nq, int 
     }
     if (lane == 0) dist[p] = bd, shift[p] = bs;
 }
+SCAL_KERNEL(256, k_sc_matrix)
 
 
 // ---- dense matrix on the matrix cores (mode 2) --------------------------------------------------------------------------------
@@ -742,7 +751,7 @@ extern "C" int scal_sc_create(const scal_sc_config* cfg, scal_sc_t** out) {
         }
     }
     // initialised on the context's own stream (the legacy null stream is not ordered against it)
-    if (rc == SCAL_OK && (hipMemsetAsync(c->gcell.p, 0, sizeof(unsigned) * DESC, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess))
+    if (rc == SCAL_OK && (op_memset_async(c->gcell.p, 0, sizeof(unsigned) * DESC, c->stream) != hipSuccess || op_stream_synchronize(c->stream) != hipSuccess))
         rc = SCAL_E_HIP;
     if (rc != SCAL_OK) {
         delete c;
@@ -756,11 +765,11 @@ extern "C" void scal_sc_destroy(scal_sc_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->fstream) {
-        (void)hipStreamSynchronize(c->fstream);
+        (void)op_stream_synchronize(c->fstream);
         release_stream(c->cfg.device, c->flane);
     }
     if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         release_stream(c->cfg.device, c->lane);
     }
     if (c->ev_ds) (void)hipEventDestroy(c->ev_ds);
@@ -786,7 +795,7 @@ static int commit_staged(scal_sc* c) {
             set_error("ScanContext database full (%d keyframes on this shard)", c->cap);
             return SCAL_E_CAPACITY;
         }
-        SCAL_LAUNCH_PROF("k_sc_store", k_sc_store, dim3(1), dim3(256), 0, s, c->staging(), c->slot(c->n_local));
+        SCAL_LAUNCH("k_sc_store", k_sc_store, dim3(1), dim3(256), 0, s, c->staging(), c->slot(c->n_local));
         SCAL_HIP(hipGetLastError());
         c->n_local++;
     }
@@ -808,8 +817,8 @@ static int make_into(scal_sc* c, const float* px, const float* py, const float* 
         db = c->slot(c->n_local);
     }
     const int nblk = std::max(1, std::min(64, div_up(n_host, 1024)));
-    SCAL_LAUNCH_PROF("k_sc_bin", k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
-    SCAL_LAUNCH_PROF("k_sc_finish", k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->staging(), db);
+    SCAL_LAUNCH("k_sc_bin", k_sc_bin, dim3(nblk), dim3(256), 0, s, px, py, pz, stride, d_n, n_host, c->cfg.max_radius, c->cfg.float_math, c->gcell.p);
+    SCAL_LAUNCH("k_sc_finish", k_sc_finish, dim3(1), dim3(256), 0, s, c->gcell.p, c->staging(), db);
     SCAL_HIP(hipGetLastError());
     if (store) c->n_local++;
     if (insert) c->n_global++;
@@ -821,7 +830,7 @@ static int upload_points(scal_sc* c, const float* xyzi, int n) {
         SCAL_TRY(c->pts.alloc((size_t)nc * 4));
         c->pts_cap = nc;
     }
-    if (n > 0) SCAL_HIP(hipMemcpyAsync(c->pts.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) SCAL_HIP(op_memcpy_async(c->pts.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
     return SCAL_OK;
 }
 
@@ -834,7 +843,7 @@ extern "C" int scal_sc_insert_cloud(scal_sc_t* c, const float* xyzi, int n) {
     SCAL_HIP(hipSetDevice(c->cfg.device));
     SCAL_TRY(upload_points(c, xyzi, n));
     SCAL_TRY(make_into(c, c->pts.p, nullptr, nullptr, 4, nullptr, n, true));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return SCAL_OK;
 }
 
@@ -857,8 +866,8 @@ extern "C" int scal_sc_make_descriptor(scal_sc_t* c, const float* xyzi, int n, d
     SCAL_HIP(hipSetDevice(c->cfg.device));
     SCAL_TRY(upload_points(c, xyzi, n));
     SCAL_TRY(make_into(c, c->pts.p, nullptr, nullptr, 4, nullptr, n, false));
-    SCAL_HIP(hipMemcpyAsync(desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_memcpy_async(desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return SCAL_OK;
 }
 
@@ -870,10 +879,10 @@ extern "C" int scal_sc_insert_descriptor(scal_sc_t* c, const double* desc) {
     std::lock_guard<std::mutex> lk(c->mu);
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
-    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_HIP(op_memcpy_async(c->qdesc.p, desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(commit_staged(c));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -895,15 +904,15 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
     }
     hipStream_t fs = c->fstream ? c->fstream : c->stream;
     SCAL_TRY(features_wait_done(feat, fs));  // start after stage A of this scan
-    if (fs != c->stream && c->tail_recorded) SCAL_HIP(hipStreamWaitEvent(fs, c->ev_tail, 0));  // the previous descriptor has been built from the buffers
+    if (fs != c->stream && c->tail_recorded) SCAL_HIP(op_stream_wait_event(fs, c->ev_tail, 0));  // the previous descriptor has been built from the buffers
     // downSizeFilterScancontext: leaf 0.4 m (laserPosegraphOptimization.cpp:890-891); tightly packed keys, up to 36 bits
     // the bounding box comes with the features context (per-block parts from k_curv): no reset / bounding-box launches here
     SCAL_TRY(c->vf.run(fs, CSoA4{v.x, v.y, v.z, v.i}, &v.P->n_kept, v.cap, 0.4f, 36, SoA4{c->dsx.p, c->dsy.p, c->dsz.p, c->dsw.p}, c->d_nds.p,
                        nullptr, v.box_parts, v.n_box_parts));
     if (v.stream != fs) SCAL_TRY(features_note_reader(feat, fs));  // the filter was the last reader of feat's buffers
     if (fs != c->stream) {
-        SCAL_HIP(hipEventRecord(c->ev_ds, fs));
-        SCAL_HIP(hipStreamWaitEvent(c->stream, c->ev_ds, 0));
+        SCAL_HIP(op_event_record(c->ev_ds, fs));
+        SCAL_HIP(op_stream_wait_event(c->stream, c->ev_ds, 0));
     }
     *d_n = c->d_nds.p;
     *n_cap = v.cap;
@@ -913,7 +922,7 @@ static int ds_features(scal_sc* c, scal_features_t* feat, const int** d_n, int* 
 // the descriptor has been built from the filter's output buffers: the next filter may overwrite them
 static int ds_consumed(scal_sc* c) {
     if (c->fstream && c->fstream != c->stream) {
-        SCAL_HIP(hipEventRecord(c->ev_tail, c->stream));
+        SCAL_HIP(op_event_record(c->ev_tail, c->stream));
         c->tail_recorded = true;
     }
     return SCAL_OK;
@@ -945,9 +954,9 @@ static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bo
     SCAL_TRY(ds_features(c, feat, &d_n, &cap));
     SCAL_TRY(make_into(c, c->dsx.p, c->dsy.p, c->dsz.p, 1, d_n, cap, false));
     SCAL_TRY(ds_consumed(c));
-    SCAL_HIP(hipMemcpyAsync(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
+    SCAL_HIP(op_memcpy_async(d_desc, c->qdesc.p, sizeof(double) * DESC, hipMemcpyDeviceToDevice, c->stream));
     if (wait) {
-        SCAL_HIP(hipStreamSynchronize(c->stream));
+        SCAL_HIP(op_stream_synchronize(c->stream));
     } else {
         if (c->made_tail - c->made_head >= 4) {
             set_error("scal_sc_make_features_enqueue: four descriptors are queued and none has been waited for");
@@ -955,7 +964,7 @@ static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bo
         }
         hipEvent_t& ev = c->made_ev[c->made_tail % 4];
         if (!ev) SCAL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        SCAL_HIP(hipEventRecord(ev, c->stream));
+        SCAL_HIP(op_event_record(ev, c->stream));
         c->made_tail++;
     }
     return SCAL_OK;
@@ -969,7 +978,7 @@ extern "C" int scal_sc_wait_descriptor(scal_sc_t* c) {
         return SCAL_E_STATE;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipEventSynchronize(c->made_ev[c->made_head % 4]));
+    SCAL_HIP(op_event_synchronize(c->made_ev[c->made_head % 4]));
     c->made_head++;
     return SCAL_OK;
 }
@@ -984,10 +993,10 @@ extern "C" int scal_sc_insert_descriptor_device(scal_sc_t* c, const double* d_de
     std::lock_guard<std::mutex> lk(c->mu);
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_desc, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_HIP(op_memcpy_async(c->qdesc.p, d_desc, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+    SCAL_LAUNCH("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(commit_staged(c));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -1001,15 +1010,15 @@ extern "C" int scal_sc_shard_query_device(scal_sc_t* c, const double* d_queries,
     hipStream_t s = c->stream;
     const int nb = std::max(1, div_up(c->n_local, 256));
     for (int q = 0; q < nq; ++q) {
-        SCAL_HIP(hipMemcpyAsync(c->qdesc.p, d_queries + (size_t)q * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
-        SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
-        SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard,
+        SCAL_HIP(op_memcpy_async(c->qdesc.p, d_queries + (size_t)q * DESC, sizeof(double) * DESC, hipMemcpyDeviceToDevice, s));
+        SCAL_LAUNCH("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+        SCAL_LAUNCH("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, c->qrkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard,
                            global_size_at_rebuild - 30, c->block_best.p, static_cast<const int*>(nullptr));
-        SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
+        SCAL_LAUNCH("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, c->qdesc.p, c->qskey.p,
                            c->qnorm.p, 1, reinterpret_cast<SCRec*>(d_out) + 3 * (size_t)q);
     }
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -1033,7 +1042,7 @@ extern "C" int scal_sc_insert_descriptors_device(scal_sc_t* c, const double* d_d
             }
             sl.slot[r] = n_local++;
         }
-    if (n > 0) SCAL_LAUNCH_PROF("k_sc_store_batch", k_sc_store_batch, dim3(n), dim3(128), 0, c->stream, d_descs, sl, c->slot(0));
+    if (n > 0) SCAL_LAUNCH("k_sc_store_batch", k_sc_store_batch, dim3(n), dim3(128), 0, c->stream, d_descs, sl, c->slot(0));
     SCAL_HIP(hipGetLastError());
     c->n_local = n_local;
     c->n_global += n;
@@ -1052,7 +1061,7 @@ extern "C" int scal_sc_shard_query_batch_device(scal_sc_t* c, const double* d_qu
     hipStream_t s = c->stream;
     const int nb = std::max(1, div_up(c->n_local, 256));
     if (c->bq_cap < nq || c->bq_nb < nb) {
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_stream_synchronize(s));
         const int cq = std::max(nq, 8), cb = std::max(nb, c->bq_nb);
         SCAL_TRY(c->bq_rkey.alloc((size_t)cq * NR));
         SCAL_TRY(c->bq_skey.alloc((size_t)cq * NS));
@@ -1063,12 +1072,12 @@ extern "C" int scal_sc_shard_query_batch_device(scal_sc_t* c, const double* d_qu
         c->bq_cap = cq, c->bq_nb = cb;
     }
     for (int q = 0; q < nq; ++q) c->bq_hlimits.p[q] = limits[q] - 30;  // NUM_EXCLUDE_RECENT
-    SCAL_HIP(hipMemcpyAsync(c->bq_limits.p, c->bq_hlimits.p, sizeof(int) * nq, hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->bq_limits.p, c->bq_hlimits.p, sizeof(int) * nq, hipMemcpyHostToDevice, s));
     if (nq > 0) {
-        SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(nq), dim3(128), 0, s, d_queries, c->bq_rkey.p, c->bq_skey.p, c->bq_norm.p);
-        SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb, nq), dim3(256), 0, s, c->rkey.p, c->bq_rkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, 0,
+        SCAL_LAUNCH("k_sc_keys", k_sc_keys, dim3(nq), dim3(128), 0, s, d_queries, c->bq_rkey.p, c->bq_skey.p, c->bq_norm.p);
+        SCAL_LAUNCH("k_sc_topk", k_sc_topk, dim3(nb, nq), dim3(256), 0, s, c->rkey.p, c->bq_rkey.p, c->n_local, c->cfg.n_shards, c->cfg.shard, 0,
                            c->bq_best.p, c->bq_limits.p);
-        SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1, nq), dim3(256), 0, s, c->bq_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, d_queries, c->bq_skey.p,
+        SCAL_LAUNCH("k_sc_detect", k_sc_detect, dim3(1, nq), dim3(256), 0, s, c->bq_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, d_queries, c->bq_skey.p,
                            c->bq_norm.p, 1, reinterpret_cast<SCRec*>(d_out));
     }
     SCAL_HIP(hipGetLastError());
@@ -1079,7 +1088,7 @@ extern "C" int scal_sc_sync(scal_sc_t* c) {
     if (!c) return SCAL_E_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return SCAL_OK;
 }
 
@@ -1092,9 +1101,9 @@ extern "C" int scal_sc_get_descriptor(scal_sc_t* c, int idx, double* desc, float
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
     const size_t sl = idx / c->cfg.n_shards;
-    if (desc) SCAL_HIP(hipMemcpyAsync(desc, c->desc.p + sl * DESC, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
-    if (ringkey20) SCAL_HIP(hipMemcpyAsync(ringkey20, c->rkey.p + sl * NR, sizeof(float) * NR, hipMemcpyDeviceToHost, c->stream));
-    SCAL_HIP(hipStreamSynchronize(c->stream));
+    if (desc) SCAL_HIP(op_memcpy_async(desc, c->desc.p + sl * DESC, sizeof(double) * DESC, hipMemcpyDeviceToHost, c->stream));
+    if (ringkey20) SCAL_HIP(op_memcpy_async(ringkey20, c->rkey.p + sl * NR, sizeof(float) * NR, hipMemcpyDeviceToHost, c->stream));
+    SCAL_HIP(op_stream_synchronize(c->stream));
     return SCAL_OK;
 }
 
@@ -1104,14 +1113,14 @@ static int search_local(scal_sc* c, int limit, bool fill_zero, SCSlot q, bool wa
     SCRec* d_rec = c->d_rec.p + 4 * slot;
     SCRec* h_rec = c->h_rec.p + 4 * slot;
     const int nb = std::max(1, div_up(c->n_local, 256));
-    SCAL_LAUNCH_PROF("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
+    SCAL_LAUNCH("k_sc_topk", k_sc_topk, dim3(nb), dim3(256), 0, s, c->rkey.p, q.rkey, c->n_local, c->cfg.n_shards, c->cfg.shard, limit,
                        c->block_best.p, static_cast<const int*>(nullptr));
-    SCAL_LAUNCH_PROF("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
+    SCAL_LAUNCH("k_sc_detect", k_sc_detect, dim3(1), dim3(256), 0, s, c->block_best.p, nb, c->db(), c->cfg.n_shards, c->cfg.shard, q.desc, q.skey,
                        q.cnorm, fill_zero ? 1 : 0, wait ? d_rec : h_rec);  // queued searches write their records straight to pinned host memory
     SCAL_HIP(hipGetLastError());
     if (wait) {
-        SCAL_HIP(hipMemcpyAsync(h_rec, d_rec, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(h_rec, d_rec, sizeof(SCRec) * 3, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     return SCAL_OK;
 }
@@ -1164,7 +1173,7 @@ static int detect_enqueue(scal_sc* c) {
     c->tree_making_period_conter++;
     // query = newest keyframe (:340-341), read in place from its database slot
     SCAL_TRY(search_local(c, c->size_at_rebuild - NUM_EXCLUDE_RECENT, true, c->slot(c->n_global - 1), false, slot));
-    SCAL_HIP(hipEventRecord(c->det_ev[slot], c->stream));
+    SCAL_HIP(op_event_record(c->det_ev[slot], c->stream));
     c->det_mode[slot] = 1;
     c->det_count++;
     return SCAL_OK;
@@ -1183,7 +1192,7 @@ static int detect_collect(scal_sc* c, scal_sc_result* res) {
     c->det_count--;
     if (mode == 2) return SCAL_OK;
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(hipEventSynchronize(c->det_ev[slot]));
+    SCAL_HIP(op_event_synchronize(c->det_ev[slot]));
     finish_result(c->h_rec.p + 4 * slot, 3, c->cfg.dist_thres, res);
     return SCAL_OK;
 }
@@ -1225,8 +1234,8 @@ extern "C" int scal_sc_shard_query(scal_sc_t* c, const double* query_desc, int g
     std::lock_guard<std::mutex> lk(c->mu);
     SCAL_HIP(hipSetDevice(c->cfg.device));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->qdesc.p, query_desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
-    SCAL_LAUNCH_PROF("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
+    SCAL_HIP(op_memcpy_async(c->qdesc.p, query_desc, sizeof(double) * DESC, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH("k_sc_keys", k_sc_keys, dim3(1), dim3(128), 0, s, c->qdesc.p, c->qrkey.p, c->qskey.p, c->qnorm.p);
     SCAL_TRY(search_local(c, global_size_at_rebuild - 30, true, c->staging()));
     static_assert(sizeof(SCRec) == sizeof(scal_sc_cand), "record layout");
     std::memcpy(out, c->h_rec.p, sizeof(SCRec) * 3);
@@ -1259,7 +1268,7 @@ namespace scal {
 // than the query by more than `exclude` keyframes (NUM_EXCLUDE_RECENT, Scancontext.h:92): d0 + j < q0 + row - exclude.
 // One workgroup per row; k rounds of a block-wide argmin over (distance, index) keys that must exceed the previous pick:
 // deterministic, ties go to the lower index.  Entries with NaN distance (no overlapping sector at any shift) never win.
-__global__ void __launch_bounds__(256) k_sc_row_topk(const double* __restrict__ dist, const int* __restrict__ shift, int nq, int nd, int q0, int d0,
+__device__ __forceinline__ void k_sc_row_topk_body(const double* __restrict__ dist, const int* __restrict__ shift, int nq, int nd, int q0, int d0,
                                                      int exclude, int k, int* __restrict__ out_idx, double* __restrict__ out_dist,
                                                      int* __restrict__ out_shift) {
     __shared__ unsigned long long s_d[4];
@@ -1306,6 +1315,7 @@ __global__ void __launch_bounds__(256) k_sc_row_topk(const double* __restrict__ 
         last_d = bd, last_j = bj, first = false;
     }
 }
+SCAL_KERNEL(256, k_sc_row_topk)
 }  // namespace scal
 
 static int ensure_pairs(scal_sc* c, size_t n) {
@@ -1337,14 +1347,14 @@ extern "C" int scal_sc_distance_pairs(scal_sc_t* c, const int* idx_a, const int*
     SCAL_HIP(hipSetDevice(c->cfg.device));
     SCAL_TRY(ensure_pairs(c, n_pairs));
     hipStream_t s = c->stream;
-    SCAL_HIP(hipMemcpyAsync(c->d_pairs.p, idx_a, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
-    SCAL_HIP(hipMemcpyAsync(c->d_pairs.p + n_pairs, idx_b, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
-    SCAL_LAUNCH_PROF("k_sc_pairs", k_sc_pairs, dim3(div_up(n_pairs, 4)), dim3(256), 0, s, c->db(), c->d_pairs.p, c->d_pairs.p + n_pairs, n_pairs, c->d_dist.p,
+    SCAL_HIP(op_memcpy_async(c->d_pairs.p, idx_a, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_pairs.p + n_pairs, idx_b, sizeof(int) * n_pairs, hipMemcpyHostToDevice, s));
+    SCAL_LAUNCH("k_sc_pairs", k_sc_pairs, dim3(div_up(n_pairs, 4)), dim3(256), 0, s, c->db(), c->d_pairs.p, c->d_pairs.p + n_pairs, n_pairs, c->d_dist.p,
                        c->d_shift.p);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * n_pairs, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(shift, c->d_shift.p, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(dist, c->d_dist.p, sizeof(double) * n_pairs, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_memcpy_async(shift, c->d_shift.p, sizeof(int) * n_pairs, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -1379,7 +1389,7 @@ static int enqueue_matrix(scal_sc* c, int q0, int q1, int d0, int d1, int mode, 
     const int nq = q1 - q0, nd = d1 - d0;
     const size_t np = static_cast<size_t>(nq) * nd;
     if (mode < 2) {
-        SCAL_LAUNCH_PROF("k_sc_matrix", k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, nq, d0, nd, mode,
+        SCAL_LAUNCH("k_sc_matrix", k_sc_matrix, dim3(static_cast<unsigned>((np + 3) / 4)), dim3(256), 0, s, c->db(), q0, nq, d0, nd, mode,
                          d_dist, d_shift);
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
@@ -1409,9 +1419,9 @@ extern "C" int scal_sc_distance_matrix(scal_sc_t* c, int q0, int q1, int d0, int
     SCAL_TRY(ensure_pairs(c, np));
     hipStream_t s = c->stream;
     SCAL_TRY(enqueue_matrix(c, q0, q1, d0, d1, mode, c->d_dist.p, c->d_shift.p, s));
-    SCAL_HIP(hipMemcpyAsync(dist, c->d_dist.p, sizeof(double) * np, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipMemcpyAsync(shift, c->d_shift.p, sizeof(int) * np, hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(dist, c->d_dist.p, sizeof(double) * np, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_memcpy_async(shift, c->d_shift.p, sizeof(int) * np, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     return SCAL_OK;
 }
 
@@ -1455,14 +1465,14 @@ extern "C" int scal_sc_batch_loop_search(scal_sc_t* c, int q0, int q1, int exclu
         const int t1 = std::min(q1, t0 + TILE_Q), nq = t1 - t0;
         const int nd = std::max(0, t1 - 1 - exclude_recent);  // columns any query of this tile can use
         if (nd > 0) SCAL_TRY(enqueue_matrix(c, t0, t1, 0, nd, mode, c->d_dist.p, c->d_shift.p, s));
-        SCAL_LAUNCH_PROF("k_sc_row_topk", k_sc_row_topk, dim3(nq), dim3(256), 0, s, c->d_dist.p, c->d_shift.p, nq, nd, t0, 0, exclude_recent, k, o_idx.p,
+        SCAL_LAUNCH("k_sc_row_topk", k_sc_row_topk, dim3(nq), dim3(256), 0, s, c->d_dist.p, c->d_shift.p, nq, nd, t0, 0, exclude_recent, k, o_idx.p,
                          o_dist.p, o_shift.p);
         SCAL_HIP(hipGetLastError());
         const size_t off = static_cast<size_t>(t0 - q0) * k;
-        SCAL_HIP(hipMemcpyAsync(idx + off, o_idx.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipMemcpyAsync(dist + off, o_dist.p, sizeof(double) * nq * k, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipMemcpyAsync(shift + off, o_shift.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(idx + off, o_idx.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_memcpy_async(dist + off, o_dist.p, sizeof(double) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_memcpy_async(shift + off, o_shift.p, sizeof(int) * nq * k, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     return SCAL_OK;
 }

@@ -15,7 +15,7 @@ namespace scal {
 
 // bounding box as per-block parts (order-preserving uint images: min xyz, max xyz); k_vox_keys reduces them.  No atomics: 768
 // atomic min/max on six words of one cache line cost more than the rest of this kernel.
-__global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restrict__ d_n, unsigned* __restrict__ parts) {
+__device__ __forceinline__ void k_vox_bbox_body(const CSoA4& in, const int* __restrict__ d_n, unsigned* __restrict__ parts) {
     __shared__ unsigned s_lo[3][4], s_hi[3][4];
     const int n = *d_n;
     unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(256) k_vox_bbox(CSoA4 in, const int* __restric
         parts[blockIdx.x * 6 + 3 + a] = max(max(s_hi[a][0], s_hi[a][1]), max(s_hi[a][2], s_hi[a][3]));
     }
 }
+SCAL_KERNEL(256, k_vox_bbox)
 
 __device__ __forceinline__ int bits_for(int cells) {  // smallest b with (1 << b) >= cells, at least 1
     int b = 1;
@@ -48,7 +49,7 @@ __device__ __forceinline__ int bits_for(int cells) {  // smallest b with (1 << b
     return b;
 }
 
-__global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restrict__ d_n, float inv, int max_bits, VoxMeta* m,
+__device__ __forceinline__ void k_vox_keys_body(const CSoA4& in, const int* __restrict__ d_n, float inv, int max_bits, VoxMeta* m,
                                                   unsigned long long* __restrict__ keys, int* __restrict__ vals, const unsigned* __restrict__ ext_parts, int n_parts) {
     const int n = *d_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,8 +115,9 @@ __global__ void __launch_bounds__(256) k_vox_keys(CSoA4 in, const int* __restric
     keys[i] = k;
     vals[i] = i;
 }
+SCAL_KERNEL(256, k_vox_keys)
 
-__global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
+__device__ __forceinline__ void k_vox_heads_body(const SortedPairs& sp, const int* __restrict__ d_n, int* __restrict__ blockcnt) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (static_cast<int>(blockIdx.x) >= nb) return;
@@ -127,6 +129,7 @@ __global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __
     block_exclusive_scan(head, s, &total);
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = total;
 }
+SCAL_KERNEL(256, k_vox_heads)
 
 // One thread per voxel (run head) sums its members in sorted = arrival order, as CentroidPoint<PointXYZI> does in f32.  The
 // additions of a run are inherently serial, the loads need not be: the block stages its 256 sorted positions plus a
@@ -134,8 +137,8 @@ __global__ void __launch_bounds__(256) k_vox_heads(SortedPairs sp, const int* __
 // run longer than the look-ahead finishes from global memory.
 // The block's output offset is the sum of the earlier blocks' head counts (k_vox_heads), summed here instead of in a scan
 // launch of its own; the last block publishes the total, runs the optional epilogue and leaves the bounding box reset.
-__global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* __restrict__ d_n, const int* __restrict__ blockcnt, CSoA4 in, SoA4 out,
-                                                    int* __restrict__ d_n_out, VoxMeta* m, VoxTail tail) {
+__device__ __forceinline__ void k_vox_reduce_body(const SortedPairs& sp, const int* __restrict__ d_n, const int* __restrict__ blockcnt, const CSoA4& in, const SoA4& out,
+                                                    int* __restrict__ d_n_out, VoxMeta* m, const VoxTail& tail) {
     const int n = *d_n;
     const int nb = (n + 255) / 256;
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -196,6 +199,7 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
     const int o = block_off + rank;
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
+SCAL_KERNEL(256, k_vox_reduce)
 
 // Filter for a cloud of <= VOX_SMALL points in TWO launches (the general path takes ~12): the corner clouds of stage C.
 //   k_vox_small_sort    one workgroup per 512-chunk of the cloud (<= 16).  Every workgroup computes the bounding box and ALL keys
@@ -207,8 +211,8 @@ __global__ void __launch_bounds__(256) k_vox_reduce(SortedPairs sp, const int* _
 //                       the output offset of a workgroup = run heads in front of it, counted from the sorted keys directly.
 // Round 2 did all of this in ONE workgroup (58 us: an LDS bitonic sort of 8192 keys by 1024 threads is 30 us of it).
 constexpr int VOX_SMALL = 8192;
-__global__ void __launch_bounds__(1024) k_vox_small_sort(CSoA4 in, const int* __restrict__ d_n, int n_cap, float inv, unsigned long long* __restrict__ sorted,
-                                                         VoxMeta* m, VoxTail tail) {
+__device__ __forceinline__ void k_vox_small_sort_body(const CSoA4& in, const int* __restrict__ d_n, int n_cap, float inv, unsigned long long* __restrict__ sorted,
+                                                         VoxMeta* m, const VoxTail& tail) {
     extern __shared__ __align__(16) unsigned long long skeys[];
     __shared__ unsigned s_lo[3][16], s_hi[3][16];
     __shared__ int s_mb[4];
@@ -302,9 +306,10 @@ __global__ void __launch_bounds__(1024) k_vox_small_sort(CSoA4 in, const int* __
     rank += __shfl_xor(rank, 1, 64);
     if (half == 0 && key != ~0ull) sorted[rank] = key;
 }
+SCAL_KERNEL(1024, k_vox_small_sort)
 
-__global__ void __launch_bounds__(256) k_vox_small_reduce(const unsigned long long* __restrict__ sorted, const int* __restrict__ d_n, int n_cap, CSoA4 in,
-                                                          SoA4 out, int* __restrict__ d_n_out, VoxTail tail) {
+__device__ __forceinline__ void k_vox_small_reduce_body(const unsigned long long* __restrict__ sorted, const int* __restrict__ d_n, int n_cap, const CSoA4& in,
+                                                          const SoA4& out, int* __restrict__ d_n_out, const VoxTail& tail) {
     const int n = min(*d_n, n_cap);
     const int nb = (n + 255) / 256;
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -365,6 +370,7 @@ __global__ void __launch_bounds__(256) k_vox_small_reduce(const unsigned long lo
     const int o = block_off + rank;
     out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
 }
+SCAL_KERNEL(256, k_vox_small_reduce)
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_voxel)
 
 int VoxelFilter::init(int capacity) {
@@ -389,8 +395,8 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
         const int lds = sizeof(unsigned long long) * VOX_SMALL;  // attribute set per device in VoxelFilter::init
         const int n_cap = min(VOX_SMALL, cap);
         const int chunks = max(1, div_up(min(n_bound, n_cap), 512));  // workgroups beyond the cloud's chunks leave at once
-        SCAL_LAUNCH_PROF(n_small.c_str(), k_vox_small_sort, dim3(chunks), dim3(1024), lds, s, in, d_n, n_cap, inv, keys.p, meta.p, tl);
-        SCAL_LAUNCH_PROF(n_small_reduce.c_str(), k_vox_small_reduce, dim3(max(1, div_up(min(n_bound, n_cap), 256))), dim3(256), 0, s, keys.p, d_n, n_cap, in, out,
+        SCAL_LAUNCH(n_small.c_str(), k_vox_small_sort, dim3(chunks), dim3(1024), lds, s, in, d_n, n_cap, inv, keys.p, meta.p, tl);
+        SCAL_LAUNCH(n_small_reduce.c_str(), k_vox_small_reduce, dim3(max(1, div_up(min(n_bound, n_cap), 256))), dim3(256), 0, s, keys.p, d_n, n_cap, in, out,
                          d_n_out, tl);
         SCAL_HIP(hipGetLastError());
         return SCAL_OK;
@@ -399,34 +405,36 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
     if (!ext_parts) {
         n_parts = min(nb, 128);
         ext_parts = box_parts.p;
-        SCAL_LAUNCH_PROF(n_bbox.c_str(), k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
+        SCAL_LAUNCH(n_bbox.c_str(), k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
     }
-    SCAL_LAUNCH_PROF(n_keys.c_str(), k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
+    SCAL_LAUNCH(n_keys.c_str(), k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
-    SCAL_LAUNCH_PROF(n_heads.c_str(), k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
-    SCAL_LAUNCH_PROF(n_reduce.c_str(), k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
+    SCAL_LAUNCH(n_heads.c_str(), k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
+    SCAL_LAUNCH(n_reduce.c_str(), k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
 
-__global__ void k_deinterleave(const float* __restrict__ aos, int n, SoA4 o) {
+__device__ __forceinline__ void k_deinterleave_body(const float* __restrict__ aos, int n, const SoA4& o) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const float4 p = reinterpret_cast<const float4*>(aos)[i];
         o.x[i] = p.x, o.y[i] = p.y, o.z[i] = p.z, o.w[i] = p.w;
     }
 }
-__global__ void k_interleave4(const int* __restrict__ d_n, CSoA4 in, float* __restrict__ aos) {
+SCAL_KERNEL(1024, k_deinterleave)
+__device__ __forceinline__ void k_interleave4_body(const int* __restrict__ d_n, const CSoA4& in, float* __restrict__ aos) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < *d_n) reinterpret_cast<float4*>(aos)[i] = make_float4(in.x[i], in.y[i], in.z[i], in.w[i]);
 }
+SCAL_KERNEL(1024, k_interleave4)
 
 void launch_deinterleave(hipStream_t s, const float* aos, int n, SoA4 o) {
-    if (n > 0) SCAL_LAUNCH_PROF("k_deinterleave", k_deinterleave, dim3(div_up(n, 256)), dim3(256), 0, s, aos, n, o);
+    if (n > 0) SCAL_LAUNCH("k_deinterleave", k_deinterleave, dim3(div_up(n, 256)), dim3(256), 0, s, aos, n, o);
 }
 void launch_interleave(hipStream_t s, const int* d_n, int n_cap, CSoA4 in, float* aos) {
-    if (n_cap > 0) SCAL_LAUNCH_PROF("k_interleave4", k_interleave4, dim3(div_up(n_cap, 256)), dim3(256), 0, s, d_n, in, aos);
+    if (n_cap > 0) SCAL_LAUNCH("k_interleave4", k_interleave4, dim3(div_up(n_cap, 256)), dim3(256), 0, s, d_n, in, aos);
 }
 
 }  // namespace scal
@@ -473,7 +481,7 @@ extern "C" void scal_voxel_destroy(scal_voxel_t* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) {
-        (void)hipStreamSynchronize(c->stream);
+        (void)op_stream_synchronize(c->stream);
         release_stream(c->device);
     }
     delete c;
@@ -496,26 +504,26 @@ static int voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float lea
     hipStream_t s = c->stream;
     const float* d_in = xyzi;
     if (!on_device) {
-        SCAL_HIP(hipMemcpyAsync(c->aos.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+        SCAL_HIP(op_memcpy_async(c->aos.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
         d_in = c->aos.p;
     }
-    SCAL_HIP(hipMemcpyAsync(c->d_n.p, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    SCAL_HIP(op_memcpy_async(c->d_n.p, &n, sizeof(int), hipMemcpyHostToDevice, s));
     SoA4 in{c->ix.p, c->iy.p, c->iz.p, c->iw.p}, o{c->ox.p, c->oy.p, c->oz.p, c->ow.p};
     launch_deinterleave(s, d_in, n, in);
     SCAL_TRY(c->vf.run(s, CSoA4{in.x, in.y, in.z, in.w}, c->d_n.p, n, leaf, 45, o, c->d_n.p + 1));
     launch_interleave(s, c->d_n.p + 1, n, CSoA4{o.x, o.y, o.z, o.w}, on_device ? out_xyzi : c->aos.p);
     VoxMeta hm;
-    SCAL_HIP(hipMemcpyAsync(&hm, c->vf.meta.p, sizeof hm, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_memcpy_async(&hm, c->vf.meta.p, sizeof hm, hipMemcpyDeviceToHost, s));
     int m = 0;
-    SCAL_HIP(hipMemcpyAsync(&m, c->d_n.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-    SCAL_HIP(hipStreamSynchronize(s));
+    SCAL_HIP(op_memcpy_async(&m, c->d_n.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
     if (hm.error) {
         set_error("voxel grid bounding box needs more than 45 key bits (or 16383 cells per axis on the small-cloud path)");
         return SCAL_E_CAPACITY;
     }
     if (!on_device) {
-        SCAL_HIP(hipMemcpyAsync(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
-        SCAL_HIP(hipStreamSynchronize(s));
+        SCAL_HIP(op_memcpy_async(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_stream_synchronize(s));
     }
     *n_out = m;
     return SCAL_OK;

@@ -118,6 +118,7 @@ EXPORTED_SYMBOLS = [
     "scal_factors_eval",
     "scal_pipeline_create", "scal_pipeline_destroy", "scal_pipeline_push_device", "scal_pipeline_push_host", "scal_pipeline_pop", "scal_pipeline_drain",
     "scal_pipeline_in_flight", "scal_pipeline_sc", "scal_pipeline_map", "scal_pipeline_odom", "scal_pipeline_features",
+    "scal_pipeline_create_multi", "scal_pipeline_seqs", "scal_pipeline_push_device_multi", "scal_pipeline_pop_multi", "scal_pipeline_sc_of", "scal_pipeline_map_of",
 ]
 
 _lib = None
@@ -248,6 +249,13 @@ def lib():
         getattr(L, fn).argtypes = [vp]
     L.scal_pipeline_features.restype = C.c_void_p
     L.scal_pipeline_features.argtypes = [vp, C.c_int]
+    L.scal_pipeline_create_multi.argtypes = [C.POINTER(PipelineConfig), C.c_int, C.POINTER(vp)]
+    L.scal_pipeline_seqs.argtypes = [vp]
+    L.scal_pipeline_push_device_multi.argtypes = [vp, C.POINTER(C.c_void_p), _i32p, C.c_int]
+    L.scal_pipeline_pop_multi.argtypes = [vp, C.POINTER(PipelineResult)]
+    for fn in ("scal_pipeline_sc_of", "scal_pipeline_map_of"):
+        getattr(L, fn).restype = C.c_void_p
+        getattr(L, fn).argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -851,13 +859,16 @@ class Pipeline:
     ScanContext part) working on consecutive scans at the same time, scheduled inside the library.  push() a scan, pop() poses in order."""
 
     def __init__(self, lidar_type, minimum_range, max_points=400000, line_res=0.4, plane_res=0.8, max_map_points=4000000, sc_mode=SC_EVERY_SCAN,
-                 sc_max_radius=80.0, sc_dist_thres=0.2, sc_max_keyframes=8192, device=0, ring=0, depth=0, float_math=0, check_finite=1, d_desc_ring=None):
+                 sc_max_radius=80.0, sc_dist_thres=0.2, sc_max_keyframes=8192, device=0, ring=0, depth=0, float_math=0, check_finite=1, d_desc_ring=None,
+                 n_seqs=1):
         self.cfg = PipelineConfig(lidar_type, SCAN_LINES.get(lidar_type, 0), float(minimum_range), max_points, float_math, check_finite, line_res,
                                   plane_res, max_map_points, sc_max_radius, sc_dist_thres, sc_max_keyframes, sc_mode, device, ring, depth, d_desc_ring)
         self.h = C.c_void_p()
-        _check(lib().scal_pipeline_create(C.byref(self.cfg), C.byref(self.h)))
-        self.sc = _borrow(SCManager, lib().scal_pipeline_sc(self.h)) if sc_mode != SC_OFF else None
-        self.map = _borrow(LaserMapping, lib().scal_pipeline_map(self.h))
+        self.n_seqs = n_seqs
+        _check(lib().scal_pipeline_create_multi(C.byref(self.cfg), n_seqs, C.byref(self.h)))
+        self.scs = [_borrow(SCManager, lib().scal_pipeline_sc_of(self.h, q)) if sc_mode != SC_OFF else None for q in range(n_seqs)]
+        self.maps = [_borrow(LaserMapping, lib().scal_pipeline_map_of(self.h, q)) for q in range(n_seqs)]
+        self.sc, self.map = self.scs[0], self.maps[0]
         self.odom = _borrow(LaserOdometry, lib().scal_pipeline_odom(self.h))
 
     def close(self):
@@ -874,11 +885,27 @@ class Pipeline:
         a = _f32(xyz)
         _check(lib().scal_pipeline_push_host(self.h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.strides[0]))
 
+    @staticmethod
+    def _res(r):
+        return dict(seq=r.seq, q=np.array(r.q_w_curr[:]), t=np.array(r.t_w_curr[:]), q_odom=np.array(r.q_odom[:]), t_odom=np.array(r.t_odom[:]),
+                    odom=r.odom, map=r.map, loop=SCManager._result(r.loop) if r.have_loop else None, d_descriptor=r.d_descriptor)
+
     def pop(self):
         r = PipelineResult()
         _check(lib().scal_pipeline_pop(self.h, C.byref(r)))
-        return dict(seq=r.seq, q=np.array(r.q_w_curr[:]), t=np.array(r.t_w_curr[:]), q_odom=np.array(r.q_odom[:]), t_odom=np.array(r.t_odom[:]),
-                    odom=r.odom, map=r.map, loop=SCManager._result(r.loop) if r.have_loop else None, d_descriptor=r.d_descriptor)
+        return self._res(r)
+
+    def push_device_multi(self, d_ptrs, ns, stride_floats=3):
+        """one scan of EVERY sequence (device pointers, point counts)"""
+        pa = (C.c_void_p * self.n_seqs)(*[C.c_void_p(int(v)) for v in d_ptrs])
+        na = (C.c_int * self.n_seqs)(*[int(v) for v in ns])
+        _check(lib().scal_pipeline_push_device_multi(self.h, pa, na, stride_floats))
+
+    def pop_multi(self):
+        """the sequences' results of the oldest scan step not yet popped: a list of n_seqs dicts"""
+        ra = (PipelineResult * self.n_seqs)()
+        _check(lib().scal_pipeline_pop_multi(self.h, ra))
+        return [self._res(ra[q]) for q in range(self.n_seqs)]
 
     def drain(self):
         _check(lib().scal_pipeline_drain(self.h))

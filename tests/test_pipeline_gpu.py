@@ -128,3 +128,61 @@ def test_cpp_replay_host_matches_python_path(S, hdl64_stream, tmp_path, mode):
         want = np.concatenate([ref[k]["q"], ref[k]["t"]])
         assert np.array_equal(got, want), (mode, k, np.abs(got - want).max())
         assert int(rows[k, 8]) == ref[k]["loop"]["loop_id"], (mode, k)
+
+
+@pytest.mark.parametrize("n_seqs", [2, 4])
+def test_multi_sequence_batched_launches_equal_solo_runs(S, worlds, n_seqs):
+    """scal_pipeline_create_multi: S independent sequences (different seeded worlds) stepping together, their kernels sharing launches
+    (every hot-path kernel takes up to four argument sets, blockIdx.z selects one; the per-stage calls are recorded per sequence and
+    zipped, csrc/batch.hpp).  Every sequence must get, bit for bit, the poses, odometry poses, block counts, loop answers and map it
+    gets when it runs alone."""
+    import torch
+    n = 12
+    seqs = [[worlds(S.HDL64, 205 + 1000 * q).scan(k) for k in range(n)] for q in range(n_seqs)]
+    cap = max(s.shape[0] for sq in seqs for s in sq) + 1024
+    descs = _descs(40)
+    solo, solo_maps = [], []
+    for q in range(n_seqs):
+        p = S.Pipeline(S.HDL64, 5.0, max_points=cap, max_map_points=3000000, sc_mode=S.SC_EVERY_SCAN, sc_dist_thres=0.4, sc_max_keyframes=len(descs) + n + 8)
+        for d in descs:
+            p.sc.saveScancontextAndKeys(d)
+        got = []
+        for k in range(n):
+            p.push(seqs[q][k])
+            while p.in_flight() > 3:
+                got.append(p.pop())
+        p.drain()
+        while p.in_flight():
+            got.append(p.pop())
+        solo.append(got)
+        solo_maps.append([_sorted_rows(p.map.export(w)) for w in (0, 1)])
+        p.close()
+    d_scans = [[torch.from_numpy(s).cuda() for s in sq] for sq in seqs]
+    torch.cuda.synchronize()
+    m = S.Pipeline(S.HDL64, 5.0, max_points=cap, max_map_points=3000000, sc_mode=S.SC_EVERY_SCAN, sc_dist_thres=0.4, sc_max_keyframes=len(descs) + n + 8,
+                   n_seqs=n_seqs)
+    for q in range(n_seqs):
+        for d in descs:
+            m.scs[q].saveScancontextAndKeys(d)
+    got = []
+    for k in range(n):
+        m.push_device_multi([d_scans[q][k].data_ptr() for q in range(n_seqs)], [seqs[q][k].shape[0] for q in range(n_seqs)])
+        while m.in_flight() > 3:
+            got.append(m.pop_multi())
+    m.drain()
+    while m.in_flight():
+        got.append(m.pop_multi())
+    assert len(got) == n
+    for k in range(n):
+        for q in range(n_seqs):
+            g, r = got[k][q], solo[q][k]
+            assert np.array_equal(g["q_odom"], r["q_odom"]) and np.array_equal(g["t_odom"], r["t_odom"]), (k, q)
+            assert np.array_equal(g["q"], r["q"]) and np.array_equal(g["t"], r["t"]), (k, q, np.abs(g["t"] - r["t"]).max())
+            assert list(g["map"].n_edge) == list(r["map"].n_edge) and list(g["map"].n_plane) == list(r["map"].n_plane), (k, q)
+            for key in ("loop_id", "nn_idx", "nn_shift"):
+                assert g["loop"][key] == r["loop"][key], (k, q, key)
+            assert g["loop"]["min_dist"] == r["loop"]["min_dist"] or (np.isnan(g["loop"]["min_dist"]) and np.isnan(r["loop"]["min_dist"])), (k, q)
+    for q in range(n_seqs):
+        for w in (0, 1):
+            assert np.array_equal(_sorted_rows(m.maps[q].export(w)), solo_maps[q][w]), (q, w)
+    m.close()

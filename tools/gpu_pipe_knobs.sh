@@ -1,4 +1,4 @@
-# C++ host, pipeline mode, 260 scans resident: development knobs of csrc/pipeline.cpp
+# C++ host, pipeline mode, 260 scans resident: development knobs
 mkdir -p gpurun_out
 python3 - <<'PY'
 import sys, os
@@ -10,10 +10,6 @@ formats.write_scan_stream('/tmp/s260.bin', [w.scan(k) for k in range(260)])
 PY
 run() { a=$1; shift; env "$@" ./sc-a-loam_amd/bin/replay_main --scans /tmp/s260.bin --mode pipeline --resident 1 --warmup 30 --sc-db 5000 --ahead $a 2> gpurun_out/knob.err | python3 -c "
 import json,sys; r=json.loads(sys.stdin.read()); print('ahead $a $*:', round(r['scans_per_s'],1), 'scans/s', r['latency_ms'])"; }
-for a in 3 4 6; do run $a X=1; run $a X=1; done
-run 4 GPU_MAX_HW_QUEUES=8
-run 4 GPU_MAX_HW_QUEUES=8
-run 4 SCALOAM_PIPE_PF_AHEAD=2
-run 4 SCALOAM_PIPE_PF_AHEAD=2 SCALOAM_PIPE_B_AHEAD=1
-run 4 SCALOAM_PIPE_SC_LANE=1
-run 4 SCALOAM_PIPE_TIMING=1; grep scal_pipeline gpurun_out/knob.err
+run 4 X=1; run 4 X=1
+run 4 HIP_FORCE_DEV_KERNARG=1; run 4 HIP_FORCE_DEV_KERNARG=1
+run 4 HIP_FORCE_DEV_KERNARG=0; run 4 HIP_FORCE_DEV_KERNARG=0
