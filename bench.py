@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--prof-steps", type=int, default=24, help="extra, untimed steps with per-kernel timestamps on every launch (kernel_ms_per_step)")
     ap.add_argument("--timeline-kernels", default="", help="with --timeline: only these kernels (comma separated), over the whole timed region")
     ap.add_argument("--timeline", default="", help="development aid: write (kernel, start ms, stop ms) of every dispatch of six timed steps to this CSV")
+    ap.add_argument("--seqs", type=int, default=4, help="N=1: after the single-sequence measurement, this many independent sequences are run through ONE "
+                    "pipeline whose kernels share launches (scal_pipeline_create_multi); reported as `batched`, never as `value` (0/1 = skip)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real runs; gloo only to rehearse N>1 on fewer GPUs")
     return ap.parse_args()
 
@@ -244,6 +246,90 @@ def lm_account(lm, which, st_):
         if which == "map":
             lm["map_blocks"] += ne + npl
             lm["map_evals"] += 1 + it
+
+
+def run_batched(a, S, n_seqs, single_rate, device, threads):
+    """SURVEY.md section 8d "batched / streamed numbers (several independent scans or sequences in flight)": n_seqs independent
+    sequences - different seeded worlds, own map / poses / ScanContext database each - step together through ONE pipeline whose
+    kernels share launches (blockIdx.z = sequence, csrc/batch.hpp).  Same K-step timed region, same per-step work as the headline
+    run for every sequence; scans/s counts the scans of all sequences.  Poses are bit-identical to solo runs
+    (tests/test_pipeline_gpu.py::test_multi_sequence_batched_launches_equal_solo_runs)."""
+    import torch
+    import scansynth
+    K, W = a.steps, a.warmup
+    R = max(1, min(a.reps, 3), min(int(math.ceil(0.1 / (K * 0.1e-3 * n_seqs))), max(1, 400 // K)))
+    PS = 12 if a.prof_every > 0 else 0  # extra, untimed steps with every launch timed (kernel table of the batched launches)
+    total = W + K * R + PS
+    gens = [scansynth.World(scansynth.HDL64, a.seed + 7919 * (q + 1), threads=threads) for q in range(n_seqs)]
+    scans = [[g.scan(k) for k in range(total)] for g in gens]
+    npts = [[s.shape[0] for s in sq] for sq in scans]
+    d_scans = [[torch.from_numpy(s).cuda(device) for s in sq] for sq in scans]
+    cap = min(400000, max(max(n) for n in npts) + 1024)
+    P = S.Pipeline(S.HDL64, 5.0, max_points=cap, line_res=0.4, plane_res=0.8, max_map_points=4000000, sc_mode=S.SC_EVERY_SCAN, sc_max_radius=80.0,
+                   sc_dist_thres=0.4, sc_max_keyframes=a.sc_db + total + 64, device=device, ring=a.ring, depth=a.depth, n_seqs=n_seqs)
+    fill = synth_descs(np.random.default_rng(4242), a.sc_db)
+    for q in range(n_seqs):
+        for d in fill:
+            P.scs[q].saveScancontextAndKeys(d.T)
+    lm = dict(map=0.0, map_launches=0, odom=0.0, odom_launches=0, map_blocks=0, map_evals=0)
+    poses = {}
+
+    def region(k0, n, prof):
+        in_flight = 0
+        for k in range(k0, k0 + n):
+            if prof:
+                S.prof_enable((k - W) % max(1, a.prof_every) == 0, "k_lm_solve_map,k_lm_solve_odom")
+            P.push_device_multi([d_scans[q][k].data_ptr() for q in range(n_seqs)], [npts[q][k] for q in range(n_seqs)])
+            in_flight += 1
+            while in_flight > a.ahead:
+                take(P.pop_multi())
+                in_flight -= 1
+        P.drain()
+        while in_flight:
+            take(P.pop_multi())
+            in_flight -= 1
+
+    def take(results):
+        for q, r in enumerate(results):
+            lm_account(lm, "map", r["map"])
+            lm_account(lm, "odom", r["odom"])
+            poses[q] = r["t"].tolist()
+
+    region(0, W, False)
+    for key in list(lm):
+        lm[key] = 0
+    S.prof_reset()
+    torch.cuda.synchronize()
+    rep_dt = []
+    for rep in range(R):
+        t0 = time.perf_counter()
+        region(W + rep * K, K, a.prof_every > 0)
+        torch.cuda.synchronize()
+        rep_dt.append(time.perf_counter() - t0)
+    S.prof_enable(False)
+    prof = S.prof_read_all()
+    table = None
+    if PS:
+        S.prof_reset()
+        S.prof_enable(True)
+        region(W + R * K, PS, False)
+        torch.cuda.synchronize()
+        S.prof_enable(False)
+        table = {k: v[0] / PS for k, v in sorted(S.prof_read_all().items())}
+    P.close()
+    dt = float(np.median(rep_dt))
+    rate = n_seqs * K / dt
+    out = {"seqs": n_seqs, "scans_per_s": rate, "ms_per_step_all_seqs": dt / K * 1e3, "ms_per_scan": dt / K / n_seqs * 1e3,
+           "speedup_vs_single_sequence": rate / single_rate if single_rate else None, "repetitions": R,
+           "rep_ms_per_step": [x / K * 1e3 for x in rep_dt], "final_map_t": poses, "kernel_ms_per_step_all_seqs": table,
+           "note": "independent sequences through ONE pipeline, their kernels sharing launches (gridDim.z = sequences); not the metric's value"}
+    if "k_lm_solve_map" in prof and prof["k_lm_solve_map"][1] and lm["map_launches"]:
+        ms, cnt = prof["k_lm_solve_map"]
+        per_launch = lm["map"] / lm["map_launches"] * n_seqs  # a batched launch carries one solve of every sequence
+        gbs = per_launch / (ms / cnt * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_lm_solve (stage C), batched launch", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "avg_launch_us": ms / cnt * 1e3, "timed_launches": cnt, "algorithmic_bytes_per_launch": per_launch}
+    return out
 
 
 def main():
@@ -575,6 +661,12 @@ def main():
         cpu = cpp = None
         if world == 1 and a.cpu_sample > 0:
             cpu = cpu_baseline(scans[: min(total, a.cpu_sample)], a.sc_db)
+        batched = None
+        if world == 1 and a.seqs > 1 and pipelined:
+            if P is not None:
+                P.close()
+                P = None
+            batched = run_batched(a, S, min(a.seqs, 4), value, local, threads)
         as_integrated = None
         if world == 1 and a.cpp_sample > 0:
             from scaloam import formats
@@ -602,7 +694,7 @@ def main():
                 "value": world * K / dt_h2d, "unit": "scans/s", "ms_per_step": dt_h2d / K * 1e3,
                 "note": "one more repetition of the K steps with every scan starting in pageable host memory: copy into pinned staging + "
                         "asynchronous upload on stage A's stream inside the timed region (scal_pipeline_push_host); not the metric's value"},
-            "as_integrated": as_integrated,
+            "as_integrated": as_integrated, "batched": batched,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 points / f64 pose algebra",
             "data": "synthetic",
             "config": {"workload": "KITTI-like HDL-64 (64 beams x 1900 az, seeded procedural world, ~95k pts after the reference's ring filter) "

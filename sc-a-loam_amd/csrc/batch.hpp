@@ -21,7 +21,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstring>
-#include <functional>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -75,23 +74,53 @@ struct KernelTraits<void(A...)> {
 // ---- recorder -----------------------------------------------------------------------------------------------------------------
 using BatchLaunchFn = hipError_t (*)(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs);
 
-struct RecOp {
+constexpr int PACK_BYTES_MAX = 1024;  // largest argument set (k_merge_write: ~620 B)
+struct RecOp {  // plain data: recording an operation allocates nothing
+    enum Kind { LAUNCH, EVENT_RECORD, STREAM_WAIT, MEMCPY, MEMSET } kind = LAUNCH;
     // launch
     BatchLaunchFn fn = nullptr;
-    std::string name;
+    const char* name = nullptr;  // a literal or a member string of the launching context: outlives the list
     dim3 grid, block;
-    int lds = 0;
+    int lds = 0, pack_size = 0;
     hipStream_t stream = nullptr;
-    std::vector<unsigned char> pack;
-    // anything else, replayed per sequence
-    std::function<hipError_t()> other;
+    // the others, replayed per sequence
+    hipEvent_t ev = nullptr;
+    unsigned flags = 0;
+    void* dst = nullptr;
+    const void* src = nullptr;
+    size_t bytes = 0;
+    int value = 0;
+    hipMemcpyKind copy_kind = hipMemcpyDefault;
+    alignas(16) unsigned char pack[PACK_BYTES_MAX];
+    hipError_t replay() const {
+        switch (kind) {
+            case EVENT_RECORD: return hipEventRecord(ev, stream);
+            case STREAM_WAIT: return hipStreamWaitEvent(stream, ev, flags);
+            case MEMCPY: return hipMemcpyAsync(dst, src, bytes, copy_kind, stream);
+            case MEMSET: return hipMemsetAsync(dst, value, bytes, stream);
+            default: return hipSuccess;
+        }
+    }
 };
 
 struct Recorder {
     std::vector<RecOp> ops;
     bool broken = false;  // this sequence had to flush in the middle of its list: it runs unbatched for the rest of the step
     hipError_t flush();   // launches / replays everything recorded so far, in order, as batches of one
+    bool will_record(hipEvent_t ev) const {
+        for (const RecOp& o : ops)
+            if (o.kind == RecOp::EVENT_RECORD && o.ev == ev) return true;
+        return false;
+    }
+    RecOp& add(RecOp::Kind k) {
+        if (ops.capacity() == 0) ops.reserve(64);
+        ops.emplace_back();
+        ops.back().kind = k;
+        return ops.back();
+    }
 };
+extern long g_forced_flushes;  // flushes in the middle of a recorded list (development statistic)
+void note_forced_flush(const char* file, int line);
 
 extern thread_local Recorder* g_recorder;
 
@@ -104,59 +133,64 @@ bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEven
 // ---- stream operations that may be recorded -------------------------------------------------------------------------------------
 inline hipError_t op_event_record(hipEvent_t ev, hipStream_t s) {
     if (Recorder* r = g_recorder) {
-        RecOp o;
-        o.other = [ev, s] { return hipEventRecord(ev, s); };
-        r->ops.push_back(std::move(o));
+        RecOp& o = r->add(RecOp::EVENT_RECORD);
+        o.ev = ev, o.stream = s;
         return hipSuccess;
     }
     return hipEventRecord(ev, s);
 }
 inline hipError_t op_stream_wait_event(hipStream_t s, hipEvent_t ev, unsigned flags) {
     if (Recorder* r = g_recorder) {
-        RecOp o;
-        o.other = [ev, s, flags] { return hipStreamWaitEvent(s, ev, flags); };
-        r->ops.push_back(std::move(o));
+        RecOp& o = r->add(RecOp::STREAM_WAIT);
+        o.ev = ev, o.stream = s, o.flags = flags;
         return hipSuccess;
     }
     return hipStreamWaitEvent(s, ev, flags);
 }
 inline hipError_t op_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
     if (Recorder* r = g_recorder) {
-        RecOp o;
-        o.other = [dst, src, bytes, kind, s] { return hipMemcpyAsync(dst, src, bytes, kind, s); };
-        r->ops.push_back(std::move(o));
+        RecOp& o = r->add(RecOp::MEMCPY);
+        o.dst = dst, o.src = src, o.bytes = bytes, o.copy_kind = kind, o.stream = s;
         return hipSuccess;
     }
     return hipMemcpyAsync(dst, src, bytes, kind, s);
 }
 inline hipError_t op_memset_async(void* dst, int value, size_t bytes, hipStream_t s) {
     if (Recorder* r = g_recorder) {
-        RecOp o;
-        o.other = [dst, value, bytes, s] { return hipMemsetAsync(dst, value, bytes, s); };
-        r->ops.push_back(std::move(o));
+        RecOp& o = r->add(RecOp::MEMSET);
+        o.dst = dst, o.value = value, o.bytes = bytes, o.stream = s;
         return hipSuccess;
     }
     return hipMemsetAsync(dst, value, bytes, s);
 }
-// operations that wait for (or look at) the device: whatever this thread recorded so far has to be on the device first
-inline hipError_t op_flush_for_wait() {
+// Operations that wait for (or look at) the device.  An event whose record is still sitting in this thread's list has to reach
+// the device first (the list is flushed and the sequence runs unbatched for the rest of the step); an event recorded by an
+// earlier, already launched step can be waited for or queried as it is - the entry points poll such events all the time.
+inline hipError_t op_flush_for_wait(const char* file, int line) {
     if (Recorder* r = g_recorder) {
         r->broken = true;
+        note_forced_flush(file, line);
         return r->flush();
     }
     return hipSuccess;
 }
-inline hipError_t op_event_synchronize(hipEvent_t ev) {
-    hipError_t e = op_flush_for_wait();
-    return e != hipSuccess ? e : hipEventSynchronize(ev);
+inline hipError_t op_event_synchronize(hipEvent_t ev, const char* file = __builtin_FILE(), int line = __builtin_LINE()) {
+    if (g_recorder && g_recorder->will_record(ev)) {
+        const hipError_t e = op_flush_for_wait(file, line);
+        if (e != hipSuccess) return e;
+    }
+    return hipEventSynchronize(ev);
 }
-inline hipError_t op_stream_synchronize(hipStream_t s) {
-    hipError_t e = op_flush_for_wait();
+inline hipError_t op_stream_synchronize(hipStream_t s, const char* file = __builtin_FILE(), int line = __builtin_LINE()) {
+    hipError_t e = op_flush_for_wait(file, line);
     return e != hipSuccess ? e : hipStreamSynchronize(s);
 }
-inline hipError_t op_event_query(hipEvent_t ev) {
-    hipError_t e = op_flush_for_wait();
-    return e != hipSuccess ? e : hipEventQuery(ev);
+inline hipError_t op_event_query(hipEvent_t ev, const char* file = __builtin_FILE(), int line = __builtin_LINE()) {
+    if (g_recorder && g_recorder->will_record(ev)) {
+        const hipError_t e = op_flush_for_wait(file, line);
+        if (e != hipSuccess) return e;
+    }
+    return hipEventQuery(ev);
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------------------------
@@ -201,12 +235,11 @@ inline hipError_t batch_launch_impl(K kernel, const char* name, dim3 grid, dim3 
 template <class Traits, class... U>
 inline void launch_or_record(BatchLaunchFn fn, const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, U&&... u) {
     const typename Traits::pack p = Traits::make(std::forward<U>(u)...);
+    static_assert(sizeof(p) <= PACK_BYTES_MAX, "argument set larger than a recorded operation holds");
     if (Recorder* r = g_recorder) {
-        RecOp o;
-        o.fn = fn, o.name = name, o.grid = grid, o.block = block, o.lds = lds, o.stream = s;
-        o.pack.resize(sizeof(p));
-        std::memcpy(o.pack.data(), static_cast<const void*>(&p), sizeof(p));
-        r->ops.push_back(std::move(o));
+        RecOp& o = r->add(RecOp::LAUNCH);
+        o.fn = fn, o.name = name, o.grid = grid, o.block = block, o.lds = lds, o.stream = s, o.pack_size = static_cast<int>(sizeof(p));
+        std::memcpy(o.pack, static_cast<const void*>(&p), sizeof(p));
         return;
     }
     const void* one = &p;

@@ -7,11 +7,29 @@ namespace scal {
 
 // ---------------------------------------------------------------------------------------------- in-launch batching (batch.hpp)
 thread_local Recorder* g_recorder = nullptr;
+long g_forced_flushes = 0;
+static std::mutex g_flush_mu;
+static std::vector<std::pair<std::string, long>> g_flush_sites;
+void note_forced_flush(const char* file, int line) {
+    std::lock_guard<std::mutex> lk(g_flush_mu);
+    ++g_forced_flushes;
+    const std::string key = std::string(file) + ":" + std::to_string(line);
+    for (auto& s : g_flush_sites)
+        if (s.first == key) {
+            ++s.second;
+            return;
+        }
+    g_flush_sites.push_back({key, 1});
+}
+void print_forced_flushes() {
+    std::lock_guard<std::mutex> lk(g_flush_mu);
+    for (auto& s : g_flush_sites) std::fprintf(stderr, "[scal_pipeline] forced flush at %s x %ld\n", s.first.c_str(), s.second);
+}
 
 static hipError_t run_op(const RecOp& o) {
-    if (!o.fn) return o.other();
-    const void* one = o.pack.data();
-    return o.fn(o.name.c_str(), o.grid, o.block, o.lds, o.stream, 1, &one);
+    if (o.kind != RecOp::LAUNCH) return o.replay();
+    const void* one = o.pack;
+    return o.fn(o.name, o.grid, o.block, o.lds, o.stream, 1, &one);
 }
 
 hipError_t Recorder::flush() {
@@ -35,10 +53,10 @@ hipError_t zip_and_launch(Recorder* const* recs, int n) {
     // lists with the same structure (same kernels and shapes at the same positions) are merged; a list that differs - a sequence
     // that took another path through its entry point, or had to flush on the way - is replayed on its own
     auto same = [](const RecOp& a, const RecOp& b) {
-        if ((a.fn == nullptr) != (b.fn == nullptr)) return false;
-        if (!a.fn) return true;
+        if (a.kind != b.kind) return false;
+        if (a.kind != RecOp::LAUNCH) return true;
         return a.fn == b.fn && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.block.x == b.block.x && a.lds == b.lds && a.stream == b.stream &&
-               a.pack.size() == b.pack.size();
+               a.pack_size == b.pack_size;
     };
     std::vector<bool> done(n, false);
     for (int i = 0; i < n; ++i) {
@@ -55,12 +73,12 @@ hipError_t zip_and_launch(Recorder* const* recs, int n) {
             }
         for (size_t k = 0; k < lead->ops.size(); ++k) {
             const RecOp& o = lead->ops[k];
-            if (o.fn) {
+            if (o.kind == RecOp::LAUNCH) {
                 const void* packs[BATCH_MAX];
-                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->ops[k].pack.data();
-                note(o.fn(o.name.c_str(), o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
+                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->ops[k].pack;
+                note(o.fn(o.name, o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
             } else {
-                for (Recorder* r : group) note(r->ops[k].other());
+                for (Recorder* r : group) note(r->ops[k].replay());
             }
         }
         for (Recorder* r : group) r->ops.clear(), r->broken = false;

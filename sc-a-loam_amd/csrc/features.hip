@@ -872,7 +872,10 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     k.lidar_type = g.lidar_type, k.n_scans = g.n_scans, k.float_math = g.float_math, k.check_finite = g.check_finite;
     const float thres = static_cast<float>(g.minimum_range);
     k.thres2 = thres * thres;
-    const int nb = max(1, div_up(n, TILE));
+    // Launch shapes follow the point count rounded up to 8192 (blocks beyond the cloud find nothing to do), so that scans of similar
+    // size - the sequences of a multi-sequence pipeline - get identical shapes and can share launches (batch.hpp).
+    const int nq = min(c->cap, div_up(max(n, 1), 8192) * 8192);
+    const int nb = min(c->nb_cap, max(1, div_up(nq, TILE)));
     FeatParams* P = c->d_P.p;
     std::unique_lock<std::mutex> ev_lk(c->ev_mu);
     for (int i = 0; i < scal_features::MAX_READERS; ++i)
@@ -888,7 +891,7 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
     SCAL_LAUNCH("k_ringscan", k_ringscan, dim3(1), dim3(1024), 0, s, c->d_hist.p, nb, g.n_scans, P);
     SCAL_LAUNCH("k_scatter", k_scatter, dim3(nb), dim3(256), 0, s, d_xyz, n, stride, P, c->d_ring.p, c->d_ori.p, c->d_hist.p, nb, c->ox.p, c->oy.p,
                        c->oz.p, c->oi.p, c->d_src.p);
-    const int nb256 = max(1, div_up(n, 256));
+    const int nb256 = max(1, div_up(nq, 256));
     SCAL_LAUNCH("k_curv", k_curv, dim3(nb256), dim3(256), 0, s, P, c->ox.p, c->oy.p, c->oz.p, c->d_curv.p, c->d_label.p, c->d_gap.p, c->d_boxparts.p);
     c->n_box_parts = nb256;
     const int lds = sizeof(unsigned long long) * RING_MAX + RING_MAX + 16;

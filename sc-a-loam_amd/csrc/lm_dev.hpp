@@ -768,9 +768,25 @@ template <class Pre, class Post>
 static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(Batch<typename LMSolveKernel<Pre, Post>::traits::pack> b) {
     batch_call<typename LMSolveKernel<Pre, Post>::tag>(b.p[blockIdx.z], std::make_index_sequence<LMSolveKernel<Pre, Post>::traits::n>());
 }
+// the same code compiled for TWO workgroups per CU (256 instead of 426 registers per lane, the rest spilled): 512 resident workgroups
+// on the device, so that the solves of more than LM_SEQS_PER_LAUNCH sequences can share a launch.  Same arithmetic, same results.
+template <class Pre, class Post>
+static __global__ void __launch_bounds__(LM_THREADS, 2) k_lm_solve_slim(Batch<typename LMSolveKernel<Pre, Post>::traits::pack> b) {
+    batch_call<typename LMSolveKernel<Pre, Post>::tag>(b.p[blockIdx.z], std::make_index_sequence<LMSolveKernel<Pre, Post>::traits::n>());
+}
+// The solve keeps its <= LM_GRID workgroups per sequence spinning on each other's partial sums, and at 426 registers per lane only
+// ONE of its workgroups fits a CU: 256 resident workgroups on the whole device.  Stage B's and stage C's solves run on different
+// streams and may overlap, so the full-register kernel carries at most LM_SEQS_PER_LAUNCH = 256 / (2 x 48) = 2 sequences per launch;
+// a batch of more goes to the two-workgroups-per-CU build of the same code (512 resident workgroups: 2 x 4 x 48 fit).
+// (Tried first: all solves ordered behind each other across the two streams with an event chain - it welds stage B's and stage C's
+// chains into one, 5,500 scans/s for four sequences; two launches of two sequences each - 5,700.)
+constexpr int LM_SEQS_PER_LAUNCH = 256 / (2 * LM_GRID);
+static_assert(LM_SEQS_PER_LAUNCH >= 1 && 2 * BATCH_MAX * LM_GRID <= 512, "LM_GRID too large for two overlapping solves");
 template <class Pre, class Post>
 static hipError_t k_lm_solve_launch(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) {
-    return batch_launch_impl<typename LMSolveKernel<Pre, Post>::traits::pack>(k_lm_solve<Pre, Post>, name, grid, block, lds, s, n, packs);
+    using P = typename LMSolveKernel<Pre, Post>::traits::pack;
+    if (n <= LM_SEQS_PER_LAUNCH) return batch_launch_impl<P>(k_lm_solve<Pre, Post>, name, grid, block, lds, s, n, packs);
+    return batch_launch_impl<P>(k_lm_solve_slim<Pre, Post>, name, grid, block, lds, s, n, packs);
 }
 
 // Results for the host in ONE launch: the state (and a counters struct) are written straight into pinned, device-visible host
@@ -804,7 +820,8 @@ inline int lm_check_residency(int device) {
     int per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SCAL_E_HIP;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_lm_solve_slim<Pre, Post>), hipFuncAttributeMaxDynamicSharedMemorySize, LM_LDS_BYTES) != hipSuccess)
         return SCAL_E_HIP;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_lm_solve<Pre, Post>), LM_THREADS, LM_LDS_BYTES) != hipSuccess)
         return SCAL_E_HIP;
@@ -825,6 +842,7 @@ inline void launch_lm_solve(hipStream_t s, FactorSoA f, const int* d_nslots, LMS
     g = g < 1 ? 1 : (g > LM_GRID ? LM_GRID : g);
     launch_or_record<typename LMSolveKernel<Pre, Post>::traits>(k_lm_solve_launch<Pre, Post>, prof_name, dim3(g), dim3(LM_THREADS), LM_LDS_BYTES, s, f, d_nslots, st,
                                                                  outer, d_enable, partials, sync, d_abort, pre, post);
+
 }
 
 }  // namespace scal

@@ -717,8 +717,10 @@ SCAL_KERNEL(256, k_map_reduce)
 // Anything unusual - old keys not strictly increasing inside a valid cube (a centroid rounded across a voxel face, a cube
 // that collected unfiltered points while it was outside the 5x5x3 window), an old point outside the window, too many new
 // points - raises MapCounters::merge_fail: k_merge_write then stops the chain and the host redoes the insertion with the full sort.
-constexpr int MERGE_MAX = 8192;
-constexpr int MERGE_IDX_BITS = 13;
+// 16384 new points per class and scan: the HDL-64 surf stacks of config #2 hold 6.5-8.5 k points depending on the world (seed 205 stays
+// just below 8192, other seeds do not - with the round-2 limit of 8192 every step of such a sequence fell back to the full sort).
+constexpr int MERGE_MAX = 16384;
+constexpr int MERGE_IDX_BITS = 14;
 constexpr int MERGE_SAMPLES = 4096;  // old keys staged in LDS for the two-level lookup
 
 struct MergeNew {            // per class, MERGE_MAX entries
@@ -804,8 +806,7 @@ __device__ __forceinline__ void k_merge_keys_body(const MergeArgs& a, const LMSt
     block_exclusive_scan(mine, s_scan, &n_eff);  // also the barrier after the fill
     if (tile == 0 && threadIdx.x == 0) C->merge_neff[cls] = n_eff;
     if (nc == 0) return;
-    const int w = wave_id();
-    if (w < nc) {
+    for (int w = wave_id(); w < nc; w += 16) {  // 16 waves, up to MERGE_CHUNKS chunks
         unsigned long long v[8];
         chunk_load(sk, w, v);
         wave_sort512(v);
@@ -1872,6 +1873,17 @@ int recover(scal_map* c) {
     }
     if (origin == c->steps.size()) return SCAL_OK;  // nothing stopped
     MapStep& e = c->steps[origin];
+    {
+        static const bool trace = std::getenv("SCALOAM_PIPE_TIMING") != nullptr;
+        static int shown = 0;
+        if (trace && shown < 12) {
+            const MapResult& R = c->res.p[e.slot];
+            std::fprintf(stderr, "[scal_map] chain stopped: S1.abort %d S2.abort %d termination %d merge_fail %d neff %d/%d n_map %d/%d stack %d/%d window_same %d\n",
+                         R.S1.abort, R.S2.abort, R.st.termination, R.C2.merge_fail, R.C2.merge_neff[0], R.C2.merge_neff[1], R.S2.n_map[0], R.S2.n_map[1],
+                         R.C2.n_corner_stack, R.C2.n_surf_stack, R.S2.window_same);
+            ++shown;
+        }
+    }
     c->cur = e.par;
     bool dropped = false;
     if (at_pose) {

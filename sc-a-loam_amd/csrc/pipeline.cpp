@@ -16,6 +16,9 @@
 #include <string>
 #include <thread>
 
+namespace scal {
+void print_forced_flushes();
+}
 using namespace scal;
 
 namespace {
@@ -426,7 +429,11 @@ extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
     if (p->t_front.joinable()) p->t_front.join();
     if (p->t_pose.joinable()) p->t_pose.join();
     if (p->t_loop.joinable()) p->t_loop.join();
-    if (TIMING) p->tm_front.print("front"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
+    if (TIMING) {
+        p->tm_front.print("front"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
+        std::fprintf(stderr, "[scal_pipeline] sequences %d, recorded lists flushed in the middle of an entry point: %ld\n", p->S, g_forced_flushes);
+        print_forced_flushes();
+    }
     (void)hipSetDevice(p->cfg.device);
     // consumers first: their destructors wait for the streams that still read the features contexts
     for (int q = 0; q < SMAX; ++q) {
