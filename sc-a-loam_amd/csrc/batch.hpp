@@ -76,7 +76,7 @@ using BatchLaunchFn = hipError_t (*)(const char* name, dim3 grid, dim3 block, in
 
 constexpr int PACK_BYTES_MAX = 1024;  // largest argument set (k_merge_write: ~620 B)
 struct RecOp {  // plain data: recording an operation allocates nothing
-    enum Kind { LAUNCH, EVENT_RECORD, STREAM_WAIT, MEMCPY, MEMSET } kind = LAUNCH;
+    enum Kind { LAUNCH, EVENT_RECORD, STREAM_WAIT, MEMCPY, MEMSET, MARK_BEGIN, MARK_END } kind = LAUNCH;
     // launch
     BatchLaunchFn fn = nullptr;
     const char* name = nullptr;  // a literal or a member string of the launching context: outlives the list
@@ -127,6 +127,16 @@ extern thread_local Recorder* g_recorder;
 // launches the lists of n recorders (all recorded on this thread for the same per-stage entry point of n sequences): same-shaped
 // launches of the same kernel are merged, the rest is replayed in order.  Clears the lists.  Returns the first HIP error.
 hipError_t zip_and_launch(Recorder* const* recs, int n);
+// The same for lists of DIFFERENT entry points that each contain one marked segment of the same kind of work (a voxel filter run:
+// stage C's surf stack filter and ScanContext's keyframe filter both sort and reduce a cloud with the same kernels).  Every list is
+// cut into (before, segment, after); all the befores are launched (merged where their structure matches), then all the segments
+// merged with each other, then the afters.  The lists must be independent of each other up to stream order - different contexts
+// working on the same scan - and the segments must run on one stream.
+hipError_t zip_marked_and_launch(Recorder* const* recs, int n);
+// brackets a segment of the current thread's recorder (no effect when nothing is being recorded)
+inline void rec_mark(bool begin) {
+    if (Recorder* r = g_recorder) r->add(begin ? RecOp::MARK_BEGIN : RecOp::MARK_END);
+}
 
 bool prof_begin(const char* name, hipStream_t stream, hipEvent_t* start, hipEvent_t* stop);  // common.cpp
 

@@ -45,44 +45,94 @@ hipError_t Recorder::flush() {
     return first;
 }
 
-hipError_t zip_and_launch(Recorder* const* recs, int n) {
-    Recorder* keep = g_recorder;
-    g_recorder = nullptr;
+namespace {
+struct Span {
+    Recorder* r;
+    size_t b, e;
+};
+bool same_op(const RecOp& a, const RecOp& b) {
+    if (a.kind != b.kind) return false;
+    if (a.kind != RecOp::LAUNCH) return true;
+    return a.fn == b.fn && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.block.x == b.block.x && a.lds == b.lds && a.stream == b.stream &&
+           a.pack_size == b.pack_size;
+}
+// Spans with the same structure (same kernels and shapes at the same positions) are merged; a span that differs - a sequence that
+// took another path through its entry point, or had to flush on the way - is replayed on its own.
+hipError_t zip_spans(const std::vector<Span>& spans) {
     hipError_t first = hipSuccess;
     auto note = [&](hipError_t e) { if (first == hipSuccess) first = e; };
-    // lists with the same structure (same kernels and shapes at the same positions) are merged; a list that differs - a sequence
-    // that took another path through its entry point, or had to flush on the way - is replayed on its own
-    auto same = [](const RecOp& a, const RecOp& b) {
-        if (a.kind != b.kind) return false;
-        if (a.kind != RecOp::LAUNCH) return true;
-        return a.fn == b.fn && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.block.x == b.block.x && a.lds == b.lds && a.stream == b.stream &&
-               a.pack_size == b.pack_size;
-    };
+    const int n = static_cast<int>(spans.size());
     std::vector<bool> done(n, false);
     for (int i = 0; i < n; ++i) {
         if (done[i]) continue;
-        Recorder* lead = recs[i];
-        std::vector<Recorder*> group{lead};
+        const Span& lead = spans[i];
+        const size_t len = lead.e - lead.b;
+        std::vector<const Span*> group{&lead};
         done[i] = true;
-        if (!lead->broken)
+        if (!lead.r->broken)
             for (int j = i + 1; j < n && static_cast<int>(group.size()) < BATCH_MAX; ++j) {
-                if (done[j] || recs[j]->broken || recs[j]->ops.size() != lead->ops.size()) continue;
+                const Span& c = spans[j];
+                if (done[j] || c.r->broken || c.e - c.b != len) continue;
                 bool ok = true;
-                for (size_t k = 0; k < lead->ops.size() && ok; ++k) ok = same(lead->ops[k], recs[j]->ops[k]);
-                if (ok) group.push_back(recs[j]), done[j] = true;
+                for (size_t k = 0; k < len && ok; ++k) ok = same_op(lead.r->ops[lead.b + k], c.r->ops[c.b + k]);
+                if (ok) group.push_back(&c), done[j] = true;
             }
-        for (size_t k = 0; k < lead->ops.size(); ++k) {
-            const RecOp& o = lead->ops[k];
+        for (size_t k = 0; k < len; ++k) {
+            const RecOp& o = lead.r->ops[lead.b + k];
             if (o.kind == RecOp::LAUNCH) {
                 const void* packs[BATCH_MAX];
-                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->ops[k].pack;
+                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->r->ops[group[g]->b + k].pack;
                 note(o.fn(o.name, o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
             } else {
-                for (Recorder* r : group) note(r->ops[k].replay());
+                for (const Span* g : group) note(g->r->ops[g->b + k].replay());
             }
         }
-        for (Recorder* r : group) r->ops.clear(), r->broken = false;
     }
+    return first;
+}
+}  // namespace
+
+hipError_t zip_and_launch(Recorder* const* recs, int n) {
+    Recorder* keep = g_recorder;
+    g_recorder = nullptr;
+    std::vector<Span> spans;
+    for (int i = 0; i < n; ++i) spans.push_back({recs[i], 0, recs[i]->ops.size()});
+    const hipError_t e = zip_spans(spans);
+    for (int i = 0; i < n; ++i) recs[i]->ops.clear(), recs[i]->broken = false;
+    g_recorder = keep;
+    return e;
+}
+
+hipError_t zip_marked_and_launch(Recorder* const* recs, int n) {
+    Recorder* keep = g_recorder;
+    g_recorder = nullptr;
+    std::vector<Span> before, seg, after;
+    for (int i = 0; i < n; ++i) {
+        Recorder* r = recs[i];
+        size_t b = r->ops.size(), e = r->ops.size();
+        for (size_t k = 0; k < r->ops.size(); ++k)
+            if (r->ops[k].kind == RecOp::MARK_BEGIN) {
+                b = k;
+                break;
+            }
+        for (size_t k = b; k < r->ops.size(); ++k)
+            if (r->ops[k].kind == RecOp::MARK_END) {
+                e = k + 1;
+                break;
+            }
+        if (r->broken || b == r->ops.size()) {  // no segment (or an unbatchable list): everything counts as "before"
+            before.push_back({r, 0, r->ops.size()});
+            continue;
+        }
+        before.push_back({r, 0, b});
+        seg.push_back({r, b, e});
+        after.push_back({r, e, r->ops.size()});
+    }
+    hipError_t first = zip_spans(before);
+    hipError_t e2 = zip_spans(seg);
+    hipError_t e3 = zip_spans(after);
+    if (first == hipSuccess) first = e2 != hipSuccess ? e2 : e3;
+    for (int i = 0; i < n; ++i) recs[i]->ops.clear(), recs[i]->broken = false;
     g_recorder = keep;
     return first;
 }

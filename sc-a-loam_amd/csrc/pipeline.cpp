@@ -142,6 +142,7 @@ void front_thread(scal_pipeline* p) {
             if (p->pushed <= k) return false;
             const long long old = k - p->ring;  // the scan that used this features context last
             if (old >= 0 && (p->c_coll <= old || p->b_enq <= old || (p->sc_on() && p->d_ins <= old))) return false;
+            if (p->sc_on() && k - p->d_coll >= 3) return false;  // the ScanContext context holds four searches / descriptors in flight
             return k - p->c_enq < PF_AHEAD;     // prefetches queued ahead of their stage-C steps
         });
         if (p->stop || p->err) return;
@@ -154,14 +155,60 @@ void front_thread(scal_pipeline* p) {
                 return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz[q], rc.n[q], rc.stride) : scal_features_run_device(reg, rc.d_xyz[q], rc.n[q], rc.stride);
             });
         });
+        // Everything that only needs stage A: stage C's prefetch (input gather, corner filter behind stage A; surf stack filter on the
+        // side stream) and ScanContext's keyframe filter + descriptor + insert.  The two big voxel filters - same kernels, same
+        // stream, different clouds - are recorded and SHARE their launches (zip_marked_and_launch): ~200 us of side-stream time per
+        // scan become ~110.  With several sequences all 2 S filter runs are merged the same way.
+        const bool search = p->cfg.sc_mode == SCAL_PIPE_SC_EVERY_SCAN;
+        double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(slot) * 1200 : nullptr;
         if (st == SCAL_OK)
-            st = p->tm_front.run(1, "C: map_prefetch_features", [&] { return p->for_all([&](int q) { return scal_map_prefetch_features(p->mp[q], p->regs[q][slot]); }); });
+            st = p->tm_front.run(1, "C: prefetch + D: insert", [&]() -> int {
+                if (!p->sc_on() && p->S == 1) return scal_map_prefetch_features(p->mp[0], p->regs[0][slot]);
+                Recorder recs[2 * SMAX];
+                Recorder* ptr[2 * SMAX];
+                int nr = 0, rc2 = SCAL_OK;
+                rc2 = p->tm_front.run(3, "   record prefetch", [&] {
+                    int r3 = SCAL_OK;
+                    for (int q = 0; q < p->S && r3 == SCAL_OK; ++q) {
+                        g_recorder = ptr[nr] = &recs[nr];
+                        ++nr;
+                        r3 = scal_map_prefetch_features(p->mp[q], p->regs[q][slot]);
+                        g_recorder = nullptr;
+                    }
+                    return r3;
+                });
+                if (rc2 == SCAL_OK && p->sc_on())
+                    rc2 = p->tm_front.run(4, "   record insert", [&] {
+                        int r3 = SCAL_OK;
+                        for (int q = 0; q < p->S && r3 == SCAL_OK; ++q) {
+                            g_recorder = ptr[nr] = &recs[nr];
+                            ++nr;
+                            r3 = search ? scal_sc_insert_features(p->sc[q], p->regs[q][slot]) : scal_sc_make_features_enqueue(p->sc[q], p->regs[q][slot], dd);
+                            g_recorder = nullptr;
+                        }
+                        return r3;
+                    });
+                if (rc2 != SCAL_OK) {  // what was recorded still has to run: the contexts' host state already counts on it
+                    for (int i = 0; i < nr; ++i) (void)recs[i].flush();
+                    return rc2;
+                }
+                return p->tm_front.run(5, "   zip + launch", [&]() -> int {
+                    if (zip_marked_and_launch(ptr, nr) != hipSuccess) {
+                        set_error("scal_pipeline: a batched launch failed: %s", hipGetErrorString(hipGetLastError()));
+                        return SCAL_E_HIP;
+                    }
+                    return SCAL_OK;
+                });
+            });
+        if (st == SCAL_OK && search) st = p->tm_front.run(2, "D: sc_detect_enqueue", [&] { return p->for_all([&](int q) { return scal_sc_detect_enqueue(p->sc[q]); }); });
         lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
             return;
         }
+        p->r(k).res[0].d_descriptor = dd;
         p->a_done = k + 1;
+        if (p->sc_on()) p->d_ins = k + 1;
         p->cv.notify_all();
     }
 }
@@ -231,60 +278,38 @@ void pose_thread(scal_pipeline* p) {
     }
 }
 
-void loop_thread(scal_pipeline* p) {
+void loop_thread(scal_pipeline* p) {  // ScanContext's answers (the searches themselves are queued by the front thread)
     std::unique_lock<std::mutex> lk(p->mu);
     const bool search = p->cfg.sc_mode == SCAL_PIPE_SC_EVERY_SCAN;
     for (;;) {
-        enum { NONE, INS, COLL } what = NONE;
         p->cv.wait(lk, [&] {
             if (p->stop || p->err) return true;
-            // Queueing comes first (it keeps the device fed; the context holds up to four searches / descriptors in flight); an answer
-            // is collected one scan behind its search - a whole period to finish - or as soon as somebody waits for it.
+            // an answer is collected one scan behind its search - a whole period to finish - or as soon as somebody waits for it
             const long long infl = p->d_ins - p->d_coll;
-            if (p->d_ins < p->a_done && infl < 3) { what = INS; return true; }
-            if (infl >= 2 || (infl > 0 && (p->pop_waiting || p->drain_req))) { what = COLL; return true; }
-            return false;
+            return infl >= 2 || (infl > 0 && (p->pop_waiting || p->drain_req));
         });
         if (p->stop || p->err) return;
-        int st = SCAL_OK;
-        if (what == INS) {
-            const long long k = p->d_ins;
-            const int slot = static_cast<int>(k % p->ring);
-            double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(slot) * 1200 : nullptr;
-            lk.unlock();
-            if (search) {
-                st = p->tm_loop.run(0, "D: sc_insert_features", [&] { return p->for_all([&](int q) { return scal_sc_insert_features(p->sc[q], p->regs[q][slot]); }); });
-                if (st == SCAL_OK) st = p->tm_loop.run(1, "D: sc_detect_enqueue", [&] { return p->for_all([&](int q) { return scal_sc_detect_enqueue(p->sc[q]); }); });
-            } else {
-                st = scal_sc_make_features_enqueue(p->sc[0], p->regs[0][slot], dd);
-            }
-            lk.lock();
-            if (st == SCAL_OK) {
-                p->r(k).res[0].d_descriptor = dd;
-                p->d_ins = k + 1;
-            }
-        } else {
-            const long long k = p->d_coll;
-            scal_pipeline_result* R = p->r(k).res;
-            lk.unlock();
-            if (search) {
-                st = p->tm_loop.run(2, "D: sc_detect_collect (wait)", [&] {
-                    return p->for_each([&](int q) {
-                        const int rc = scal_sc_detect_collect(p->sc[q], &R[q].loop);
-                        R[q].have_loop = rc == SCAL_OK;
-                        return rc;
-                    });
+        const long long k = p->d_coll;
+        scal_pipeline_result* R = p->r(k).res;
+        lk.unlock();
+        int st;
+        if (search) {
+            st = p->tm_loop.run(2, "D: sc_detect_collect (wait)", [&] {
+                return p->for_each([&](int q) {
+                    const int rc = scal_sc_detect_collect(p->sc[q], &R[q].loop);
+                    R[q].have_loop = rc == SCAL_OK;
+                    return rc;
                 });
-            } else {
-                st = scal_sc_wait_descriptor(p->sc[0]);
-            }
-            lk.lock();
-            if (st == SCAL_OK) p->d_coll = k + 1;
+            });
+        } else {
+            st = scal_sc_wait_descriptor(p->sc[0]);
         }
+        lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
             return;
         }
+        p->d_coll = k + 1;
         p->cv.notify_all();
     }
 }

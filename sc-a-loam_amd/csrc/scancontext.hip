@@ -972,13 +972,17 @@ static int make_features(scal_sc_t* c, scal_features_t* feat, double* d_desc, bo
 // waits for the OLDEST descriptor queued by scal_sc_make_features_enqueue (not for younger work on the stream)
 extern "C" int scal_sc_wait_descriptor(scal_sc_t* c) {
     if (!c) return SCAL_E_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::unique_lock<std::mutex> lk(c->mu);
     if (c->made_head == c->made_tail) {
         set_error("scal_sc_wait_descriptor: nothing queued");
         return SCAL_E_STATE;
     }
     SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(op_event_synchronize(c->made_ev[c->made_head % 4]));
+    hipEvent_t ev = c->made_ev[c->made_head % 4];
+    lk.unlock();  // further descriptors may be queued from another thread while this one is waited for
+    const hipError_t e = op_event_synchronize(ev);
+    lk.lock();
+    SCAL_HIP(e);
     c->made_head++;
     return SCAL_OK;
 }
@@ -1178,7 +1182,9 @@ static int detect_enqueue(scal_sc* c) {
     c->det_count++;
     return SCAL_OK;
 }
-static int detect_collect(scal_sc* c, scal_sc_result* res) {
+// `lk` (the context's mutex, held on entry and on return) is released while the search is waited for: inserts and further searches
+// from another thread - scal_pipeline's front thread - go on meanwhile.  The slot stays reserved until the answer has been read.
+static int detect_collect(scal_sc* c, scal_sc_result* res, std::unique_lock<std::mutex>* lk = nullptr) {
     std::memset(res, 0, sizeof *res);
     res->loop_id = -1;
     res->min_dist = 10000000;
@@ -1188,13 +1194,21 @@ static int detect_collect(scal_sc* c, scal_sc_result* res) {
     }
     const int slot = c->det_head;
     const int mode = c->det_mode[slot];
+    int rc = SCAL_OK;
+    if (mode != 2) {
+        hipError_t e = hipSetDevice(c->cfg.device);
+        if (lk) lk->unlock();
+        if (e == hipSuccess) e = op_event_synchronize(c->det_ev[slot]);
+        if (e == hipSuccess) finish_result(c->h_rec.p + 4 * slot, 3, c->cfg.dist_thres, res);
+        if (lk) lk->lock();
+        if (e != hipSuccess) {
+            set_error("scal_sc_detect_collect: %s", hipGetErrorString(e));
+            rc = SCAL_E_HIP;
+        }
+    }
     c->det_head = (c->det_head + 1) % scal_sc::DET_DEPTH;
     c->det_count--;
-    if (mode == 2) return SCAL_OK;
-    SCAL_HIP(hipSetDevice(c->cfg.device));
-    SCAL_HIP(op_event_synchronize(c->det_ev[slot]));
-    finish_result(c->h_rec.p + 4 * slot, 3, c->cfg.dist_thres, res);
-    return SCAL_OK;
+    return rc;
 }
 
 extern "C" int scal_sc_detect_enqueue(scal_sc_t* c) {
@@ -1210,8 +1224,8 @@ extern "C" int scal_sc_detect_collect(scal_sc_t* c, scal_sc_result* res) {
         set_error("scal_sc_detect_collect: null argument");
         return SCAL_E_ARG;
     }
-    std::lock_guard<std::mutex> lk(c->mu);
-    return detect_collect(c, res);
+    std::unique_lock<std::mutex> lk(c->mu);
+    return detect_collect(c, res, &lk);
 }
 extern "C" int scal_sc_detect(scal_sc_t* c, scal_sc_result* res) {
     if (!c || !res) {

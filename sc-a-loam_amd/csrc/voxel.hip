@@ -407,11 +407,13 @@ int VoxelFilter::run(hipStream_t s, CSoA4 in, const int* d_n, int n_bound, float
         ext_parts = box_parts.p;
         SCAL_LAUNCH(n_bbox.c_str(), k_vox_bbox, dim3(n_parts), dim3(256), 0, s, in, d_n, box_parts.p);
     }
+    rec_mark(true);  // keys .. reduce: the segment that filter runs of different contexts can share launches for (batch.hpp)
     SCAL_LAUNCH(n_keys.c_str(), k_vox_keys, dim3(nb), dim3(256), 0, s, in, d_n, inv, max_bits, meta.p, keys.p, vals.p, ext_parts, n_parts);
     SortedPairs sp;
     SCAL_TRY(sorter.sort(s, keys.p, vals.p, d_n, n_bound, max_bits, &meta.p->used_bits, &sp));
     SCAL_LAUNCH(n_heads.c_str(), k_vox_heads, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p);
     SCAL_LAUNCH(n_reduce.c_str(), k_vox_reduce, dim3(nb), dim3(256), 0, s, sp, d_n, blockcnt.p, in, out, d_n_out, meta.p, tl);
+    rec_mark(false);
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
 }
