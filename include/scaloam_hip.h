@@ -288,6 +288,9 @@ int scal_map_collect(scal_map_t* ctx, double* q_w_curr, double* t_w_curr, scal_m
 int scal_map_finish(scal_map_t* ctx);
 /* current map points of the 5x5x3 window (laserCloudCornerFromMap / SurfFromMap content); returns count */
 int scal_map_export(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
+/* every point of the 21x21x11 cube grid, one feature class: the content of /laser_cloud_map (laserMapping.cpp:824-837 adds the corner
+ * and surf clouds of all 4,851 cubes every 20 frames); out_xyzi NULL or cap 0: only the count.  Returns the number of points written. */
+int scal_map_export_all(scal_map_t* ctx, int which /*0 corner, 1 surf*/, float* out_xyzi, int cap);
 int scal_map_get_wmap_wodom(scal_map_t* ctx, double* q_xyzw, double* t);
 /* enable (default) / disable the merge insert; both give identical maps, the switch exists for tests and measurements */
 int scal_map_set_merge_insert(scal_map_t* ctx, int enable);

@@ -402,6 +402,18 @@ struct Mapper {
         return 0;
     }
 
+    // every cube of the grid, one class: what laserMapping.cpp:824-837 adds up for /laser_cloud_map
+    int export_all(int which, P4* out, int cap) const {
+        int m = 0;
+        for (size_t i = 0; i < cornerArr.size(); i++) {
+            const std::vector<P4>& v = which == 0 ? *cornerArr[i] : *surfArr[i];
+            for (const P4& p : v) {
+                if (m < cap) out[m] = p;
+                ++m;
+            }
+        }
+        return m;
+    }
     int export_map(int which, P4* out, int cap) const {
         int m = 0;
         for (int i = 0; i < validNum; i++) {
@@ -446,6 +458,9 @@ int orc_map_step(void* h, const float* corner_last, int n_corner, const float* s
                                              reinterpret_cast<const orc::P4*>(surf_last), n_surf,
                                              reinterpret_cast<const orc::P4*>(full_res), n_full, q_wodom, t_wodom, q_w_curr, t_w_curr,
                                              reinterpret_cast<orc::P4*>(registered), stats);
+}
+int orc_map_export_all(void* h, int which, float* out, int cap) {
+    return static_cast<orc::Mapper*>(h)->export_all(which, reinterpret_cast<orc::P4*>(out), cap);
 }
 int orc_map_export(void* h, int which, float* out, int cap) {
     return static_cast<orc::Mapper*>(h)->export_map(which, reinterpret_cast<orc::P4*>(out), cap);

@@ -96,6 +96,7 @@ int orc_map_step(void* h, const float* corner_last, int n_corner, const float* s
                  double* q_w_curr_xyzw, double* t_w_curr, float* registered, OrcMapStats* stats);
 /* current map content of the valid (5x5x3) window in reference gather order; returns counts */
 int orc_map_export(void* h, int which /*0 corner,1 surf*/, float* out_xyzi, int cap);
+int orc_map_export_all(void* h, int which, float* out_xyzi, int cap); /* all 4851 cubes (laserMapping.cpp:824-837) */
 void orc_map_get_wmap_wodom(void* h, double* q_xyzw, double* t);
 
 /* ---- stage B: odometry ---- */

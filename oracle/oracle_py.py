@@ -83,6 +83,7 @@ def lib():
         L.orc_map_step.argtypes = [C.c_void_p, _f32p, C.c_int, _f32p, C.c_int, _f32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f32p,
                                    C.POINTER(MapStats)]
         L.orc_map_export.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_int]
+        L.orc_map_export_all.argtypes = [C.c_void_p, C.c_int, _f32p, C.c_int]
         L.orc_map_get_wmap_wodom.argtypes = [C.c_void_p, _f64p, _f64p]
         L.orc_odom_create.restype = C.c_void_p
         L.orc_odom_destroy.argtypes = [C.c_void_p]
@@ -282,6 +283,13 @@ class Mapper:
         lib().orc_map_step(self.h, _p(c, _f32p), c.shape[0], _p(s, _f32p), s.shape[0], _p(f, _f32p), 0 if f is None else f.shape[0],
                            _p(q, _f64p), _p(t, _f64p), _p(qo, _f64p), _p(to, _f64p), _p(reg, _f32p), C.byref(st))
         return qo, to, st, reg
+
+    def export_all(self, which):
+        """every cube of the 21x21x11 grid (what /laser_cloud_map carries, laserMapping.cpp:824-837), one feature class"""
+        n = lib().orc_map_export_all(self.h, which, None, 0)
+        out = np.zeros((max(n, 1), 4), np.float32)
+        lib().orc_map_export_all(self.h, which, _p(out, _f32p), n)
+        return out[:n]
 
     def export(self, which):
         n = lib().orc_map_export(self.h, which, None, 0)

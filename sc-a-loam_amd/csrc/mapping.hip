@@ -1349,6 +1349,7 @@ struct scal_map {
     // device
     DevBuf<MapState> d_S;
     DevBuf<float> aos;  // upload staging
+    DevBuf<float> export_buf;  // map-sized staging of scal_map_export / _export_all (allocated by the first export)
     SoAStore corner_in2[NSETS], surf_in2[NSETS], corner_stack2[NSETS], surf_stack2[NSETS];
     SoAStore full_in, full_out;
     SoAStore& corner_in(int st) { return corner_in2[st]; }
@@ -2262,19 +2263,47 @@ extern "C" int scal_map_export(scal_map_t* c, int which, float* out_xyzi, int ca
     MapStore& M = c->map[which];
     c->h_misc.p[1] = 0;
     SCAL_HIP(op_memcpy_async(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
-    const int room = std::min(cap, c->scan_cap);
+    // staging for the map-sized exports (the scan-sized upload staging cut a 5x5x3 window larger than one scan short): once, on demand
+    if (out_xyzi && c->export_buf.n < static_cast<size_t>(c->map_cap) * 4) SCAL_TRY(c->export_buf.alloc(static_cast<size_t>(c->map_cap) * 4));
+    const int room = std::min(cap, c->map_cap);
     SCAL_LAUNCH("k_export_valid", k_export_valid, dim3(std::max(1, std::min(1024, div_up(M.n, 256)))), dim3(256), 0, s, M.cloud(c->cur), c->d_S.p, which,
-                       c->d_nfull.p + 1, c->aos.p, out_xyzi ? room : 0);
+                       c->d_nfull.p + 1, out_xyzi ? c->export_buf.p : nullptr, out_xyzi ? room : 0);
     SCAL_HIP(op_memcpy_async(c->h_misc.p + 2, c->d_nfull.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SCAL_HIP(op_stream_synchronize(s));
     const int n = c->h_misc.p[2];
     if (out_xyzi && room > 0) {
         const int m = std::min(n, room);
-        SCAL_HIP(op_memcpy_async(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(op_memcpy_async(out_xyzi, c->export_buf.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
         SCAL_HIP(op_stream_synchronize(s));
         return m;
     }
     return n;
+}
+
+// Every point of the 21 x 21 x 11 cube grid, one feature class: what /laser_cloud_map carries (laserMapping.cpp:824-837 adds up
+// laserCloudCornerArray[i] and laserCloudSurfArray[i] over all 4,851 cubes every 20 frames).  Here that is the class's whole map
+// array: the next re-filter drops what has left the grid, nothing else is stored.  Order: this library's (valid cubes in voxel
+// order, then the cubes outside the 5x5x3 window in arrival order), not the reference's cube-index order - a point set.
+extern "C" int scal_map_export_all(scal_map_t* c, int which, float* out_xyzi, int cap) {
+    if (!c || (which != 0 && which != 1) || cap < 0) {
+        set_error("scal_map_export_all: bad argument");
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    if (map_finish(c) != SCAL_OK) return -1;
+    MapStore& M = c->map[which];
+    if (!out_xyzi || cap == 0) return M.n;
+    const int m = std::min(M.n, cap);
+    if (m == 0) return 0;
+    hipStream_t s = c->stream;
+    if (c->export_buf.n < static_cast<size_t>(c->map_cap) * 4) SCAL_TRY(c->export_buf.alloc(static_cast<size_t>(c->map_cap) * 4));
+    c->h_misc.p[1] = m;
+    SCAL_HIP(op_memcpy_async(c->d_nfull.p + 1, c->h_misc.p + 1, sizeof(int), hipMemcpyHostToDevice, s));
+    const MapCloud mc = M.cloud(c->cur);
+    launch_interleave(s, c->d_nfull.p + 1, m, CSoA4{mc.x, mc.y, mc.z, mc.w}, c->export_buf.p);
+    SCAL_HIP(op_memcpy_async(out_xyzi, c->export_buf.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+    SCAL_HIP(op_stream_synchronize(s));
+    return m;
 }
 
 extern "C" int scal_map_set_merge_insert(scal_map_t* c, int enable) {

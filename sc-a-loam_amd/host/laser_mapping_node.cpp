@@ -54,7 +54,7 @@ HANDLER(cornerHandler, cornerBuf) HANDLER(surfHandler, surfBuf) HANDLER(fullHand
 
 static void process() {
     int frameCount = 0;
-    std::vector<float> reg, exported(4 * 400000);
+    std::vector<float> reg, exported(4 * static_cast<size_t>(2 * 4000000));  // both classes of the whole map (scal_map_config::max_map_points each)
     while (ros::ok()) {
         sensor_msgs::PointCloud2ConstPtr mc, ms, mf;
         nav_msgs::Odometry::ConstPtr mo;
@@ -87,13 +87,23 @@ static void process() {
                 SCAL_CHECK(scal_map_get_wmap_wodom(g_map, q_wmap_wodom, t_wmap_wodom));  // transformUpdate happened on the device (:735)
             }
             const ros::Time stamp = mo->header.stamp;
+            // `exported` holds 2 x max_map_points records: both classes of the whole cube grid fit
+            auto export_both = [&](int (*fn)(scal_map_t*, int, float*, int)) -> int {
+                const int cap = static_cast<int>(exported.size() / 4);
+                const int nc = fn(g_map, 0, exported.data(), cap);
+                if (nc < 0) { ROS_ERROR("map export: %s", scal_last_error()); return -1; }   // <0 = error: never used as an offset
+                const int ns = fn(g_map, 1, exported.data() + 4 * static_cast<size_t>(nc), cap - nc);
+                if (ns < 0) { ROS_ERROR("map export: %s", scal_last_error()); return -1; }
+                return nc + ns;
+            };
             if (frameCount % 5 == 0) {  // :807-822: the 5x5x3 window (corner + surf)
-                int n = scal_map_export(g_map, 0, exported.data(), 400000);
-                n += scal_map_export(g_map, 1, exported.data() + 4 * n, 400000 - n);
-                pubSurround.publish(scal_ros::to_msg(exported.data(), n, stamp, "/camera_init"));
+                const int n = export_both(scal_map_export);
+                if (n >= 0) pubSurround.publish(scal_ros::to_msg(exported.data(), n, stamp, "/camera_init"));
             }
-            // :824-837 publishes all 4851 cubes every 20 scans; the window export above is what this library keeps addressable
-            if (frameCount % 20 == 0) pubMap.publish(scal_ros::to_msg(exported.data(), 0, stamp, "/camera_init"));
+            if (frameCount % 20 == 0) {  // :824-837: all 4851 cubes, corner + surf
+                const int n = export_both(scal_map_export_all);
+                if (n >= 0) pubMap.publish(scal_ros::to_msg(exported.data(), n, stamp, "/camera_init"));
+            }
             pubRegLocal.publish(*mf);                                                                     // :839-843, sensor frame (PGO keyframes)
             pubReg.publish(scal_ros::to_msg(reg.data(), static_cast<int>(f.size() / 4), stamp, "/camera_init"));  // :845-855
             nav_msgs::Odometry o;  // :861-886

@@ -99,6 +99,9 @@ def test_window_roll(O, S, stage_ab):
         for which in (0, 1):
             mo, mg = _sorted_rows(om.export(which)), _sorted_rows(gm.export(which))
             assert mo.shape == mg.shape, (step, which)
+            # /laser_cloud_map: every cube of the 21x21x11 grid (laserMapping.cpp:824-837), incl. the cubes outside the 5x5x3 window
+            ao, ag = _sorted_rows(om.export_all(which)), _sorted_rows(gm.export_all(which))
+            assert ao.shape == ag.shape and ao.shape[0] >= mo.shape[0] and np.array_equal(ao, ag), (step, which, ao.shape, ag.shape)
     gm.close()
 
 
