@@ -13,13 +13,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, every=1):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "sc-a-loam_amd", "python"))
     import torch
     import torch.distributed as dist
     import oracle_py as O
     import scaloam as S
+    from scaloam.sharded import TreePeriodBook
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,8 +35,29 @@ def _worker(rank, world, port, q):
         descs.append(d)
     single = O.SCManager(dist_thres=0.3)
     local_keys, local_idx = [], []
-    counter, size_at_rebuild = 0, 0
+    book = TreePeriodBook(0)  # the bookkeeping bench.py uses: a query's tree size depends on the ORDER of the queries only
     ok = True
+    pending = []              # `every` queries travel in one all_gather (bench.py --sc-exchange-every)
+
+    def exchange(batch):
+        """one all_gather carries the shard-local records of all queries of the batch; every query is merged on its own"""
+        good = True
+        t = torch.from_numpy(np.stack([b[0] for b in batch]))
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        for j, (_, ref) in enumerate(batch):
+            cands = []
+            for g in gathered:
+                for row in g[j].numpy():
+                    if row[4] > 0:
+                        cands.append(S.SCCand(np.float32(row[0]), int(row[1]), float(row[2]), int(row[3]), 0))
+                    else:
+                        cands.append(S.SCCand(3.4e38, -1, 1e7, 0, 0))
+            got = S.merge_candidates(cands, 0.3)
+            good &= got["loop_id"] == ref["loop_id"] and got["nn_idx"] == ref["nn_idx"] and abs(got["min_dist"] - ref["min_dist"]) < 1e-12
+            good &= list(got["cand"]) == list(ref["cand"])
+        return good
+
     for i, d in enumerate(descs):
         single.saveScancontextAndKeys(d)
         if i % world == rank:  # shard ownership: keyframe i on rank i % N
@@ -44,9 +66,8 @@ def _worker(rank, world, port, q):
         ref = single.detectLoopClosureID()
         if i + 1 < 31:
             continue
-        if counter % 30 == 0:
-            size_at_rebuild = i + 1
-        counter += 1
+        book.n_global = i
+        size_at_rebuild = book.step(1)[0]
         # shard-local top-3 by nanoflann's f32 key distance over eligible keys, then SC distance of those three
         qk = single.get(i)[1]
         rec = np.zeros((3, 6), np.float64)  # key_dist, idx, sc_dist, shift, valid, pad
@@ -63,36 +84,32 @@ def _worker(rank, world, port, q):
             for s, o in enumerate(order):
                 dd, sh = O.sc_distance(d, descs[gi[o]])
                 rec[s] = [acc[o], gi[o], dd, sh, 1, 0]
-        t = torch.from_numpy(rec)
-        gathered = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(gathered, t)
-        cands = []
-        for g in gathered:
-            for row in g.numpy():
-                if row[4] > 0:
-                    cands.append(S.SCCand(np.float32(row[0]), int(row[1]), float(row[2]), int(row[3]), 0))
-                else:
-                    cands.append(S.SCCand(3.4e38, -1, 1e7, 0, 0))
-        got = S.merge_candidates(cands, 0.3)
-        ok &= got["loop_id"] == ref["loop_id"] and got["nn_idx"] == ref["nn_idx"] and abs(got["min_dist"] - ref["min_dist"]) < 1e-12
-        ok &= list(got["cand"]) == list(ref["cand"])
+        pending.append((rec, ref))
+        if len(pending) == every:
+            ok &= exchange(pending)
+            pending = []
+    if pending:  # the last, partial batch (every rank holds the same number of queries)
+        ok &= exchange(pending)
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, bool(ok)))
 
 
-def test_sharded_sc_search_gloo_world2():
+@pytest.mark.parametrize("world,every", [(2, 1), (2, 4), (3, 1), (3, 7)])
+def test_sharded_sc_search_gloo(world, every):
+    """every = 1: one exchange per query, as the reference's cadence allows at most; every > 1: the batched exchange of
+    bench.py --sc-exchange-every (one pair of all-gathers per `every` scans).  The answers must not depend on it."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + every
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, every)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(60)
-    assert sorted(res) == [(0, True), (1, True)], res
+    assert sorted(res) == [(r, True) for r in range(world)], res
 
 
 def _voxel_worker(rank, world, port, q):
