@@ -785,7 +785,8 @@ def roofline_of(prof, c, pipelined=True, prof_all=None, n_all_steps=0):
         sb = stage_bytes(c)
         stages = {}
         for st, names in STAGE_KERNELS.items():
-            ms = sum(v[0] for k, v in prof_all.items() if k in names or k.endswith("." + st)) / n_all_steps
+            # "k_rs_scatter.C+D": one launch carrying stage C's surf filter and ScanContext's keyframe filter - charged half and half
+            ms = sum(v[0] / (k.count("+") + 1) for k, v in prof_all.items() if k in names or st in k.rsplit(".", 1)[-1].split("+") and "." in k) / n_all_steps
             if ms > 0:
                 gbs = sb[st] / (ms * 1e-3) / 1e9
                 stages[st] = {"algorithmic_bytes_per_scan": sb[st], "kernel_ms_per_scan": ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}

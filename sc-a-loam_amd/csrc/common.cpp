@@ -2,6 +2,7 @@
 #include "common.hpp"
 #include <chrono>
 #include <cstdlib>
+#include <memory>
 
 namespace scal {
 
@@ -46,6 +47,19 @@ hipError_t Recorder::flush() {
 }
 
 namespace {
+// name of a launch that carries work of differently tagged callers ("k_rs_scatter.C" + "k_rs_scatter.D" -> "k_rs_scatter.C+D"):
+// interned, so that the const char* outlives the call (scal_prof_* keeps names)
+const char* merged_name(const char* a, const char* b) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<std::string>> pool;
+    const char* dot = std::strrchr(b, '.');
+    const std::string key = std::string(a) + "+" + (dot ? dot + 1 : b);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& s : pool)
+        if (*s == key) return s->c_str();
+    pool.push_back(std::make_unique<std::string>(key));
+    return pool.back()->c_str();
+}
 struct Span {
     Recorder* r;
     size_t b, e;
@@ -81,8 +95,13 @@ hipError_t zip_spans(const std::vector<Span>& spans) {
             const RecOp& o = lead.r->ops[lead.b + k];
             if (o.kind == RecOp::LAUNCH) {
                 const void* packs[BATCH_MAX];
-                for (size_t g = 0; g < group.size(); ++g) packs[g] = group[g]->r->ops[group[g]->b + k].pack;
-                note(o.fn(o.name, o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
+                const char* name = o.name;
+                for (size_t g = 0; g < group.size(); ++g) {
+                    const RecOp& og = group[g]->r->ops[group[g]->b + k];
+                    packs[g] = og.pack;
+                    if (g > 0 && std::strcmp(og.name, o.name) != 0 && !std::strstr(name, "+")) name = merged_name(o.name, og.name);
+                }
+                note(o.fn(name, o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
             } else {
                 for (const Span* g : group) note(g->r->ops[g->b + k].replay());
             }

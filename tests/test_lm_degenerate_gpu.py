@@ -96,8 +96,9 @@ def test_open_field_ground_only(O, S):
 
 
 def test_thin_scan_at_the_map_size_gate(O, S):
-    """A corridor scan thinned to every 12th firing column: few features, a map that hovers around laserCloudCornerFromMapNum > 10 &&
-    laserCloudSurfFromMapNum > 50 (laserMapping.cpp:555) - solved and unsolved scans must alternate exactly as in the oracle."""
+    """A low-walled corridor thinned to every 12th firing column: a few dozen plane blocks per solve (28-46) against ~900 edge blocks,
+    a map of a few hundred points just above the reference's gate laserCloudCornerFromMapNum > 10 && laserCloudSurfFromMapNum > 50
+    (laserMapping.cpp:555) - the solved flag, the block counts and the accept / reject sequence must follow the oracle scan by scan."""
     walls = [(-4.0, 3.0), (6.0, 3.0)]
     scans = []
     for k in range(8):

@@ -1,9 +1,10 @@
-# HBM traffic per dispatch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, kernel trace only) of the serial
-# schedule of bench.py, aggregated per kernel -> gpurun_out/pmc_summary.json (copy to profiles/ after checking)
+# HBM traffic per dispatch (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, kernel trace only) of the BENCHMARKED
+# configuration of bench.py (scal_pipeline schedule, 5,000-keyframe database), aggregated per kernel -> gpurun_out/pmc_summary.json
+# (copy to profiles/ after checking)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CFG="--steps 20 --warmup 5 --reps 1 --h2d 0 --cpu-sample 0 --sc-db 200 --no-overlap --prof-every 0"
+CFG="--steps 20 --warmup 5 --reps 1 --min-timed-s 0 --h2d 0 --cpu-sample 0 --cpp-sample 0 --seqs 0 --prof-every 0"
 rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py $CFG > $R/gpurun_out/pmc_fetch.log 2>&1
 echo fetch rc=$?
@@ -25,7 +26,7 @@ for tag in ('fetch','write'):
         for r in csv.DictReader(open(f)):
             a[short(r['Kernel_Name'])][0]+=float(r['Counter_Value']); a[short(r['Kernel_Name'])][1]+=1
     agg[tag]=a
-out={'config':'python3 bench.py $CFG (serial schedule, one stream), FETCH_SIZE / WRITE_SIZE in KB per dispatch as rocprofv3 reports them; '
+out={'config':'python3 bench.py $CFG (the benchmarked schedule and database; counter collection serialises the dispatches), FETCH_SIZE / WRITE_SIZE in KB per dispatch as rocprofv3 reports them; '
      'FETCH_SIZE raw (the guide\\'s x2 correction applies to 16-B-per-lane streaming reads; these kernels read 4-8 B per lane)','kernels':{}}
 for k in sorted(set(agg['fetch'])|set(agg['write'])):
     f,w=agg['fetch'].get(k,[0,0]),agg['write'].get(k,[0,0])
