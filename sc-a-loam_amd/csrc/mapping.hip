@@ -93,6 +93,11 @@ __device__ __forceinline__ int grid_cell(const MapParams& mp, float x, float y, 
     return cx + GX * (cy + GY * cz);
 }
 
+struct MapCounters;
+__device__ __forceinline__ unsigned long long map_key(const MapParams& mp, float inv_leaf, float x, float y, float z, int pc, MapCounters* C);
+constexpr unsigned long long MAP_NOMERGE_SLOT = 127ull;
+__device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >> 27) == MAP_NOMERGE_SLOT; }
+
 __device__ __forceinline__ bool cube_valid(const MapParams& mp, int packed) {
     int ai, aj, ak;
     unpack_cube(packed, ai, aj, ak);
@@ -115,6 +120,9 @@ struct GridArgs {
     int2* cell[2];  // per cell (count, start in the point pool): one 8-byte load per neighbour cell
     int* rank[2];
     GridPts g[2];
+    // one-launch build only: the merge insert's keys of the old points and its sortedness check ride on this walk over the map
+    unsigned long long* okeys[2];
+    float inv_leaf[2];
 };
 // Fixed launch shape (the map sizes are device words): a quarter of the blocks walks the corner map, the rest the surf map,
 // each with a block-stride loop.  `i0` is the first point of this block's current tile, uniform over the block.
@@ -173,29 +181,43 @@ __device__ __forceinline__ void k_grid_build_body(const GridArgs& a, int cap0, i
     const int n = S->n_map[cls];
     const int cap = cls ? cap1 : cap0;
     const MapCloud& m = a.m[cls];
-    bool over = false;
+    bool over = false, unsorted = false;
     for (int i0 = first; i0 < n; i0 += stride) {
         const int i = i0 + threadIdx.x;
         const bool in = i < n;
         bool v = false;
-        if (in && cube_valid(mp, m.cube[i])) {
-            v = true;
+        if (in) {
             const float x = m.x[i], y = m.y[i], z = m.z[i];
-            const int c = grid_cell(mp, x, y, z);
-            const int r = atomicAdd(&a.cell[cls][c].x, 1);
-            a.rank[cls][i] = r;  // >= 0: this point's cell counter has to be cleared again
-            if (r < cap) {
-                a.g[cls].p[static_cast<size_t>(c) * cap + r] = make_float4(x, y, z, __int_as_float(i));
-                if (r == 0) a.cell[cls][c].y = c * cap;
-            } else {
-                over = true;
+            const int pc = m.cube[i];
+            // the merge insert's key of this (old) point and its sortedness check: the window is fixed for the step, so they are
+            // known here, on a walk over the map that happens anyway (round 2 walked the map a second time for them in k_merge_keys)
+            const unsigned long long k = map_key(mp, a.inv_leaf[cls], x, y, z, pc, C);
+            a.okeys[cls][i] = k;
+            bool bad = k == ~0ull;
+            if (i > 0) {
+                const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
+                bad |= kp > k || (kp == k && !key_nomerge(k));
             }
-        } else if (in) {
-            a.rank[cls][i] = -1;
+            unsorted |= bad;
+            if (cube_valid(mp, pc)) {
+                v = true;
+                const int c = grid_cell(mp, x, y, z);
+                const int r = atomicAdd(&a.cell[cls][c].x, 1);
+                a.rank[cls][i] = r;  // >= 0: this point's cell counter has to be cleared again
+                if (r < cap) {
+                    a.g[cls].p[static_cast<size_t>(c) * cap + r] = make_float4(x, y, z, __int_as_float(i));
+                    if (r == 0) a.cell[cls][c].y = c * cap;
+                } else {
+                    over = true;
+                }
+            } else {
+                a.rank[cls][i] = -1;
+            }
         }
         const uint64_t b = __ballot(v);
         if (lane_id() == 0 && b) atomicAdd(&s_valid, __popcll(b));
     }
+    if (unsorted) C->merge_fail = 1;
     if (over) __hip_atomic_store(&S->abort, static_cast<int>(MAP_ABORT_GRID), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (threadIdx.x == 0 && s_valid) atomicAdd(&C->n_valid[cls], s_valid);
@@ -752,43 +774,46 @@ struct MergeArgs {
 //   k_merge_write  256 threads: blocks [0, WB0) / [WB0, WB0 + WB1) old points, then MERGE_MAX / 256 blocks per class for the new runs
 constexpr int MERGE_CHUNKS = MERGE_MAX / 512;
 constexpr int MERGE_KB0 = 24, MERGE_KB1 = 88;
-constexpr int MERGE_KEYS_GRID = MERGE_KB0 + MERGE_KB1 + 2 * MERGE_CHUNKS;
+constexpr int MERGE_KEYS_GRID = 2 * MERGE_CHUNKS;
 constexpr int MERGE_NEW_BLOCKS = MERGE_MAX / 256;
 constexpr int MERGE_WB0 = 256, MERGE_WB1 = 1536;
 constexpr int MERGE_WRITE_GRID = MERGE_WB0 + MERGE_WB1 + 2 * MERGE_NEW_BLOCKS;
 
-__device__ __forceinline__ bool key_nomerge(unsigned long long k) { return (k >> 27) == MAP_NOMERGE; }
+static_assert(MAP_NOMERGE_SLOT == MAP_NOMERGE, "one constant");
 
 // Old points: their keys, the sortedness check, the zero invariant of the cell grid.  New points: every sorting block stages ALL
 // new keys of its class in LDS (written by k_map_pose_done), sorts the 512-chunks in registers (one wave each), then ranks the
 // keys of ITS chunk against the other chunks with binary searches - rank = sorted position, the keys are distinct because they
 // carry the arrival index - and scatters them.  No merge network across workgroups, no second launch.
+// keys of the old points + sortedness check as a launch of their own: the general path, whose three-launch grid build does not
+// compute them (the speculative chain's k_grid_build does)
+__device__ __forceinline__ void k_merge_okeys_body(const MergeArgs& a, const MapState* __restrict__ S, MapCounters* C) {
+    if (S->abort) return;
+    const MapParams mp = S->mp;
+    int b = blockIdx.x;
+    const int cls = b < MERGE_KB0 ? 0 : 1;
+    const int nblk = cls ? MERGE_KB1 : MERGE_KB0;
+    if (cls) b -= MERGE_KB0;
+    const MapCloud m = a.in[cls];
+    const int n_old = S->n_map[cls];
+    for (int i = b * 1024 + threadIdx.x; i < n_old; i += nblk * 1024) {
+        const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
+        a.okeys[cls][i] = k;
+        bool bad = k == ~0ull;
+        if (i > 0) {
+            const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
+            bad |= kp > k || (kp == k && !key_nomerge(k));
+        }
+        if (bad) C->merge_fail = 1;
+    }
+}
+SCAL_KERNEL(1024, k_merge_okeys)
+
 __device__ __forceinline__ void k_merge_keys_body(const MergeArgs& a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
     if (S->abort) return;
     extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX packed keys
     __shared__ int s_scan[17];
-    const MapParams mp = S->mp;
     int b = blockIdx.x;
-    if (b < MERGE_KB0 + MERGE_KB1) {
-        const int cls = b < MERGE_KB0 ? 0 : 1;
-        const int nblk = cls ? MERGE_KB1 : MERGE_KB0;
-        if (cls) b -= MERGE_KB0;
-        const MapCloud m = a.in[cls];
-        const int n_old = S->n_map[cls];
-        for (int i = b * 1024 + threadIdx.x; i < n_old; i += nblk * 1024) {
-            const unsigned long long k = map_key(mp, a.inv_leaf[cls], m.x[i], m.y[i], m.z[i], m.cube[i], C);
-            a.okeys[cls][i] = k;
-            if (a.grid_rank[cls][i] >= 0) a.grid_cell[cls][grid_cell(mp, m.x[i], m.y[i], m.z[i])].x = 0;  // zero invariant of the cell grid
-            bool bad = k == ~0ull;
-            if (i > 0) {
-                const unsigned long long kp = map_key(mp, a.inv_leaf[cls], m.x[i - 1], m.y[i - 1], m.z[i - 1], m.cube[i - 1], C);
-                bad |= kp > k || (kp == k && !key_nomerge(k));
-            }
-            if (bad) C->merge_fail = 1;
-        }
-        return;
-    }
-    b -= MERGE_KB0 + MERGE_KB1;
     const int cls = b / MERGE_CHUNKS, tile = b % MERGE_CHUNKS;
     const int ns = *a.d_ns[cls];
     const int n_new = min(ns, MERGE_MAX);
@@ -899,6 +924,17 @@ SCAL_KERNEL(512, k_merge_lookup)
 // host redoes this insertion with the full sort and replays the steps queued behind it.
 __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S, MapCounters* C) {
     if (S->abort) return;
+    if (static_cast<int>(blockIdx.x) < MERGE_WB0 + MERGE_WB1) {
+        // zero invariant of the cell grid: the blocks that walk the old points clear the cells their points were binned into -
+        // first of all, also when the merge is about to be called off (the full-sort redo does not touch the grid)
+        const int cls0 = static_cast<int>(blockIdx.x) < MERGE_WB0 ? 0 : 1;
+        const int b0 = cls0 ? blockIdx.x - MERGE_WB0 : blockIdx.x, nblk0 = cls0 ? MERGE_WB1 : MERGE_WB0;
+        const MapParams mp0 = S->mp;
+        const MapCloud m0 = a.in[cls0];
+        const int n0 = S->n_map[cls0];
+        for (int i = b0 * 256 + threadIdx.x; i < n0; i += nblk0 * 256)
+            if (a.grid_rank[cls0][i] >= 0) a.grid_cell[cls0][grid_cell(mp0, m0.x[i], m0.y[i], m0.z[i])].x = 0;
+    }
     if (C->merge_fail) {
         if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&S->abort, static_cast<int>(MAP_ABORT_MERGE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -1565,6 +1601,8 @@ GridArgs grid_args(scal_map* c, int par, bool fixed_pool = false) {
         GridStore& G = c->grid[k];
         ga.m[k] = c->map[k].cloud(par);
         ga.cell[k] = G.cell.p, ga.rank[k] = G.rank.p, ga.g[k] = G.pts(fixed_pool);
+        ga.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;  // the merge insert's view of the same buffers (launch_insert_merge)
+        ga.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
     }
     return ga;
 }
@@ -1611,6 +1649,8 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
     }
     a.cap = c->map_cap;
     const int lds = sizeof(unsigned long long) * MERGE_MAX;  // attribute set per device in scal_map_create
+    if (!fused)  // general path: the three-launch grid build has not computed the old points' keys (k_grid_build does on the chain)
+        SCAL_LAUNCH("k_merge_okeys", k_merge_okeys, dim3(MERGE_KB0 + MERGE_KB1), dim3(1024), 0, s, a, c->d_S.p, C);
     SCAL_LAUNCH("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
     SCAL_LAUNCH("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
     MergeTail t{};
