@@ -41,9 +41,6 @@ __device__ __forceinline__ unsigned long long make_key(float d, unsigned seq) {
 }
 
 constexpr int RING_TAB = 96;   // per-ring first/last index tables of a target cloud
-constexpr int NN_QT = 64;      // queries per block
-constexpr int NN_TC = 2048;    // target points per block (staged through LDS)
-constexpr int NN_PARTS = 16;   // waves per block: each takes 1/16 of the block's targets for all 64 queries
 
 // TransformToStart (:111-129): q_last_curr * p + t_last_curr in f64, stored to f32
 __device__ __forceinline__ void transform_to_start(const double* x7, float ox, float oy, float oz, float* o) {
@@ -54,66 +51,72 @@ __device__ __forceinline__ void transform_to_start(const double* x7, float ox, f
     o[2] = static_cast<float>(r[2] + 1.0 * x7[6]);
 }
 
-// Exact NN(1), tiled: block (qt, ch) scans target chunk ch (2048 points staged in LDS, read as wave-wide broadcasts)
-// for 64 queries; thread (q = tid % 64, part = tid / 64) covers a quarter of the chunk.  The per-(query, chunk) minima
-// are (f32 distance bits, target index) keys; k_odom_assoc takes the minimum over chunks.
-__device__ __forceinline__ void k_odom_nn_body(const CSoA4& sharp, const CSoA4& flat, const CSoA4& CL, const CSoA4& SL, const LMState* __restrict__ st,
-                                                 const OdomCounters* __restrict__ C, int slot_cap, int nch, unsigned long long* __restrict__ part) {
-    __shared__ float tx[NN_TC], ty[NN_TC], tz[NN_TC];
-    __shared__ unsigned long long red[NN_PARTS][NN_QT];
-    if (!C->enable) return;
-    const int ns = C->n_sharp, nf = C->n_flat;
-    // a tile never mixes sharp and flat queries: tiles are laid out per class
-    const int sharp_tiles = (ns + NN_QT - 1) / NN_QT;
-    const bool is_edge = static_cast<int>(blockIdx.x) < sharp_tiles;
-    const int qbase = is_edge ? blockIdx.x * NN_QT : (blockIdx.x - sharp_tiles) * NN_QT;
-    const int nq = is_edge ? ns : nf;
-    if (qbase >= nq) return;
-    const CSoA4& Q = is_edge ? sharp : flat;
-    const CSoA4& T = is_edge ? CL : SL;
-    const int nT = is_edge ? C->n_corner_last : C->n_surf_last;
-    const int t0 = blockIdx.y * NN_TC;
-    if (t0 >= nT) return;
-    const int tn = min(NN_TC, nT - t0);
-    for (int i = threadIdx.x; i < tn; i += 64 * NN_PARTS) tx[i] = T.x[t0 + i], ty[i] = T.y[t0 + i], tz[i] = T.z[t0 + i];
-    __syncthreads();
-    const int ql = threadIdx.x & 63, partq = threadIdx.x >> 6;
-    const int qi = qbase + ql;
-    unsigned long long best = ~0ull;
-    if (qi < nq) {
-        double x7[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-        float sel[3];
-        transform_to_start(x7, Q.x[qi], Q.y[qi], Q.z[qi], sel);
-        const int per = (tn + NN_PARTS - 1) / NN_PARTS;
-        const int b0 = partq * per, b1 = min(tn, b0 + per);
-        float bd = 3.4e38f;
-        int bi = -1;
-#pragma unroll 4
-        for (int t = b0; t < b1; ++t) {
-            const float dx = sel[0] - tx[t], dy = sel[1] - ty[t], dz = sel[2] - tz[t];
-            float d = dx * dx;  // FLANN L2_Simple<float>
-            d += dy * dy;
-            d += dz * dz;
-            if (d < bd) bd = d, bi = t;  // ascending t: the first (lowest index) of equal distances is kept
-        }
-        if (bi >= 0) best = make_key(bd, static_cast<unsigned>(t0 + bi));
-    }
-    red[partq][ql] = best;
-    __syncthreads();
-    if (partq == 0 && qi < nq) {
-        unsigned long long b = red[0][ql];
-        for (int p = 1; p < NN_PARTS; ++p) b = red[p][ql] < b ? red[p][ql] : b;
-        const int slot = is_edge ? qi : ns + qi;
-        if (slot < slot_cap) part[(size_t)slot * nch + blockIdx.y] = b;
-    }
+// NN(1) index over a target cloud: cells hashed into OD_H buckets, points stored bucket by bucket (counting sort done by the
+// hand-over: count + rank in k_odom_handover, offsets in k_odom_cellscan, placement in k_odom_cellfill), at two cell sizes.  A query
+// looks at the 27 buckets of the cells around it; two cells sharing a bucket only add candidates, every candidate's distance is
+// computed.  A point closer than one cell edge lies in a neighbouring cell on every axis, so if the best candidate is closer than that,
+// it is the exact NN of the whole cloud (ties included: they were all candidates).  Level 0 (1 m cells) answers almost every query;
+// level 1 (5 m cells) covers DISTANCE_SQ_THRESHOLD = 25 (:65): a query it cannot answer has no usable neighbour at all.
+constexpr int OD_H = 8192;
+constexpr int OD_LEVELS = 2;
+__device__ constexpr float OD_INV_CELL[OD_LEVELS] = {1.0f, 0.2f};
+// squared distances below which a level's answer is exact; the margins keep the f32 rounding of the sum and of v * 0.2f clear of the edge
+__device__ constexpr float OD_EXACT_D2[OD_LEVELS] = {0.99f, 24.9f};
+struct CellIndex {
+    const int* start[OD_LEVELS];   // [OD_H + 1]
+    const float4* pts[OD_LEVELS];  // x, y, z, original index (bit pattern)
+};
+__device__ __forceinline__ int od_cell(float v, int level) { return static_cast<int>(floorf(v * OD_INV_CELL[level])); }
+__device__ __forceinline__ unsigned od_hash(int cx, int cy, int cz) {
+    return (static_cast<unsigned>(cx) * 73856093u ^ static_cast<unsigned>(cy) * 19349663u ^ static_cast<unsigned>(cz) * 83492791u) & (OD_H - 1);
 }
-SCAL_KERNEL(64 * NN_PARTS, k_odom_nn)
+__device__ __forceinline__ unsigned od_bucket(float x, float y, float z, int level) { return od_hash(od_cell(x, level), od_cell(y, level), od_cell(z, level)); }
+// best (f32 distance bits, original index) key among the 27 buckets around (sx, sy, sz); called by all 256 threads of a workgroup
+__device__ __forceinline__ unsigned long long od_cell_nn(const int* __restrict__ start, const float4* __restrict__ pts, int level, float sx, float sy, float sz,
+                                                          int* s_beg, int* s_pre, unsigned long long* s_nn) {
+    const int lane = lane_id(), wv = wave_id();
+    if (wv == 0) {
+        int b = 0, cnt = 0;
+        if (lane < 27) {
+            const unsigned h = od_hash(od_cell(sx, level) + lane % 3 - 1, od_cell(sy, level) + (lane / 3) % 3 - 1, od_cell(sz, level) + lane / 9 - 1);
+            b = start[h];
+            cnt = start[h + 1] - b;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        if (lane < 27) s_beg[lane] = b, s_pre[lane + 1] = incl;
+        if (lane == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+    unsigned long long best = ~0ull;
+    const int n_cand = s_pre[27];
+    for (int m = threadIdx.x; m < n_cand; m += 256) {
+        int j = 0;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1)
+            if (j + o <= 26 && s_pre[j + o] <= m) j += o;
+        const float4 p = pts[s_beg[j] + (m - s_pre[j])];
+        const float dx = sx - p.x, dy = sy - p.y, dz = sz - p.z;
+        float d = dx * dx;  // FLANN L2_Simple<float>
+        d += dy * dy;
+        d += dz * dz;
+        best = min(best, make_key(d, __float_as_uint(p.w)));
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) s_nn[wv] = best;
+    __syncthreads();
+    best = min(min(s_nn[0], s_nn[1]), min(s_nn[2], s_nn[3]));
+    __syncthreads();  // the LDS arrays may be rewritten by the next level
+    return best;
+}
 
 // one wave per query
 __device__ __forceinline__ void k_odom_assoc_body(const CSoA4& sharp, const CSoA4& flat, const CSoA4& CL, const CSoA4& SL, const LMState* __restrict__ st, OdomCounters* C,
-                                                    int outer, const FactorSoA& f, int nch, const unsigned long long* __restrict__ part,
+                                                    int outer, const FactorSoA& f, const CellIndex& ci_corner, const CellIndex& ci_surf,
                                                     const int* __restrict__ ring_tab) {
     if (!C->enable) return;
     const int ns = C->n_sharp, nf = C->n_flat;
@@ -135,14 +138,41 @@ __device__ __forceinline__ void k_odom_assoc_body(const CSoA4& sharp, const CSoA
     transform_to_start(x7, ox, oy, oz, sel);
     const float sx = sel[0], sy = sel[1], sz = sel[2];
 
-    // ---- NN(1): minimum over the per-chunk minima of k_odom_nn (exact argmin of FLANN's L2_Simple<float>, ties -> lower index)
-    unsigned long long best = ~0ull;
-    const int used = (nT + NN_TC - 1) / NN_TC;
-    for (int ch = lane; ch < used; ch += 64) {
-        const unsigned long long k = part[(size_t)q * nch + ch];
-        best = k < best ? k : best;
+    // ---- NN(1) (:302, :390): exact argmin of FLANN's L2_Simple<float> over the target cloud, ties -> lower index (see CellIndex)
+    __shared__ int s_beg[27], s_pre[28];
+    __shared__ unsigned long long s_nn[4];
+    const CellIndex& ci = is_edge ? ci_corner : ci_surf;
+    unsigned long long best = od_cell_nn(ci.start[0], ci.pts[0], 0, sx, sy, sz, s_beg, s_pre, s_nn);
+    auto dist_of = [](unsigned long long k) { return __uint_as_float(static_cast<unsigned>(k >> 32)); };
+    if (best == ~0ull || !(dist_of(best) < OD_EXACT_D2[0])) {  // uniform branches: one query per workgroup
+        best = od_cell_nn(ci.start[1], ci.pts[1], 1, sx, sy, sz, s_beg, s_pre, s_nn);
+        if (best == ~0ull || !(dist_of(best) < OD_EXACT_D2[1])) {
+            // nothing certified within 5 m: the answer only matters if some point's f32 distance lands in [24.9, 25) - the whole cloud
+            // decides, four independent loads per thread and step
+            best = ~0ull;
+            for (int t0 = threadIdx.x; t0 < nT; t0 += 1024) {
+                float txx[4], tyy[4], tzz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = min(t0 + 256 * u, nT - 1);
+                    txx[u] = T.x[t], tyy[u] = T.y[t], tzz[u] = T.z[t];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = min(t0 + 256 * u, nT - 1);  // a clamped repeat of the last point cannot change the minimum
+                    const float dx = sx - txx[u], dy = sy - tyy[u], dz = sz - tzz[u];
+                    float d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    best = min(best, make_key(d, static_cast<unsigned>(t)));
+                }
+            }
+            best = wave_min_u64(best);
+            if (lane == 0) s_nn[wv] = best;
+            __syncthreads();
+            best = min(min(s_nn[0], s_nn[1]), min(s_nn[2], s_nn[3]));
+        }
     }
-    best = wave_min_u64(best);
     int valid = 0;
     int kind = is_edge ? 0 : 1;
     double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
@@ -285,6 +315,8 @@ struct HandoverArgs {
     const LMState* st;  // the solved state goes to the host slot from here (no launch of its own)
     LMState* host_st;
     const LMSync* sync; // an abandoned solve (any workgroup, this step or one queued in front of it) reaches the host as termination 5
+    int* cell_cnt[2][OD_LEVELS];   // [OD_H] per target cloud and level, zero on entry (k_odom_cellscan leaves them so)
+    int* cell_rank[2][OD_LEVELS];  // arrival order of point i within its bucket
 };
 __device__ __forceinline__ void k_odom_handover_body(const HandoverArgs& a) {
     int b = blockIdx.x;
@@ -305,19 +337,102 @@ __device__ __forceinline__ void k_odom_handover_body(const HandoverArgs& a) {
     const int n = min(*a.d_n[k], a.cap[k]);
     const int i = b * 256 + threadIdx.x;
     if (i == 0) *a.d_n_out[k] = n;
+    if (b * 256 >= n) return;
+    const int lane = lane_id();
+    float x = 0, y = 0, z = 0;
     if (i < n) {
         const float w = in.w[i];
-        out.x[i] = in.x[i], out.y[i] = in.y[i], out.z[i] = in.z[i], out.w[i] = w;
+        x = in.x[i], y = in.y[i], z = in.z[i];
+        out.x[i] = x, out.y[i] = y, out.z[i] = z, out.w[i] = w;
         const int r = min(max(static_cast<int>(w), 0), RING_TAB - 1);
         // consecutive points mostly share a ring: only ring boundaries (and the wave's first lane) touch the tables
         const int rp = __shfl_up(r, 1, 64);
         const int rn = __shfl_down(r, 1, 64);
-        const int lane = lane_id();
         if (lane == 0 || rp != r) atomicMin(&first_idx[r], i);
         if (lane == 63 || rn != r || i == n - 1) atomicMax(&last_idx[r], i);
     }
+    // bucket counts: neighbours along the cloud mostly share a cell, so one atomic per run of equal buckets in the wave
+#pragma unroll
+    for (int l = 0; l < OD_LEVELS; ++l) {
+        const unsigned h = i < n ? od_bucket(x, y, z, l) : 0xffffffffu;
+        const unsigned hp = __shfl_up(h, 1, 64);
+        const unsigned long long heads = __ballot(lane == 0 || hp != h);
+        const int head = 63 - __clzll(heads & (~0ull >> (63 - lane)));           // start of this lane's run
+        const unsigned long long above = lane == 63 ? 0ull : heads & (~0ull << (lane + 1));
+        const int next = above ? __ffsll(static_cast<long long>(above)) - 1 : 64;  // start of the next run
+        int base = 0;
+        if (lane == head && i < n) {
+            // the run ends at the next head; the tail of the last run may hold lanes past n, which carry the sentinel and form their own run
+            base = atomicAdd(&a.cell_cnt[k][l][h], next - head);
+        }
+        base = __shfl(base, head, 64);
+        if (i < n) a.cell_rank[k][l][i] = base + (lane - head);
+    }
 }
 SCAL_KERNEL(256, k_odom_handover)
+// bucket offsets, one block per table (cloud x level): exclusive scan of the counts, which are left zero for the next hand-over
+constexpr int OD_START_STRIDE = OD_H + 4;
+__device__ __forceinline__ void k_odom_cellscan_body(int* cnt_all, int* start_all) {
+    constexpr int PER = OD_H / 1024;
+    static_assert(PER % 4 == 0, "int4 loads");
+    int* cnt = cnt_all + blockIdx.x * OD_H;
+    int* start = start_all + blockIdx.x * OD_START_STRIDE;
+    __shared__ int s_w[16];
+    int v[PER];
+    int4* c4 = reinterpret_cast<int4*>(cnt + threadIdx.x * PER);
+    int sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER / 4; ++u) {
+        const int4 q = c4[u];
+        v[4 * u] = q.x, v[4 * u + 1] = q.y, v[4 * u + 2] = q.z, v[4 * u + 3] = q.w;
+        sum += q.x + q.y + q.z + q.w;
+        c4[u] = make_int4(0, 0, 0, 0);
+    }
+    int incl = sum;
+    const int lane = lane_id(), wv = wave_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wv; ++w) base += s_w[w];
+    int4* s4 = reinterpret_cast<int4*>(start + threadIdx.x * PER);
+#pragma unroll
+    for (int u = 0; u < PER / 4; ++u) {
+        int4 o;
+        o.x = base, base += v[4 * u];
+        o.y = base, base += v[4 * u + 1];
+        o.z = base, base += v[4 * u + 2];
+        o.w = base, base += v[4 * u + 3];
+        s4[u] = o;
+    }
+    if (threadIdx.x == 1023) start[OD_H] = base;
+}
+SCAL_KERNEL(1024, k_odom_cellscan)
+// places the points of both target clouds bucket by bucket; same block layout as k_odom_handover
+struct CellFillArgs {
+    CSoA4 in[2];        // corner_last, surf_last as the hand-over wrote them
+    const int* d_n[2];
+    const int* rank[2][OD_LEVELS];
+    const int* start[2][OD_LEVELS];
+    float4* pts[2][OD_LEVELS];
+    int nb0;
+};
+__device__ __forceinline__ void k_odom_cellfill_body(const CellFillArgs& a) {
+    int b = blockIdx.x;
+    const int k = b < a.nb0 ? 0 : 1;
+    if (k) b -= a.nb0;
+    const int i = b * 256 + threadIdx.x;
+    if (i >= *a.d_n[k]) return;
+    const float x = a.in[k].x[i], y = a.in[k].y[i], z = a.in[k].z[i];
+    const float4 rec = make_float4(x, y, z, __uint_as_float(static_cast<unsigned>(i)));
+#pragma unroll
+    for (int l = 0; l < OD_LEVELS; ++l) a.pts[k][l][a.start[k][l][od_bucket(x, y, z, l)] + a.rank[k][l][i]] = rec;
+}
+SCAL_KERNEL(256, k_odom_cellfill)
 // Start of a device-resident step in ONE launch: refreshes the per-scan counters and copies the four feature clouds of a
 // features context (sharp / flat / lessSharp as xyzi records, lessFlat as SoA) into this context's SoA clouds.
 // Block ranges: [0,nbs) sharp, [nbs,2nbs) flat, [2nbs,2nbs+nbf) lessSharp, the rest lessFlat.
@@ -400,8 +515,18 @@ struct scal_odom {
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
     DevBuf<LMSync> lm_sync;
-    DevBuf<unsigned long long> nn_part;
-    int nch = 1;
+    DevBuf<int> cell_cnt, cell_start, cell_rank;  // NN(1) bucket index of corner_last | surf_last (see CellIndex)
+    DevBuf<float4> cell_pts;
+    // tables are laid out [cloud][level]; point arrays [level][corner | surf]
+    int* cell_cnt_of(int k, int l) const { return cell_cnt.p + (k * OD_LEVELS + l) * OD_H; }
+    int* cell_start_of(int k, int l) const { return cell_start.p + (k * OD_LEVELS + l) * OD_START_STRIDE; }
+    int* cell_rank_of(int k, int l) const { return cell_rank.p + (size_t)l * (feat_cap + cap) + (k ? feat_cap : 0); }
+    float4* cell_pts_of(int k, int l) const { return cell_pts.p + (size_t)l * (feat_cap + cap) + (k ? feat_cap : 0); }
+    CellIndex cell_index(int k) const {
+        CellIndex ci;
+        for (int l = 0; l < OD_LEVELS; ++l) ci.start[l] = cell_start_of(k, l), ci.pts[l] = cell_pts_of(k, l);
+        return ci;
+    }
     DevBuf<int> ring_tab;  // 2 sets of [corner first | corner last | surf first | surf last] x RING_TAB (double-buffered)
     int tab_cur = 0;       // set read by this scan's association
     DevBuf<LMState> d_st;
@@ -441,8 +566,8 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
     A(c->fcp.alloc(3 * (size_t)c->slot_cap)); A(c->fpa.alloc(3 * (size_t)c->slot_cap)); A(c->fpb.alloc(3 * (size_t)c->slot_cap));
     A(c->partials.alloc(LM_PARTIAL_WORDS));
     A(c->lm_sync.alloc(1));
-    c->nch = std::max(1, div_up(c->cap, NN_TC));
-    A(c->nn_part.alloc((size_t)c->slot_cap * c->nch));
+    A(c->cell_cnt.alloc(2 * OD_LEVELS * OD_H)); A(c->cell_start.alloc(2 * OD_LEVELS * OD_START_STRIDE));
+    A(c->cell_rank.alloc(OD_LEVELS * ((size_t)c->feat_cap + c->cap))); A(c->cell_pts.alloc(OD_LEVELS * ((size_t)c->feat_cap + c->cap)));
     A(c->ring_tab.alloc(8 * RING_TAB));
     A(c->bl_live.alloc(c->slot_cap)); A(c->bl_rowoff.alloc(c->slot_cap + 1)); A(c->bl_counts.alloc(2)); A(c->h_counts.alloc(2)); A(c->h_x7.alloc(8));
     A(c->d_x7.alloc(8)); A(c->d_res.alloc(3 * (size_t)c->slot_cap)); A(c->d_jac.alloc(21 * (size_t)c->slot_cap)); A(c->d_blocks.alloc(10 * (size_t)c->slot_cap));
@@ -458,6 +583,8 @@ extern "C" int scal_odom_create(const scal_odom_config* cfg, scal_odom_t** out) 
         if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
         if (rc == SCAL_OK && op_memset_async(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && op_memset_async(c->d_C.p, 0, sizeof(OdomCounters), c->stream) != hipSuccess) rc = SCAL_E_HIP;
+        if (rc == SCAL_OK) rc = c->cell_cnt.zero(c->stream);
+        if (rc == SCAL_OK) rc = c->cell_start.zero(c->stream);
         SCAL_LAUNCH("k_odom_init_pose", k_odom_init_pose, dim3(1), dim3(256), 0, c->stream, c->d_st.p, c->ring_tab.p);
         if (rc == SCAL_OK && op_stream_synchronize(c->stream) != hipSuccess) rc = SCAL_E_HIP;
     }
@@ -497,7 +624,7 @@ void o_rot(const double* q, const double* v, double* o) {
     o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
 }
 
-int launch_handover(scal_odom* c, int slot);
+int launch_handover(scal_odom* c, int slot, hipEvent_t ev);
 // inputs already in sharp / flat / less_sharp / less_flat with counts in d_C
 int odom_enqueue(scal_odom* c) {
     hipStream_t s = c->stream;
@@ -511,27 +638,21 @@ int odom_enqueue(scal_odom* c) {
     if (solve) {
         for (int outer = 0; outer < 2; ++outer) {  // :278
             {
-                // sharp and flat tiles are laid out back to back; +2 tiles of slack for the two partial tiles
-                SCAL_LAUNCH("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
-                                   c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
-            }
-            {
                 SCAL_LAUNCH("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(),
-                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
+                                   c->corner_last.cv(), c->surf_last.cv(), st, C, outer, F, c->cell_index(0), c->cell_index(1), c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
             }
             {
                                 launch_lm_solve(s, F, &C->n_slots, st, &C->enable, c->partials.p, c->lm_sync.p, outer, nullptr, LMNoHook(), LMNoHook(), "k_lm_solve_odom");
             }
         }
     }
-    SCAL_TRY(launch_handover(c, slot));
-    SCAL_HIP(op_event_record(c->ev[slot], s));
+    SCAL_TRY(launch_handover(c, slot, c->ev[slot]));
     c->pending.push_back({slot, solve});
     return SCAL_OK;
 }
 
 // hand-over (:554-563): the current lessSharp / lessFlat clouds become the next scan's targets; the state goes to the host slot
-int launch_handover(scal_odom* c, int slot) {
+int launch_handover(scal_odom* c, int slot, hipEvent_t ev) {
     hipStream_t s = c->stream;
     OdomCounters* C = c->d_C.p;
     LMState* st = c->d_st.p;
@@ -546,8 +667,21 @@ int launch_handover(scal_odom* c, int slot) {
         h.tab_write = c->ring_tab.p + (c->tab_cur ^ 1) * 4 * RING_TAB;
         h.tab_reset = c->ring_tab.p + c->tab_cur * 4 * RING_TAB;
         h.st = st, h.host_st = c->h_st.p + slot, h.sync = c->lm_sync.p;
-        SCAL_LAUNCH("k_odom_handover", k_odom_handover, dim3(h.nb0 + std::max(1, div_up(c->cap, 256))), dim3(256), 0, s, h);
+        for (int k = 0; k < 2; ++k)
+            for (int l = 0; l < OD_LEVELS; ++l) h.cell_cnt[k][l] = c->cell_cnt_of(k, l), h.cell_rank[k][l] = c->cell_rank_of(k, l);
+        const dim3 grid(h.nb0 + std::max(1, div_up(c->cap, 256)));
+        SCAL_LAUNCH("k_odom_handover", k_odom_handover, grid, dim3(256), 0, s, h);
         c->tab_cur ^= 1;
+        // the pose is out with the hand-over; the bucket index of the new targets is only needed by the next step's association
+        if (ev) SCAL_HIP(op_event_record(ev, s));
+        SCAL_LAUNCH("k_odom_cellscan", k_odom_cellscan, dim3(2 * OD_LEVELS), dim3(1024), 0, s, c->cell_cnt.p, c->cell_start.p);
+        CellFillArgs f;
+        f.in[0] = c->corner_last.cv(), f.in[1] = c->surf_last.cv();
+        f.d_n[0] = &C->n_corner_last, f.d_n[1] = &C->n_surf_last;
+        for (int k = 0; k < 2; ++k)
+            for (int l = 0; l < OD_LEVELS; ++l) f.rank[k][l] = c->cell_rank_of(k, l), f.start[k][l] = c->cell_start_of(k, l), f.pts[k][l] = c->cell_pts_of(k, l);
+        f.nb0 = h.nb0;
+        SCAL_LAUNCH("k_odom_cellfill", k_odom_cellfill, grid, dim3(256), 0, s, f);
     }
     SCAL_HIP(hipGetLastError());
     return SCAL_OK;
@@ -756,10 +890,8 @@ extern "C" int scal_odom_associate(scal_odom_t* c, const double* q_last_curr, co
     LMState* st = c->d_st.p;
     FactorSoA F = c->factors();
     SCAL_TRY(odom_set_pose(c, q_last_curr, t_last_curr));
-    SCAL_LAUNCH("k_odom_nn", k_odom_nn, dim3(div_up(c->slot_cap, NN_QT) + 2, c->nch), dim3(64 * NN_PARTS), 0, s, c->sharp.cv(), c->flat.cv(),
-                     c->corner_last.cv(), c->surf_last.cv(), st, C, c->slot_cap, c->nch, c->nn_part.p);
     SCAL_LAUNCH("k_odom_assoc", k_odom_assoc, dim3(std::max(1, c->slot_cap)), dim3(256), 0, s, c->sharp.cv(), c->flat.cv(), c->corner_last.cv(),
-                     c->surf_last.cv(), st, C, std::min(c->outer_next, 1), F, c->nch, c->nn_part.p, c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
+                     c->surf_last.cv(), st, C, std::min(c->outer_next, 1), F, c->cell_index(0), c->cell_index(1), c->ring_tab.p + c->tab_cur * 4 * RING_TAB);
     c->outer_next++;
     SCAL_LAUNCH("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
     SCAL_HIP(hipGetLastError());
@@ -827,8 +959,7 @@ extern "C" int scal_odom_adapter_finish(scal_odom_t* c, const double* q_last_cur
     SCAL_TRY(odom_set_pose(c, q_last_curr, t_last_curr));  // para_q / para_t of the next scan's initial guess
     const int slot = c->next_slot;
     c->next_slot = (c->next_slot + 1) % scal_odom::MAX_STEPS;
-    SCAL_TRY(launch_handover(c, slot));
-    SCAL_HIP(op_event_record(c->ev[slot], c->stream));
+    SCAL_TRY(launch_handover(c, slot, c->ev[slot]));
     c->pending.push_back({slot, c->adapter_solve});
     double q_lc[4], t_lc[3];
     return odom_collect(c, q_lc, t_lc, q_w_curr, t_w_curr, nullptr);  // pose integration (:504-505)
