@@ -769,23 +769,25 @@ static __global__ void __launch_bounds__(LM_THREADS) k_lm_solve(Batch<typename L
     batch_call<typename LMSolveKernel<Pre, Post>::tag>(b.p[blockIdx.z], std::make_index_sequence<LMSolveKernel<Pre, Post>::traits::n>());
 }
 // the same code compiled for TWO workgroups per CU (256 instead of 426 registers per lane, the rest spilled): 512 resident workgroups
-// on the device, so that the solves of more than LM_SEQS_PER_LAUNCH sequences can share a launch.  Same arithmetic, same results.
+// on the device, for launches of more than LM_WGS_PER_LAUNCH workgroups.  Same arithmetic, same results.
 template <class Pre, class Post>
 static __global__ void __launch_bounds__(LM_THREADS, 2) k_lm_solve_slim(Batch<typename LMSolveKernel<Pre, Post>::traits::pack> b) {
     batch_call<typename LMSolveKernel<Pre, Post>::tag>(b.p[blockIdx.z], std::make_index_sequence<LMSolveKernel<Pre, Post>::traits::n>());
 }
 // The solve keeps its <= LM_GRID workgroups per sequence spinning on each other's partial sums, and at 426 registers per lane only
 // ONE of its workgroups fits a CU: 256 resident workgroups on the whole device.  Stage B's and stage C's solves run on different
-// streams and may overlap, so the full-register kernel carries at most LM_SEQS_PER_LAUNCH = 256 / (2 x 48) = 2 sequences per launch;
-// a batch of more goes to the two-workgroups-per-CU build of the same code (512 resident workgroups: 2 x 4 x 48 fit).
-// (Tried first: all solves ordered behind each other across the two streams with an event chain - it welds stage B's and stage C's
-// chains into one, 5,500 scans/s for four sequences; two launches of two sequences each - 5,700.)
-constexpr int LM_SEQS_PER_LAUNCH = 256 / (2 * LM_GRID);
-static_assert(LM_SEQS_PER_LAUNCH >= 1 && 2 * BATCH_MAX * LM_GRID <= 512, "LM_GRID too large for two overlapping solves");
+// streams and may overlap, so one launch of the full-register kernel may bring at most LM_WGS_PER_LAUNCH = 128 workgroups (two
+// sequences of stage C's 48, four of stage B's 9); anything larger goes to the two-workgroups-per-CU build of the same code (512
+// resident workgroups).  (32 workgroups per solve, so that four of stage C's fit: their solves drop from 77 to 59 us, but four
+// sequences run at 5,550 scans/s instead of 6,000 - 164 CUs held by spinning full-register workgroups starve the other stages.)  (Tried first: all solves ordered behind each other across the two streams with an event chain - it welds
+// stage B's and stage C's chains into one, 5,500 scans/s for four sequences; two launches of two sequences each - 5,700; the slim
+// build for every batch of more than two sequences of 48 workgroups - 6,000, its solve taking 77 us against 45.)
+constexpr int LM_WGS_PER_LAUNCH = 128;
+static_assert(2 * BATCH_MAX * LM_GRID <= 512, "two overlapping batches of solves must fit the device at two workgroups per CU");
 template <class Pre, class Post>
 static hipError_t k_lm_solve_launch(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) {
     using P = typename LMSolveKernel<Pre, Post>::traits::pack;
-    if (n <= LM_SEQS_PER_LAUNCH) return batch_launch_impl<P>(k_lm_solve<Pre, Post>, name, grid, block, lds, s, n, packs);
+    if (n * static_cast<int>(grid.x) <= LM_WGS_PER_LAUNCH) return batch_launch_impl<P>(k_lm_solve<Pre, Post>, name, grid, block, lds, s, n, packs);
     return batch_launch_impl<P>(k_lm_solve_slim<Pre, Post>, name, grid, block, lds, s, n, packs);
 }
 

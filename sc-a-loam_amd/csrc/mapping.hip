@@ -352,57 +352,53 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int2* __res
     }
 }
 
-// symmetric 3x3 eigen-decomposition by cyclic Jacobi (stands in for Eigen::SelfAdjointEigenSolver, :606);
-// returns the largest eigenvalue's unit eigenvector and the two largest eigenvalues
+// Largest eigenpair and second-largest eigenvalue of a symmetric positive semi-definite 3x3 matrix (stands in for
+// Eigen::SelfAdjointEigenSolver, :606-612): eigenvalues in closed form (trigonometric solution of the characteristic cubic of the
+// shifted, scaled matrix), the eigenvector as the largest cross product of two rows of A - w I.  One sqrt, one reciprocal, one acos,
+// two cos, one more sqrt and division on the critical path - a cyclic Jacobi iteration to 1e-20 (rounds 1-2) took 18 rotations of two
+// square roots and three divisions each and was 10-16 us of k_assoc_fit's 17.  Where the reference goes on (largest > 3 x second, :612) the
+// largest eigenvalue is simple and well separated, which is where both the closed form and the cross product are accurate to rounding.
 __device__ __forceinline__ void eig3_largest(double a00, double a01, double a02, double a11, double a12, double a22, double* w1, double* w2,
                                              double* dir) {
-    double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
-    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-        const double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
-        if (off <= 1e-40 * diag || off == 0.0) break;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int q = p + 1; q < 3; ++q) {
-                if (a[p][q] == 0.0) continue;
-                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = a[k][p], akq = a[k][q];
-                    a[k][p] = c * akp - s * akq;
-                    a[k][q] = s * akp + c * akq;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = a[p][k], aqk = a[q][k];
-                    a[p][k] = c * apk - s * aqk;
-                    a[q][k] = s * apk + c * aqk;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = v[k][p], vkq = v[k][q];
-                    v[k][p] = c * vkp - s * vkq;
-                    v[k][q] = s * vkp + c * vkq;
-                }
-            }
+    const double p1 = a01 * a01 + a02 * a02 + a12 * a12;
+    const double q = (a00 + a11 + a22) / 3.0;
+    const double b00 = a00 - q, b11 = a11 - q, b22 = a22 - q;
+    const double p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * p1;
+    dir[0] = 1.0, dir[1] = 0.0, dir[2] = 0.0;
+    if (!(p2 > 0.0)) {  // a multiple of the identity (or not a number): no direction stands out
+        *w1 = q, *w2 = q;
+        return;
     }
-    // ascending order of the diagonal; ties keep the lower index first (as a stable sort of three)
-    int o0 = 0, o1 = 1, o2 = 2;
-    if (a[o1][o1] < a[o0][o0]) { int t = o0; o0 = o1; o1 = t; }
-    if (a[o2][o2] < a[o1][o1]) { int t = o1; o1 = o2; o2 = t; }
-    if (a[o1][o1] < a[o0][o0]) { int t = o0; o0 = o1; o1 = t; }
-    *w1 = a[o1][o1];
-    *w2 = a[o2][o2];
-    double n = sqrt(v[0][o2] * v[0][o2] + v[1][o2] * v[1][o2] + v[2][o2] * v[2][o2]);
-    dir[0] = v[0][o2] / n, dir[1] = v[1][o2] / n, dir[2] = v[2][o2] / n;
+    const double p = sqrt(p2 / 6.0);
+    const double ip = 1.0 / p;
+    const double c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+    double r = 0.5 * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+    r = fmin(1.0, fmax(-1.0, r));
+    const double phi = acos(r) / 3.0;
+    const double l3 = q + 2.0 * p * cos(phi);                          // largest
+    const double l1 = q + 2.0 * p * cos(phi + 2.0943951023931953);     // smallest (phi + 2 pi / 3)
+    *w2 = l3;
+    *w1 = 3.0 * q - l1 - l3;
+    const double r0[3] = {a00 - l3, a01, a02}, r1[3] = {a01, a11 - l3, a12}, r2[3] = {a02, a12, a22 - l3};
+    const double x0[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+    const double x1[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+    const double x2[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    const double n0 = x0[0] * x0[0] + x0[1] * x0[1] + x0[2] * x0[2];
+    const double n1 = x1[0] * x1[0] + x1[1] * x1[1] + x1[2] * x1[2];
+    const double n2 = x2[0] * x2[0] + x2[1] * x2[1] + x2[2] * x2[2];
+    const bool use1 = n1 > n0 && n1 >= n2, use2 = n2 > n0 && n2 > n1;
+    const double vx = use2 ? x2[0] : (use1 ? x1[0] : x0[0]), vy = use2 ? x2[1] : (use1 ? x1[1] : x0[1]), vz = use2 ? x2[2] : (use1 ? x1[2] : x0[2]);
+    const double nn = use2 ? n2 : (use1 ? n1 : n0);
+    if (nn > 0.0) {
+        const double n = sqrt(nn);
+        dir[0] = vx / n, dir[1] = vy / n, dir[2] = vz / n;
+    }
 }
 
 // least squares A n = b for a 5x3 A by column-pivoted Householder QR (stands in for colPivHouseholderQr().solve, :664)
-__device__ __forceinline__ void colpiv_qr_5x3(double A[5][3], double b[5], double x[3]) {
+// Every index is a compile-time constant after unrolling (column swaps, the permutation and the rank-limited back substitution are
+// selects): the arrays stay in registers.  With run-time indices they lived in scratch memory, 7 of k_assoc_fit's 14 us.
+__device__ __forceinline__ void colpiv_qr_5x3(double (&A)[5][3], double (&b)[5], double (&x)[3]) {
     int perm[3] = {0, 1, 2};
     double rdiag[3] = {0, 0, 0};
     double maxpivot = 0;
@@ -410,31 +406,39 @@ __device__ __forceinline__ void colpiv_qr_5x3(double A[5][3], double b[5], doubl
     for (int k = 0; k < 3; ++k) {
         int best = k;
         double bestn = -1;
+#pragma unroll
         for (int j = k; j < 3; ++j) {
             double s = 0;
+#pragma unroll
             for (int i = k; i < 5; ++i) s += A[i][j] * A[i][j];
             if (s > bestn) bestn = s, best = j;
         }
-        if (best != k) {
+#pragma unroll
+        for (int j = k + 1; j < 3; ++j) {
+            const bool sw = best == j;
+#pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const double t = A[i][k];
-                A[i][k] = A[i][best];
-                A[i][best] = t;
+                A[i][k] = sw ? A[i][j] : t;
+                A[i][j] = sw ? t : A[i][j];
             }
             const int t = perm[k];
-            perm[k] = perm[best];
-            perm[best] = t;
+            perm[k] = sw ? perm[j] : t;
+            perm[j] = sw ? t : perm[j];
         }
         double tail = 0;
+#pragma unroll
         for (int i = k + 1; i < 5; ++i) tail += A[i][k] * A[i][k];
         const double c0 = A[k][k];
         double tau, beta;
         if (tail <= 2.2250738585072014e-308) {
             tau = 0, beta = c0;
+#pragma unroll
             for (int i = k + 1; i < 5; ++i) A[i][k] = 0;
         } else {
             beta = sqrt(c0 * c0 + tail);
             if (c0 >= 0) beta = -beta;
+#pragma unroll
             for (int i = k + 1; i < 5; ++i) A[i][k] /= (c0 - beta);
             tau = (beta - c0) / beta;
         }
@@ -442,32 +446,46 @@ __device__ __forceinline__ void colpiv_qr_5x3(double A[5][3], double b[5], doubl
         rdiag[k] = beta;
         maxpivot = fmax(maxpivot, fabs(beta));
         if (tau != 0) {
+#pragma unroll
             for (int c = k + 1; c < 3; ++c) {
                 double s = A[k][c];
+#pragma unroll
                 for (int i = k + 1; i < 5; ++i) s += A[i][k] * A[i][c];
                 s *= tau;
                 A[k][c] -= s;
+#pragma unroll
                 for (int i = k + 1; i < 5; ++i) A[i][c] -= s * A[i][k];
             }
             double s = b[k];
+#pragma unroll
             for (int i = k + 1; i < 5; ++i) s += A[i][k] * b[i];
             s *= tau;
             b[k] -= s;
+#pragma unroll
             for (int i = k + 1; i < 5; ++i) b[i] -= s * A[i][k];
         }
     }
     const double thr = 2.220446049250313e-16 * 3.0 * maxpivot;
     int rank = 0;
+#pragma unroll
     for (int k = 0; k < 3; ++k)
         if (fabs(rdiag[k]) > thr) ++rank;
     double y[3] = {0, 0, 0};
-    for (int k = rank - 1; k >= 0; --k) {
-        double s = b[k];
-        for (int c = k + 1; c < rank; ++c) s -= A[k][c] * y[c];
-        y[k] = s / A[k][k];
-    }
+#pragma unroll
+    for (int k = 2; k >= 0; --k)
+        if (k < rank) {
+            double s = b[k];
+#pragma unroll
+            for (int c = k + 1; c < 3; ++c)
+                if (c < rank) s -= A[k][c] * y[c];
+            y[k] = s / A[k][k];
+        }
     x[0] = x[1] = x[2] = 0;
-    for (int k = 0; k < 3; ++k) x[perm[k]] = y[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (perm[k] == d) x[d] = y[k];
 }
 
 // pointAssociateToMap (:155-164): f64 rotate + translate, stored back as f32
@@ -517,7 +535,11 @@ __device__ __forceinline__ void k_assoc_knn_body(const CSoA4& cs, const CSoA4& s
         unsigned long long bk[5];
         int bp[5];
         const GridPts g = is_edge ? cg : sg;
+        if (lane == 0 && i == 0) SCAL_STAMP(28);
+        if (lane == 0 && i == nc + 4) SCAL_STAMP(30);
         knn5_wave(mp, is_edge ? ccell : scell, g, sel[0], sel[1], sel[2], bk, bp);
+        if (lane == 0 && i == 0) SCAL_STAMP(29);
+        if (lane == 0 && i == nc + 4) SCAL_STAMP(31);
         // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
         int mine = bp[0];
 #pragma unroll
@@ -612,7 +634,12 @@ __device__ __forceinline__ void k_assoc_fit_body(const AssocFit& fit, const MapS
     if (S->abort || !fit.C->solve_on) return;
     const int nc = fit.C->n_corner_stack, ns = fit.C->n_surf_stack;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int surf_block = nc / 64 + 1;
+    if (threadIdx.x == 0 && blockIdx.x == 0) SCAL_STAMP(24);
+    if (threadIdx.x == 0 && static_cast<int>(blockIdx.x) == surf_block) SCAL_STAMP(26);
     if (i < nc + ns && i < fit.f.cap) fit.fit(i, nc);
+    if (threadIdx.x == 0 && blockIdx.x == 0) SCAL_STAMP(25);
+    if (threadIdx.x == 0 && static_cast<int>(blockIdx.x) == surf_block) SCAL_STAMP(27);
 }
 SCAL_KERNEL(64, k_assoc_fit)
 

@@ -1,4 +1,5 @@
-"""Development aid: per-round section timings of the map's k_lm_solve (library built with `make STAMPS=1`)."""
+"""Development aid: section timings inside k_lm_solve_map's rounds (library built with `make STAMPS=1`, SCALOAM_LIB pointing at it).
+Sections per round: evaluate | wave reduce + publish | collect (poll) | sum of partials | serial trust-region step."""
 import ctypes, sys, os
 import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -7,19 +8,26 @@ sys.path.insert(0, os.path.join(HERE, 'synth'))
 import scaloam as S
 import scansynth
 lib = S.lib()
-world = scansynth.World(scansynth.HDL64, 205)
+world = scansynth.World(scansynth.HDL64, 205, threads=16)
 reg = S.ScanRegistration(S.HDL64, 5.0)
-od = S.LaserOdometry()
-mp = S.LaserMapping(0.4, 0.8)
+od, mp = S.LaserOdometry(), S.LaserMapping(0.4, 0.8)
 buf = (ctypes.c_longlong * 32)()
-names = ['eval', 'blockred', 'barrier', 'sum', 'tail']
-for k in range(8):
-    reg.laserCloudHandler(world.scan(k))
-    qlc, tlc, qw, tw, st = od.step_features(reg)
-    qm, tm, ms = mp.process_features(reg, qw, tw)
+names = ['eval', 'reduce+publish', 'collect', 'sum', 'serial']
+for k in range(12):
+    reg.laserCloudHandler(world.scan(10 + k))
+    _, _, qw, tw, _ = od.step_features(reg)
+    _, _, st = mp.process_features(reg, qw, tw)
     lib.scal_debug_stamps_map(buf)
-    st = np.array(buf[:24], dtype=np.int64).reshape(4, 6)
-    if k >= 4:
-        for r in range(4):
-            d = np.diff(st[r]) * 0.01
-            print(k, 'round', r, ' '.join(f'{n}={v:.2f}' for n, v in zip(names, d)), 'total', (st[r, 5] - st[r, 0]) * 0.01, 'blocks', list(ms.n_edge), list(ms.n_plane), list(ms.lm_iters))
+    sv = np.array(buf[:24], dtype=np.int64)
+    ex = np.array(buf[24:32], dtype=np.int64)
+    if k < 4:
+        continue
+    rows = []
+    for r in range(4):
+        s = sv[6 * r:6 * r + 6]
+        nxt = sv[6 * (r + 1)] if r < 3 else s[5]
+        rows.append(' '.join(f'{n}={(s[i + 1] - s[i]) * 0.01:.1f}' for i, n in enumerate(names)) + f' to-next-round={(nxt - s[5]) * 0.01:.1f}')
+    print(f'scan {k}: blocks {st.n_edge[1]}+{st.n_plane[1]} iters {list(st.lm_iters)}')
+    print(f'   k_assoc_fit: edge thread {(ex[1] - ex[0]) * 0.01:.1f} us, plane thread {(ex[3] - ex[2]) * 0.01:.1f} us; knn5_wave: edge query {(ex[5] - ex[4]) * 0.01:.1f} us, plane query {(ex[7] - ex[6]) * 0.01:.1f} us')
+    for r, row in enumerate(rows):
+        print(f'   round {r}: {row}   round total {(sv[6 * r + 5] - sv[6 * r]) * 0.01:.1f} us')
