@@ -73,6 +73,12 @@ struct MapState {
     int n_map[2];                             // points per class in the current map buffers
     int abort;                                // sticky: while set, every kernel of a speculatively queued step returns at once
     int seq;                                  // steps begun
+    // left by a merge write that also binned its output into the NEXT step's cell grid (MergeArgs::prebuild), taken over and
+    // cleared by that step's k_map_begin: points inside the window, "a stored point no longer has the key it was placed under"
+    // (the next merge insert must not trust the order: merge_fail), "a cell overflowed its fixed slice" (MAP_ABORT_GRID)
+    int next_valid[2];
+    int next_unsorted;
+    int next_over;
 };
 
 __device__ __forceinline__ int pack_cube(int ai, int aj, int ak) { return (ai + 512) | ((aj + 512) << 10) | ((ak + 512) << 20); }
@@ -793,6 +799,16 @@ struct MergeArgs {
     int cap;
     int2* grid_cell[2];            // cell headers of the neighbour grid: counts restored to zero here (saves a launch)
     const int* grid_rank[2];
+    // prebuild = 1 (speculative chain): k_merge_write bins every point it writes into the cell grid of the NEXT step (the other grid
+    // set, all zero on entry) and stores the key the point has now - the window of a queued step cannot move (k_map_begin stops the
+    // chain if it would), so the next step starts with its grid, its old keys and its counts in place instead of a 20 us walk over
+    // the map (k_grid_build, which remains for the first queued step behind a general one)
+    int prebuild;
+    int2* next_cell[2];
+    int* next_rank[2];
+    float4* next_pool[2];
+    unsigned long long* next_okeys[2];
+    int next_cap[2];
 };
 // Launch shapes (the map sizes are device words, so the old points are walked with block-stride loops):
 //   k_merge_keys   1024 threads: blocks [0, KB0) old corner points, [KB0, KB0 + KB1) old surf points, then MERGE_CHUNKS blocks
@@ -984,6 +1000,8 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
     if (part == 0)
         for (int q = threadIdx.x; q < n_samp; q += 256) s_samp[q] = nw.samp[q];
     if (threadIdx.x < MERGE_CHUNKS) s_base[threadIdx.x + 1] = nw.blocktot[threadIdx.x];
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
     __syncthreads();
     if (threadIdx.x == 0) {  // inserted runs in front of every 512-block
         int run = 0;
@@ -1002,6 +1020,30 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
     }
     if (b == 0 && part == 0 && threadIdx.x == 0) __hip_atomic_store(&C->n_map_new[cls], n_old + total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     auto pre_at = [&](int t) { return t < n_eff ? nw.pre[t] + s_base[t >> 9] : total; };
+    const MapParams mp = S->mp;
+    bool drifted = false, over = false;
+    int n_in = 0;
+    // the written point o goes into the next step's grid; `placed` = the key it was merged under
+    auto prebuild = [&](int o, float x, float y, float z, int cube, unsigned long long placed) {
+        const unsigned long long k = map_key(mp, a.inv_leaf[cls], x, y, z, cube, C);
+        a.next_okeys[cls][o] = k;
+        drifted |= k != placed;
+        if (cube_valid(mp, cube)) {
+            ++n_in;
+            const int cap = a.next_cap[cls];
+            const int c = grid_cell(mp, x, y, z);
+            const int r = atomicAdd(&a.next_cell[cls][c].x, 1);
+            a.next_rank[cls][o] = r;
+            if (r < cap) {
+                a.next_pool[cls][static_cast<size_t>(c) * cap + r] = make_float4(x, y, z, __int_as_float(o));
+                if (r == 0) a.next_cell[cls][c].y = c * cap;
+            } else {
+                over = true;
+            }
+        } else {
+            a.next_rank[cls][o] = -1;
+        }
+    };
     if (part == 0) {
         for (int i = b * 256 + threadIdx.x; i < n_old; i += nblk * 256) {
             const unsigned long long k = a.okeys[cls][i];
@@ -1036,24 +1078,39 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
                 }
             }
             const float c = static_cast<float>(cnt);
-            out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c, out.cube[o] = in.cube[i];
+            const int cube = in.cube[i];
+            const float ox = ax / c, oy = ay / c, oz = az / c;
+            out.x[o] = ox, out.y[o] = oy, out.z[o] = oz, out.w[o] = aw / c, out.cube[o] = cube;
+            if (a.prebuild) prebuild(o, ox, oy, oz, cube, k);
         }
-        return;
+    } else {
+        const int i = b * 256 + threadIdx.x;
+        if (i < n_eff && (nw.hm[i] & 3) == 1) {  // only heads of inserted runs
+            const unsigned long long k = nw.sorted[i] >> MERGE_IDX_BITS;
+            const int o = nw.lb[i] + pre_at(i);
+            float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
+            int u = i;
+            do {
+                const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
+                ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
+                ++u;
+            } while (!key_nomerge(k) && u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k);
+            const float c = static_cast<float>(u - i);
+            const int cube = nw.cube[static_cast<int>(nw.sorted[i] & (MERGE_MAX - 1))];
+            const float ox = ax / c, oy = ay / c, oz = az / c;
+            out.x[o] = ox, out.y[o] = oy, out.z[o] = oz, out.w[o] = aw / c;
+            out.cube[o] = cube;
+            if (a.prebuild) prebuild(o, ox, oy, oz, cube, k);
+        }
     }
-    const int i = b * 256 + threadIdx.x;
-    if (i >= n_eff || (nw.hm[i] & 3) != 1) return;  // only heads of inserted runs
-    const unsigned long long k = nw.sorted[i] >> MERGE_IDX_BITS;
-    const int o = nw.lb[i] + pre_at(i);
-    float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-    int u = i;
-    do {
-        const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
-        ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
-        ++u;
-    } while (!key_nomerge(k) && u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k);
-    const float c = static_cast<float>(u - i);
-    out.x[o] = ax / c, out.y[o] = ay / c, out.z[o] = az / c, out.w[o] = aw / c;
-    out.cube[o] = nw.cube[static_cast<int>(nw.sorted[i] & (MERGE_MAX - 1))];
+    if (!a.prebuild) return;
+    if (drifted) S->next_unsorted = 1;
+    if (over) S->next_over = 1;
+    // one global atomic per workgroup for the count of points inside the window
+    for (int o = 32; o >= 1; o >>= 1) n_in += __shfl_xor(n_in, o, 64);
+    if (lane_id() == 0 && n_in) atomicAdd(&s_valid, n_in);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&S->next_valid[cls], s_valid);
 }
 
 // What the host reads per step, in pinned memory: state + counters when the pose is ready (1) and after the insertion (2)
@@ -1171,10 +1228,13 @@ struct MapPoseIn {
 // allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
 // raises the sticky abort flag instead - the host then redoes this step on the general path and replays what was queued behind.
 __device__ __forceinline__ void k_map_begin_body(MapState* S, const MapPoseIn& in, LMState* st, int allow_window_change, float inv_line, float inv_plane, MapCounters* C,
-                            int slot_cap) {
+                            int slot_cap, int prebuilt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (S->abort) return;
     C->n_slots = min(C->n_corner_stack + C->n_surf_stack, slot_cap);  // residual-block slots (both stack filters have finished)
+    // what the previous step's merge write left for this one (MergeArgs::prebuild); consumed here whatever happens next
+    const int nv0 = S->next_valid[0], nv1 = S->next_valid[1], drifted = S->next_unsorted, over = S->next_over;
+    S->next_valid[0] = 0, S->next_valid[1] = 0, S->next_unsorted = 0, S->next_over = 0;
     double x0[7];
     m_qmul(S->q_wmap_wodom, in.q_wodom, x0);
     double rt[3];
@@ -1202,6 +1262,14 @@ __device__ __forceinline__ void k_map_begin_body(MapState* S, const MapPoseIn& i
     if (!allow_window_change && !same) {
         S->abort = MAP_ABORT_WINDOW;
         return;
+    }
+    if (prebuilt) {
+        if (over) {  // a cell of the prebuilt grid overflowed its fixed slice: as k_grid_build would have reported it
+            S->abort = MAP_ABORT_GRID;
+            return;
+        }
+        C->n_valid[0] = nv0, C->n_valid[1] = nv1;
+        if (drifted) C->merge_fail = 1;
     }
     S->mp = mp;
     S->have_mp = 1;
@@ -1320,13 +1388,16 @@ struct MapStore {
     MapCloud cloud(int b) { return MapCloud{pts[b].x.p, pts[b].y.p, pts[b].z.p, pts[b].w.p, cube[b].p}; }
 };
 
+// Two sets, one per map buffer parity: set p describes the map in buffers p.  On the speculative chain the merge write that fills
+// buffers p ^ 1 bins its output into set p ^ 1 while it restores the zero invariant of set p.
 struct GridStore {
-    DevBuf<int2> cell;
-    DevBuf<int> rank;
-    DevBuf<float4> g;
-    DevBuf<float4> fixed;  // one-launch build: `fixed_cap` entries per cell
+    DevBuf<int2> cell[2];
+    DevBuf<int> rank[2];
+    DevBuf<float4> g;          // compact point pool of the three-launch build (general path: one step at a time)
+    DevBuf<float4> fixed[2];   // one-launch build: `fixed_cap` entries per cell
+    DevBuf<unsigned long long> okeys[2];  // merge-insert keys of the map points
     int fixed_cap = 0;
-    GridPts pts(bool fixed_pool = false) { return GridPts{fixed_pool ? fixed.p : g.p}; }
+    GridPts pts(int par, bool fixed_pool = false) { return GridPts{fixed_pool ? fixed[par].p : g.p}; }
 };
 
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_map)
@@ -1360,6 +1431,7 @@ struct MapStep {
     bool pose_collected = false;  // the caller has the pose
     bool confirmed = false;       // the insertion is known to have completed; a step leaves the queue when both hold
     bool failed = false;          // the LM solve was abandoned twice (MAP_ABORT_LM): nothing of this step was committed
+    bool prebuilt = false;        // the previous step's merge write left this step's cell grid, keys and counts in place
     unsigned feat_generation = 0; // run of `feat` this step was enqueued for: a replay must find the same scan in the context
     int n_corner_bound = 0, n_surf_bound = 0;
     int insert_path = 0;
@@ -1423,6 +1495,7 @@ struct scal_map {
     MapStore map[2];  // corner, surf
     GridStore grid[2];
     bool grid_fixed = false;        // both fixed pools exist: speculative steps build the grid in one launch
+    bool grid_prebuilt = false;     // the last queued step was a speculative one: its merge write leaves the next step's grid
     int grid_cap_now[2] = {0, 0};   // <= fixed_cap (scal_map_debug_set_grid_cap lowers it to force the overflow path in tests)
     RadixSort sorter;
     DevBuf<unsigned long long> keys;
@@ -1493,7 +1566,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
             A(c->map[k].pts[b].alloc(mc));
             A(c->map[k].cube[b].alloc(mc));
         }
-        A(c->grid[k].cell.alloc(GCELLS)); A(c->grid[k].rank.alloc(mc));
+        for (int par = 0; par < 2; ++par) { A(c->grid[k].cell[par].alloc(GCELLS)); A(c->grid[k].rank[par].alloc(mc)); A(c->grid[k].okeys[par].alloc(mc)); }
         A(c->grid[k].g.alloc(mc));
     }
     A(c->sorter.init(c->map_cap));
@@ -1512,7 +1585,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     A(c->d_res.alloc(3 * sc)); A(c->d_jac.alloc(21 * sc)); A(c->d_blocks.alloc(10 * sc));
     A(c->h_C.alloc(1)); A(c->h_S.alloc(1)); A(c->h_misc.alloc(4)); A(c->res.alloc(scal_map::NSLOTS));
     // Optional, and therefore LAST (after every mandatory buffer, so that a device where they do not fit still gets a working context
-    // with the three-launch build): fixed-slice pools of the one-launch grid build, 16 B x voxels per cell x 9.4 M cells = 5.3 GB at
+    // with the three-launch build): fixed-slice pools of the one-launch grid build, two sets of 16 B x voxels per cell x 9.4 M cells = 10.5 GB at
     // the reference's 0.4 / 0.8 m, sparsely touched.  SCALOAM_MAP_FIXED_GRID=0 switches the shortcut (and its footprint) off.
     const char* fixed_env = std::getenv("SCALOAM_MAP_FIXED_GRID");
     if (rc == SCAL_OK && !(fixed_env && fixed_env[0] == '0')) {
@@ -1521,15 +1594,16 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
             const int a = voxels_per_cell_axis(k == 0 ? c->cfg.line_res : c->cfg.plane_res);
             cap[k] = a * a * a;
         }
-        if (cap[0] + cap[1] <= 48) {  // 5.3 GB at the reference's 0.4 / 0.8 m; finer filters keep the three-launch build
+        if (cap[0] + cap[1] <= 48) {  // 10.5 GB at the reference's 0.4 / 0.8 m; finer filters keep the three-launch build
             c->grid_fixed = true;
             for (int k = 0; k < 2 && c->grid_fixed; ++k) {
-                if (c->grid[k].fixed.alloc(static_cast<size_t>(GCELLS) * cap[k]) != SCAL_OK) c->grid_fixed = false;  // not fatal: no memory, no shortcut
+                for (int par = 0; par < 2; ++par)
+                    if (c->grid[k].fixed[par].alloc(static_cast<size_t>(GCELLS) * cap[k]) != SCAL_OK) c->grid_fixed = false;  // not fatal: no memory, no shortcut
                 c->grid[k].fixed_cap = c->grid_cap_now[k] = cap[k];
             }
             if (!c->grid_fixed) {
                 (void)hipGetLastError();
-                for (int k = 0; k < 2; ++k) c->grid[k].fixed.release();
+                for (int k = 0; k < 2; ++k) c->grid[k].fixed[0].release(), c->grid[k].fixed[1].release();
             }
         }
     }
@@ -1550,7 +1624,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     if (rc == SCAL_OK) {
         // Everything is initialised on the context's own stream (the legacy null stream is not ordered against it).
         // The cell counters obey a zero invariant: every step clears exactly the cells it touched.
-        for (int k = 0; k < 2 && rc == SCAL_OK; ++k) rc = c->grid[k].cell.zero(c->stream);
+        for (int k = 0; k < 4 && rc == SCAL_OK; ++k) rc = c->grid[k & 1].cell[k >> 1].zero(c->stream);
         if (rc == SCAL_OK && op_memset_async(c->d_st.p, 0, sizeof(LMState), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK && op_memset_async(c->lm_sync.p, 0, sizeof(LMSync), c->stream) != hipSuccess) rc = SCAL_E_HIP;
         if (rc == SCAL_OK) rc = c->partials.zero(c->stream);  // sequence number 0 = never published
@@ -1627,8 +1701,8 @@ GridArgs grid_args(scal_map* c, int par, bool fixed_pool = false) {
     for (int k = 0; k < 2; ++k) {
         GridStore& G = c->grid[k];
         ga.m[k] = c->map[k].cloud(par);
-        ga.cell[k] = G.cell.p, ga.rank[k] = G.rank.p, ga.g[k] = G.pts(fixed_pool);
-        ga.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;  // the merge insert's view of the same buffers (launch_insert_merge)
+        ga.cell[k] = G.cell[par].p, ga.rank[k] = G.rank[par].p, ga.g[k] = G.pts(par, fixed_pool);
+        ga.okeys[k] = G.okeys[par].p;
         ga.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
     }
     return ga;
@@ -1670,10 +1744,14 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
         a.stack[k] = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
         a.d_ns[k] = k == 0 ? &C->n_corner_stack : &C->n_surf_stack;
         a.inv_leaf[k] = 1.0f / (k == 0 ? c->cfg.line_res : c->cfg.plane_res);
-        a.okeys[k] = k == 0 ? c->keys.p : c->sorter.keys_alt.p;
+        GridStore& G = c->grid[k];
+        a.okeys[k] = G.okeys[e.par].p;
         a.nw[k] = c->merge_new(k);
-        a.grid_cell[k] = c->grid[k].cell.p, a.grid_rank[k] = c->grid[k].rank.p;
+        a.grid_cell[k] = G.cell[e.par].p, a.grid_rank[k] = G.rank[e.par].p;
+        a.next_cell[k] = G.cell[e.par ^ 1].p, a.next_rank[k] = G.rank[e.par ^ 1].p, a.next_pool[k] = G.fixed[e.par ^ 1].p;
+        a.next_okeys[k] = G.okeys[e.par ^ 1].p, a.next_cap[k] = c->grid_cap_now[k];
     }
+    a.prebuild = fused && c->grid_fixed ? 1 : 0;
     a.cap = c->map_cap;
     const int lds = sizeof(unsigned long long) * MERGE_MAX;  // attribute set per device in scal_map_create
     if (!fused)  // general path: the three-launch grid build has not computed the old points' keys (k_grid_build does on the chain)
@@ -1759,12 +1837,12 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     }
     if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
     SCAL_LAUNCH("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
-                     c->slot_cap);
+                     c->slot_cap, e.prebuilt ? 1 : 0);
     // cell grids over the valid cubes (both classes per launch): one launch on the speculative chain, three in general
     const bool fixed_pool = e.fast && c->grid_fixed && !prepare_only;
     const GridArgs ga = grid_args(c, e.par, fixed_pool);
     if (fixed_pool) {
-        SCAL_LAUNCH("k_grid_build", k_grid_build, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, c->grid_cap_now[0], c->grid_cap_now[1], S, C);
+        if (!e.prebuilt) SCAL_LAUNCH("k_grid_build", k_grid_build, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, c->grid_cap_now[0], c->grid_cap_now[1], S, C);
     } else {
         SCAL_LAUNCH("k_grid_count", k_grid_count, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
         SCAL_LAUNCH("k_grid_alloc", k_grid_alloc, dim3(GRID_BLOCKS), dim3(256), 0, s, ga, S, C);
@@ -1782,7 +1860,7 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     for (int outer = 0; outer < 2; ++outer) {
         {
             SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
-                             c->grid[0].cell.p, c->grid[0].pts(fixed_pool), c->grid[1].cell.p, c->grid[1].pts(fixed_pool), st, C, c->nnbuf());
+                             c->grid[0].cell[e.par].p, c->grid[0].pts(e.par, fixed_pool), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par, fixed_pool), st, C, c->nnbuf());
         }
         SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
         // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
@@ -1824,11 +1902,21 @@ int lm_reset(scal_map* c, bool restore_pose) {
 }
 
 int general_insert(scal_map* c, MapStep& e);
+// A speculative step's merge write has binned the map for a successor on the chain; a step that builds its own grid (general path,
+// Ceres-adapter mode, a changed slice size) first restores the zero invariant of that grid set.  All queued steps have finished.
+int drop_prebuilt_grid(scal_map* c) {
+    if (!c->grid_prebuilt) return SCAL_OK;
+    SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, c->stream, grid_args(c, c->cur), c->d_S.p);
+    SCAL_HIP(hipGetLastError());
+    c->grid_prebuilt = false;
+    return SCAL_OK;
+}
 // General path, synchronous: the window may move, the insertion falls back to the full sort.  All earlier steps have finished.
 // Returns MAP_RC_LM (nothing committed, exchange not yet cleared) when the solve was abandoned.
 int run_general_once(scal_map* c, MapStep& e) {
-    e.fast = false;
+    e.fast = false, e.prebuilt = false;
     e.par = c->cur;
+    SCAL_TRY(drop_prebuilt_grid(c));  // a general step starts and ends with both grid sets empty
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_HIP(op_event_synchronize(c->ev_pose[e.slot]));
@@ -1892,6 +1980,7 @@ int launch_fast(scal_map* c, MapStep& e) {
     e.fast = true;
     e.par = c->cur;
     e.insert_path = 1;
+    e.prebuilt = c->grid_prebuilt && c->grid_fixed;
     c->n_fast++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_TRY(launch_insert_merge(c, e, true));
@@ -1900,6 +1989,7 @@ int launch_fast(scal_map* c, MapStep& e) {
     SCAL_HIP(op_event_record(c->ev_done[e.slot], c->stream));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, c->stream));  // the registration transform reads the full-resolution cloud last
     c->cur = e.par ^ 1;
+    c->grid_prebuilt = c->grid_fixed;
     return SCAL_OK;
 }
 
@@ -1953,6 +2043,7 @@ int recover(scal_map* c) {
         }
     }
     c->cur = e.par;
+    c->grid_prebuilt = false;  // whatever is redone below ends with both grid sets empty
     bool dropped = false;
     if (at_pose) {
         c->n_recover_pose++;
@@ -1960,7 +2051,10 @@ int recover(scal_map* c) {
         const bool lm = lm_gave_up(R0);
         if (lm) SCAL_TRY(lm_reset(c, true));  // clears the abort word too
         else SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
-        if (lm || R0.S1.abort == MAP_ABORT_GRID)  // the grid was built and the kernel that clears its counters never ran
+        // the grid of this step exists - built by its own k_grid_build (unless the window check stopped the chain before it) or left
+        // by the previous step's merge write - and the kernel that clears its counters never ran.  MapState::mp is still the window
+        // it was built under: a stopped k_map_begin does not store the new one.
+        if (lm || R0.S1.abort == MAP_ABORT_GRID || e.prebuilt)
             SCAL_LAUNCH("k_grid_clear", k_grid_clear, dim3(GRID_BLOCKS), dim3(256), 0, s, grid_args(c, e.par), c->d_S.p);
         SCAL_TRY(check_generation(e, !e.prefetched));
         const int rc = run_general(c, e);
@@ -2453,6 +2547,7 @@ extern "C" int scal_map_adapter_begin(scal_map_t* c, const float* corner_last, i
     for (int i = 0; i < 4; ++i) e.pose.q_wodom[i] = q_wodom[i];
     for (int i = 0; i < 3; ++i) e.pose.t_wodom[i] = t_wodom[i];
     e.fast = false, e.par = c->cur;
+    SCAL_TRY(drop_prebuilt_grid(c));
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e, true));  // stack filters, transformAssociateToMap + window, cell grids
     hipStream_t s = c->stream;
@@ -2493,7 +2588,7 @@ extern "C" int scal_map_associate(scal_map_t* c, const double* q_w_curr, const d
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
     SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
-                     c->grid[0].cell.p, c->grid[0].pts(), c->grid[1].cell.p, c->grid[1].pts(), c->d_st.p, C, c->nnbuf());
+                     c->grid[0].cell[e.par].p, c->grid[0].pts(e.par), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par), c->d_st.p, C, c->nnbuf());
     const AssocFit fit{c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->nnbuf(), C, F};
     SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, c->d_S.p);
     SCAL_LAUNCH("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());
@@ -2601,6 +2696,8 @@ extern "C" int scal_map_debug_set_grid_cap(scal_map_t* c, int cap_corner, int ca
     }
     if (!c->grid_fixed) return SCAL_OK;
     SCAL_TRY(map_finish(c));
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    SCAL_TRY(drop_prebuilt_grid(c));  // binned under the old slice size: the next step builds its own
     c->grid_cap_now[0] = std::min(cap_corner, c->grid[0].fixed_cap);
     c->grid_cap_now[1] = std::min(cap_surf, c->grid[1].fixed_cap);
     return SCAL_OK;
