@@ -1608,7 +1608,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         }
     }
     c->lane = stage_lane(STAGE_MAP);
-    if (rc == SCAL_OK) rc = lm_check_residency<LMNoHook, MapPoseDone>(c->cfg.device);
+    if (rc == SCAL_OK) rc = lm_check_residency<AssocFit, MapPoseDone>(c->cfg.device);
     // per device, hence here and not behind a process-wide flag at the first launch
     if (rc == SCAL_OK && hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_keys), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(sizeof(unsigned long long) * MERGE_MAX)) != hipSuccess)
@@ -1862,10 +1862,11 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
             SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
                              c->grid[0].cell[e.par].p, c->grid[0].pts(e.par, fixed_pool), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par, fixed_pool), st, C, c->nnbuf());
         }
-        SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, S);
-        // the solve and (second iteration) transformUpdate + the host copy + the insertion keys: one launch
+        // PCA / plane fit of every slot (by the thread that evaluates it), the solve and (second iteration) transformUpdate + the host
+        // copy + the insertion keys: one launch.  (The fit had a launch of its own while it took 17 us at one thread per slot; at 3 us
+        // - closed-form eigenpair, register-only QR - it fits in front of the first evaluation.)
         pd.active = outer == 1;
-        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, LMNoHook(), pd, "k_lm_solve_map");
+        launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, fit, pd, "k_lm_solve_map");
     }
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(op_event_record(c->ev_pose[e.slot], s));
