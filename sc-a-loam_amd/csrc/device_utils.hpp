@@ -88,6 +88,20 @@ __device__ __forceinline__ unsigned long long wave_min_u64_dpp(unsigned long lon
     const unsigned hi = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), 63));
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
+// minimum over each 32-lane half of the wave (lanes 0-31 / 32-63), returned to every lane of that half
+__device__ __forceinline__ unsigned long long half_min_u64_dpp(unsigned long long v) {
+    v = dpp_min_step_u64<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_min_step_u64<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_min_step_u64<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_min_step_u64<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row minimum
+    v = dpp_min_step_u64<0x142, 0xa>(v);  // row_bcast:15 -> lanes 31 and 63 hold the minima of their halves
+    const unsigned lo0 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 31));
+    const unsigned hi0 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), 31));
+    const unsigned lo1 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+    const unsigned hi1 = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), 63));
+    const unsigned long long m0 = (static_cast<unsigned long long>(hi0) << 32) | lo0, m1 = (static_cast<unsigned long long>(hi1) << 32) | lo1;
+    return (threadIdx.x & 32) ? m1 : m0;
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
     const int l = lane_id();

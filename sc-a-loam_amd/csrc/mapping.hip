@@ -290,12 +290,13 @@ SCAL_KERNEL(256, k_grid_clear)
 
 // ---------------------------------------------------------------------------------------------- association
 
-// Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by ONE WAVE.
-// Lanes 2c and 2c+1 own neighbour cell c (one round trip for the 27 (count, start) pairs) and walk its points alternately, two
-// loads in flight per lane; every lane keeps the five best of ITS candidates as an ascending register list of 64-bit
-// (f32 distance bits, map index) keys.  The wave then takes the minimum of the list heads five times (DPP reduction), the owning
-// lane popping its head each time.  The instruction count follows the fullest cell, not the number of candidates.
-// Every lane returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
+// Exact 5 nearest map points of q among the 27 cells around it, ascending (distance, map index), by HALF A WAVE: lanes 0-31 serve
+// one query, lanes 32-63 another.  Lane c < 27 of a half owns neighbour cell c (one round trip for the 27 (count, start) pairs) and
+// walks its points, two loads in flight; every lane keeps the five best of ITS candidates as an ascending register list of 64-bit
+// (f32 distance bits, map index) keys.  The half then takes the minimum of the list heads five times (DPP reduction), the owning
+// lane popping its head each time.  (Rounds 1-3 gave a query a whole wave, two lanes per cell: the 9-13 k queries of a scan did not
+// fit the device at once at 6 waves per SIMD, and a wave is a chain of dependent round trips either way - 16 us per launch.)
+// Every lane of a half returns the same ascending (key, grid position) list; position -1 = fewer than five candidates.
 __device__ __forceinline__ void knn5_insert(unsigned long long (&k)[5], int (&p)[5], unsigned long long key, int pos) {
     // branch-free, statically indexed insertion into the ascending list (keys are distinct: they carry the map index)
     const bool c0 = key < k[0], c1 = key < k[1], c2 = key < k[2], c3 = key < k[3], c4 = key < k[4];
@@ -313,18 +314,15 @@ __device__ __forceinline__ unsigned long long knn_key(const float4 pt, float qx,
     dist += dz * dz;
     return (static_cast<unsigned long long>(__float_as_uint(dist)) << 32) | static_cast<unsigned>(__float_as_int(pt.w));
 }
-__device__ __forceinline__ void knn5_wave(const MapParams& mp, const int2* __restrict__ cell, const GridPts& g,
+__device__ __forceinline__ void knn5_half(const MapParams& mp, const int2* __restrict__ cell, const float4* __restrict__ pool, bool active,
                                           float qx, float qy, float qz, unsigned long long (&bk)[5], int (&bp)[5]) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int k = 0; k < 5; ++k) bk[k] = ~0ull, bp[k] = -1;
+    const int lane = lane_id(), hl = lane & 31, half = lane >> 5;
     const int cx = static_cast<int>(floorf(qx)) - mp.ox, cy = static_cast<int>(floorf(qy)) - mp.oy, cz = static_cast<int>(floorf(qz)) - mp.oz;
     // a query further than one cell outside the grid has no map point within 1 m
     const bool inside = !(cx < -1 || cx > GX || cy < -1 || cy > GY || cz < -1 || cz > GZ);
-    const int own = lane >> 1, half = lane & 1;
     int cnt = 0, start = 0;
-    if (inside && own < 27) {
-        const int xx = cx + (own % 3) - 1, yy = cy + ((own / 3) % 3) - 1, zz = cz + (own / 9) - 1;
+    if (active && inside && hl < 27) {
+        const int xx = cx + (hl % 3) - 1, yy = cy + ((hl / 3) % 3) - 1, zz = cz + (hl / 9) - 1;
         if (xx >= 0 && xx < GX && yy >= 0 && yy < GY && zz >= 0 && zz < GZ) {
             const int2 h = cell[xx + GX * (yy + GY * zz)];
             cnt = h.x, start = h.y;
@@ -334,24 +332,25 @@ __device__ __forceinline__ void knn5_wave(const MapParams& mp, const int2* __res
     int mpos[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) mk[k] = ~0ull, mpos[k] = -1;
-    // my candidates: start + half, start + half + 2, ... (< start + cnt), two per trip
-    for (int t = start + half, end = start + cnt; __ballot(t < end) != 0; t += 4) {
-        const bool a = t < end, b = t + 2 < end;
+    for (int t = start, end = start + cnt; __ballot(t < end) != 0; t += 2) {
+        const bool a = t < end, b = t + 1 < end;
         float4 pa, pb;
-        if (a) pa = g.p[t];
-        if (b) pb = g.p[t + 2];
+        if (a) pa = pool[t];
+        if (b) pb = pool[t + 1];
         if (a) knn5_insert(mk, mpos, knn_key(pa, qx, qy, qz), t);
-        if (b) knn5_insert(mk, mpos, knn_key(pb, qx, qy, qz), t + 2);
+        if (b) knn5_insert(mk, mpos, knn_key(pb, qx, qy, qz), t + 1);
     }
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        const unsigned long long best = wave_min_u64_dpp(mk[0]);
-        if (best == ~0ull) break;
-        const uint64_t ownb = __ballot(mk[0] == best);
-        const int owner = __ffsll(static_cast<long long>(ownb)) - 1;
+        const unsigned long long best = half_min_u64_dpp(mk[0]);
+        const bool have = best != ~0ull;
+        const uint64_t ownb = __ballot(have && mk[0] == best);  // keys are distinct inside a query: at most one lane per half
+        const unsigned own0 = static_cast<unsigned>(ownb), own1 = static_cast<unsigned>(ownb >> 32);
+        const int o0 = own0 ? __ffs(static_cast<int>(own0)) - 1 : 0, o1 = own1 ? 32 + __ffs(static_cast<int>(own1)) - 1 : 32;
+        const int p0 = __builtin_amdgcn_readlane(mpos[0], o0), p1 = __builtin_amdgcn_readlane(mpos[0], o1);
         bk[r] = best;
-        bp[r] = __builtin_amdgcn_readlane(mpos[0], owner);
-        if (lane == owner) {
+        bp[r] = have ? (half ? p1 : p0) : -1;
+        if (have && lane == (half ? o1 : o0)) {
             mk[0] = mk[1], mk[1] = mk[2], mk[2] = mk[3], mk[3] = mk[4], mk[4] = ~0ull;
             mpos[0] = mpos[1], mpos[1] = mpos[2], mpos[2] = mpos[3], mpos[3] = mpos[4], mpos[4] = -1;
         }
@@ -512,53 +511,56 @@ struct NNBuf {
 };
 
 // slots [0, n_corner_stack): edge candidates; [n_corner_stack, n_corner_stack + n_surf_stack): plane candidates
-// k_assoc_knn: one WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
+// k_assoc_knn: half a WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
 // many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
 // so it wants every lane busy with a different point).
 __device__ __forceinline__ void k_assoc_knn_body(const CSoA4& cs, const CSoA4& ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, const GridPts& cg,
                                                    const int2* __restrict__ scell, const GridPts& sg, const LMState* __restrict__ st,
                                                    MapCounters* C, const NNBuf& nb) {
-    if (S->abort) return;
-    // :555 - evaluated here (the map counts are complete once the grid launches are): the one-launch grid build has no later
-    // launch of its own that could do it; workgroup 0 publishes the decision for the fit, the solve and the host
-    const bool solve_on = C->n_valid[0] > 10 && C->n_valid[1] > 50;
-    if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = solve_on ? 1 : 0;
-    if (!solve_on) return;
-    const MapParams mp = S->mp;
+    // everything the kernel decides on, fetched together: the checks below would otherwise be a chain of dependent scalar round trips
+    const int stop = S->abort, nv0 = C->n_valid[0], nv1 = C->n_valid[1];
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const int n = min(nc + ns, nb.cap);
+    const MapParams mp = S->mp;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
-    const int lane = lane_id();
-    // bounded grid, wave-stride loop over the slots: a grid sized for the capacity would be ~95 % empty workgroups
-    for (int i = blockIdx.x * 4 + wave_id(); i < n; i += gridDim.x * 4) {
+    if (stop) return;
+    // :555 - evaluated here (the map counts are complete once the grid is): the one-launch grid build has no later
+    // launch of its own that could do it; workgroup 0 publishes the decision for the fit, the solve and the host
+    const bool solve_on = nv0 > 10 && nv1 > 50;
+    if (blockIdx.x == 0 && threadIdx.x == 0) C->solve_on = solve_on ? 1 : 0;
+    if (!solve_on) return;
+    const int n = min(nc + ns, nb.cap);
+    const int lane = lane_id(), hl = lane & 31, half = lane >> 5;
+    // bounded grid, wave-stride loop over pairs of slots: a grid sized for the capacity would be ~95 % empty workgroups
+    for (int i0 = (blockIdx.x * 4 + wave_id()) * 2; i0 < n; i0 += gridDim.x * 8) {
+        const int i = i0 + half;
+        const bool active = i < n;
         const bool is_edge = i < nc;
-        const int j = is_edge ? i : i - nc;
-        const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
+        const int j = active ? (is_edge ? i : i - nc) : 0;
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (active) ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
         float sel[3];
         associate_to_map(x7, ox, oy, oz, sel);
         unsigned long long bk[5];
         int bp[5];
-        const GridPts g = is_edge ? cg : sg;
+        const float4* pool = is_edge ? cg.p : sg.p;
         if (lane == 0 && i == 0) SCAL_STAMP(28);
-        if (lane == 0 && i == nc + 4) SCAL_STAMP(30);
-        knn5_wave(mp, is_edge ? ccell : scell, g, sel[0], sel[1], sel[2], bk, bp);
+        knn5_half(mp, is_edge ? ccell : scell, pool, active, sel[0], sel[1], sel[2], bk, bp);
         if (lane == 0 && i == 0) SCAL_STAMP(29);
-        if (lane == 0 && i == nc + 4) SCAL_STAMP(31);
-        // lane k < 5 fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
+        // lane k < 5 of a half fetches and stores neighbour k (statically indexed selects: the lists stay in registers)
         int mine = bp[0];
 #pragma unroll
         for (int k = 1; k < 5; ++k)
-            if (lane == k) mine = bp[k];
-        if (lane < 5) {
+            if (hl == k) mine = bp[k];
+        if (active && hl < 5) {
             const bool have = mine >= 0;
-            const float4 pt = have ? g.p[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
-            nb.px[lane * nb.cap + i] = pt.x;
-            nb.py[lane * nb.cap + i] = pt.y;
-            nb.pz[lane * nb.cap + i] = pt.z;
+            const float4 pt = have ? pool[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
+            nb.px[hl * nb.cap + i] = pt.x;
+            nb.py[hl * nb.cap + i] = pt.y;
+            nb.pz[hl * nb.cap + i] = pt.z;
         }
-        if (lane == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
+        if (active && hl == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
     }
 }
 SCAL_KERNEL(256, k_assoc_knn)
@@ -1854,7 +1856,7 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     }
     // two outer iterations (:563)
     FactorSoA F = c->factors();
-    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
+    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 8)));
     MapPoseDone pd = make_pose_done(c, e);
     const AssocFit fit{c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), c->nnbuf(), C, F};
     for (int outer = 0; outer < 2; ++outer) {
@@ -2587,7 +2589,7 @@ extern "C" int scal_map_associate(scal_map_t* c, const double* q_w_curr, const d
     SCAL_TRY(adapter_set_pose(c, q_w_curr, t_w_curr));
     SCAL_HIP(op_stream_synchronize(s));  // the pinned scratch is reused
     FactorSoA F = c->factors();
-    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 4)));
+    const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 8)));
     SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
                      c->grid[0].cell[e.par].p, c->grid[0].pts(e.par), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par), c->d_st.p, C, c->nnbuf());
     const AssocFit fit{c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->nnbuf(), C, F};
