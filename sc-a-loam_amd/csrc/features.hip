@@ -325,55 +325,47 @@ __device__ __forceinline__ PickWindow load_window(const unsigned long long* keys
     return w;
 }
 
-// marks the picked point and its +-reach neighbours in LDS and in the register window
+// marks the picked point and its +-reach neighbours in LDS (one store: lane d + 5 owns offset d) and in the register window
 __device__ __forceinline__ void apply_pick(PickWindow& w, int pli, int pnf, int pnb, unsigned pg, unsigned char* flags, int lane) {
-    if (lane == 0) flags[pli] = 1u | (((pg >> 5) & 1u) << 1);
-    if (lane >= 1 && lane <= pnf) flags[pli + lane] = 1u | (((pg >> (5 + lane)) & 1u) << 1);
-    if (lane >= 1 && lane <= pnb) flags[pli - lane] = 1u | (((pg >> (5 - lane)) & 1u) << 1);
+    const int d = lane - 5;
+    if (lane <= 10 && d <= pnf && -d <= pnb) flags[pli + d] = static_cast<unsigned char>(1u | (((pg >> lane) & 1u) << 1));
     if (w.li >= pli - pnb && w.li <= pli + pnf) w.ok = false;
 }
 
+// The picks of a phase stay in registers while the phase runs - lane n keeps the n-th pick - and reach `label` and the per-segment
+// slot arrays afterwards, all at once: the loop body of a pick is ballot -> readlane -> one LDS store -> range test (rounds 1-3 also
+// stored label and slots from lane 0 inside it, behind three exec-mask branches: 0.27 us per pick, 39 of k_ring's 73 us).
 __device__ __forceinline__ void pick_segment(const unsigned long long* keys, int L, int rs, int seg, unsigned char* picked, int* __restrict__ label, int* __restrict__ seg_sharp, int* __restrict__ seg_less,
                                              int* __restrict__ seg_flat, int* __restrict__ seg_cnt, int lane) {
-    // ---- sharp / lessSharp: largest curvature first (:304-357)
-    int largestPickedNum = 0, n_sh = 0, n_ls = 0;
-    for (int base = 0; base < L; base += 64) {
+    // ---- sharp / lessSharp: largest curvature first (:304-357).  The 21st acceptable candidate ends the scan of the segment
+    // without being marked (:327-330), so the loop simply stops after 20 picks.
+    int n_pick = 0, my_pick = 0;
+    for (int base = 0; base < L && n_pick < 20; base += 64) {
         PickWindow w = load_window<true>(keys, L, base, picked, lane);
         const uint64_t stopm = __ballot(base + lane < L && !w.cand);  // sorted: nothing after the first failure can pass
         const uint64_t live = stopm ? ((1ull << (__ffsll(static_cast<long long>(stopm)) - 1)) - 1ull) : ~0ull;
-        bool done = false;
-        while (true) {
+        while (n_pick < 20) {
             const uint64_t okm = __ballot(w.ok) & live;
             if (!okm) break;
             const int f = __ffsll(static_cast<long long>(okm)) - 1;
             const int pli = __builtin_amdgcn_readlane(w.li, f);
             const int pnf = __builtin_amdgcn_readlane(w.nf, f), pnb = __builtin_amdgcn_readlane(w.nb, f);
             const unsigned pg = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w.g), f));
-            largestPickedNum++;
-            if (largestPickedNum <= 2) {
-                if (lane == 0) {
-                    label[rs + pli] = 2;
-                    seg_sharp[seg * 2 + n_sh] = rs + pli;
-                    seg_less[seg * 20 + n_ls] = rs + pli;
-                }
-                n_sh++, n_ls++;
-            } else if (largestPickedNum <= 20) {
-                if (lane == 0) {
-                    label[rs + pli] = 1;
-                    seg_less[seg * 20 + n_ls] = rs + pli;
-                }
-                n_ls++;
-            } else {
-                done = true;  // :327-330: the 21st candidate ends the scan of this segment
-                break;
-            }
+            my_pick = lane == n_pick ? pli : my_pick;
+            ++n_pick;
             apply_pick(w, pli, pnf, pnb, pg, picked, lane);
         }
         __builtin_amdgcn_wave_barrier();
-        if (done || stopm) break;
+        if (stopm) break;
+    }
+    const int n_sh = min(n_pick, 2), n_ls = n_pick;
+    if (lane < n_pick) {
+        label[rs + my_pick] = lane < 2 ? 2 : 1;
+        seg_less[seg * 20 + lane] = rs + my_pick;
+        if (lane < 2) seg_sharp[seg * 2 + lane] = rs + my_pick;
     }
     // ---- flat: smallest curvature first (:359-403)
-    int smallestPickedNum = 0;
+    int smallestPickedNum = 0, my_flat = 0;
     for (int base = 0; base < L; base += 64) {
         PickWindow w = load_window<false>(keys, L, base, picked, lane);
         const uint64_t stopm = __ballot(base + lane < L && !w.cand);
@@ -386,10 +378,7 @@ __device__ __forceinline__ void pick_segment(const unsigned long long* keys, int
             const int pli = __builtin_amdgcn_readlane(w.li, f);
             const int pnf = __builtin_amdgcn_readlane(w.nf, f), pnb = __builtin_amdgcn_readlane(w.nb, f);
             const unsigned pg = static_cast<unsigned>(__builtin_amdgcn_readlane(static_cast<int>(w.g), f));
-            if (lane == 0) {
-                label[rs + pli] = -1;
-                seg_flat[seg * 4 + smallestPickedNum] = rs + pli;
-            }
+            my_flat = lane == smallestPickedNum ? pli : my_flat;
             smallestPickedNum++;
             if (smallestPickedNum >= 4) {  // the 4th is appended but neither marked nor suppressing (:371-375)
                 done = true;
@@ -399,6 +388,10 @@ __device__ __forceinline__ void pick_segment(const unsigned long long* keys, int
         }
         __builtin_amdgcn_wave_barrier();
         if (done || stopm) break;
+    }
+    if (lane < smallestPickedNum) {
+        label[rs + my_flat] = -1;
+        seg_flat[seg * 4 + lane] = rs + my_flat;
     }
     if (lane == 0) {
         seg_cnt[seg * 3 + 0] = n_sh;

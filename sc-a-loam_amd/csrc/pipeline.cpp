@@ -1,12 +1,14 @@
 // scal_pipeline: the reference's four concurrently running nodes (scanRegistration.cpp:475-517, laserOdometry.cpp:186-600,
 // laserMapping.cpp:909-952, laserPosegraphOptimization.cpp:874-906) as one object on one GPU.  See include/scaloam_hip.h.
 //
-// The schedule (what round 2 kept in bench.py's Python threads) lives here, on three host threads that only ever queue work:
+// The schedule (what round 2 kept in bench.py's Python threads) lives here, on four host threads that only ever queue work:
 //   front   stage A of scan k on features context k % ring, then stage C's pose-independent prefetch (input gather + stack filters);
 //           a features context is rewritten only when the scan that used it last has left stage C (pose collected), has been queued
 //           into stage B and has been handed to ScanContext (the library's reader events then order the device side);
-//   pose    stage B is queued up to two scans ahead of the pose it hands to stage C; the collected odometry pose goes straight into
-//           stage C's enqueue, which queues behind the stage-C steps still running on the device (`depth` uncollected);
+//   odom    stage B is queued up to two scans ahead of the pose it hands to stage C, its poses are collected (the only thing this
+//           thread ever waits for);
+//   pose    a collected odometry pose goes straight into stage C's enqueue, which queues behind the stage-C steps still running on
+//           the device (`depth` uncollected); finished steps are collected;
 //   loop    ScanContext: keyframe filter + descriptor + insert + search per scan, answers collected one scan behind.
 // Nothing here touches the device except through the per-stage C-ABI, so the poses are those of the per-stage calls.
 #include "common.hpp"
@@ -87,8 +89,8 @@ struct scal_pipeline {
     bool stop = false;
     int err = SCAL_OK;
     std::string errmsg;
-    std::thread t_front, t_pose, t_loop;
-    HostTimer tm_front, tm_pose, tm_loop;
+    std::thread t_front, t_odom, t_pose, t_loop;
+    HostTimer tm_front, tm_odom, tm_pose, tm_loop;
 
     bool sc_on() const { return cfg.sc_mode != SCAL_PIPE_SC_OFF; }
     Rec& r(long long k) { return rec[k % REC_N]; }
@@ -213,20 +215,18 @@ void front_thread(scal_pipeline* p) {
     }
 }
 
-void pose_thread(scal_pipeline* p) {
+// Stage B's thread: queues the odometry steps (up to B_AHEAD in front of the collected ones) and collects their poses.  It only ever
+// waits for stage B: while the two stages shared a thread, the wait for a pose (100 us) kept finished stage-C steps from being collected
+// and the caller's next push from starting.
+void odom_thread(scal_pipeline* p) {
     std::unique_lock<std::mutex> lk(p->mu);
     for (;;) {
-        enum { NONE, B_ENQ, B_COLL, C_COLL, FINISH } what = NONE;
+        enum { NONE, B_ENQ, B_COLL } what = NONE;
         p->cv.wait(lk, [&] {
             if (p->stop || p->err) return true;
             if (p->b_enq < p->a_done && p->b_enq - p->b_coll < B_AHEAD) { what = B_ENQ; return true; }
-            const long long inflight = p->c_enq - p->c_coll;
-            // collecting stage B's pose queues the scan's stage-C step: at most depth + 1 of them in flight (scal_map allows 4)
-            if (p->b_coll < p->b_enq && inflight <= p->depth) { what = B_COLL; return true; }
-            // A pose is collected when more than `depth` steps are queued on the device - or at once when the caller waits for it and
-            // nothing more can be queued meanwhile (every pushed scan is through stage B): never at the price of an empty queue.
-            if (inflight > p->depth || (inflight > 0 && (p->pop_waiting || p->drain_req) && p->b_coll == p->pushed)) { what = C_COLL; return true; }
-            if (p->drain_req && p->c_coll == p->pushed) { what = FINISH; return true; }
+            // a pose is only collected when stage C has room to take it soon: the record of an uncollected step is not reused meanwhile
+            if (p->b_coll < p->b_enq && p->b_coll - p->c_enq < 2) { what = B_COLL; return true; }
             return false;
         });
         if (p->stop || p->err) return;
@@ -235,26 +235,58 @@ void pose_thread(scal_pipeline* p) {
             const long long k = p->b_enq;
             const int slot = static_cast<int>(k % p->ring);
             lk.unlock();
-            st = p->tm_pose.run(0, "B: odom_enqueue_features", [&] { return p->for_all([&](int q) { return scal_odom_enqueue_features(p->od[q], p->regs[q][slot]); }); });
+            st = p->tm_odom.run(0, "B: odom_enqueue_features", [&] { return p->for_all([&](int q) { return scal_odom_enqueue_features(p->od[q], p->regs[q][slot]); }); });
             lk.lock();
             if (st == SCAL_OK) p->b_enq = k + 1;
-        } else if (what == B_COLL) {
+        } else {
             const long long k = p->b_coll;
-            const int slot = static_cast<int>(k % p->ring);
             scal_pipeline_result* R = p->r(k).res;
             lk.unlock();
-            st = p->tm_pose.run(1, "B: odom_collect (wait)", [&] {
+            st = p->tm_odom.run(1, "B: odom_collect (wait)", [&] {
                 return p->for_each([&](int q) {
                     double qlc[4], tlc[3];
                     return scal_odom_collect(p->od[q], qlc, tlc, R[q].q_odom, R[q].t_odom, &R[q].odom);
                 });
             });
-            if (st == SCAL_OK)  // the pose goes straight into stage C
-                st = p->tm_pose.run(2, "C: map_enqueue_features", [&] {
-                    return p->for_all([&](int q) { return scal_map_enqueue_features(p->mp[q], p->regs[q][slot], R[q].q_odom, R[q].t_odom); });
-                });
             lk.lock();
-            if (st == SCAL_OK) p->b_coll = k + 1, p->c_enq = k + 1;
+            if (st == SCAL_OK) p->b_coll = k + 1;
+        }
+        if (st != SCAL_OK) {
+            p->fail(st);
+            return;
+        }
+        p->cv.notify_all();
+    }
+}
+
+// Stage C's thread: a collected stage-B pose goes straight into a stage-C step (at most depth + 1 of them in flight, scal_map allows 4),
+// finished steps are collected.
+void pose_thread(scal_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        enum { NONE, C_ENQ, C_COLL, FINISH } what = NONE;
+        p->cv.wait(lk, [&] {
+            if (p->stop || p->err) return true;
+            const long long inflight = p->c_enq - p->c_coll;
+            if (p->c_enq < p->b_coll && inflight <= p->depth) { what = C_ENQ; return true; }
+            // A pose is collected when more than `depth` steps are queued on the device - or at once when the caller waits for it and
+            // nothing more can be queued meanwhile (every pushed scan has its step queued): never at the price of an empty queue.
+            if (inflight > p->depth || (inflight > 0 && (p->pop_waiting || p->drain_req) && p->c_enq == p->pushed)) { what = C_COLL; return true; }
+            if (p->drain_req && p->c_coll == p->pushed) { what = FINISH; return true; }
+            return false;
+        });
+        if (p->stop || p->err) return;
+        int st = SCAL_OK;
+        if (what == C_ENQ) {
+            const long long k = p->c_enq;
+            const int slot = static_cast<int>(k % p->ring);
+            scal_pipeline_result* R = p->r(k).res;
+            lk.unlock();
+            st = p->tm_pose.run(2, "C: map_enqueue_features", [&] {
+                return p->for_all([&](int q) { return scal_map_enqueue_features(p->mp[q], p->regs[q][slot], R[q].q_odom, R[q].t_odom); });
+            });
+            lk.lock();
+            if (st == SCAL_OK) p->c_enq = k + 1;
         } else if (what == C_COLL) {
             const long long k = p->c_coll;
             scal_pipeline_result* R = p->r(k).res;
@@ -432,6 +464,7 @@ int create(const scal_pipeline_config* cfg, int n_seqs, scal_pipeline_t** out) {
         return rc;
     }
     p->t_front = std::thread(front_thread, p);
+    p->t_odom = std::thread(odom_thread, p);
     p->t_pose = std::thread(pose_thread, p);
     if (p->sc_on()) p->t_loop = std::thread(loop_thread, p);
     *out = p;
@@ -452,10 +485,11 @@ extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
         p->cv.notify_all();
     }
     if (p->t_front.joinable()) p->t_front.join();
+    if (p->t_odom.joinable()) p->t_odom.join();
     if (p->t_pose.joinable()) p->t_pose.join();
     if (p->t_loop.joinable()) p->t_loop.join();
     if (TIMING) {
-        p->tm_front.print("front"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
+        p->tm_front.print("front"), p->tm_odom.print("odom"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
         std::fprintf(stderr, "[scal_pipeline] sequences %d, recorded lists flushed in the middle of an entry point: %ld\n", p->S, g_forced_flushes);
         print_forced_flushes();
     }
