@@ -13,7 +13,7 @@
 //                                      map points with atomics; both acceptance gates need the 5th neighbour
 //                                      within 1 m (:585, :653) so the 27 surrounding cells hold every candidate
 //   association (:578-688)             k_assoc_edge / k_assoc_plane: exact 5-NN by f32 (dx^2+dy^2)+dz^2, ties by map
-//                                      index; 3x3 Jacobi eigen-decomposition (edge) or pivoted Householder QR
+//                                      index; closed-form largest eigenpair (edge) or pivoted Householder QR
 //                                      (plane) in f64 registers -> residual blocks
 //   solve (:713-721) x2 (:563)         lm_dev.hpp, all on the device
 //   insert + per-cube voxel (:738-802) k_insert_keys -> radix sort by (cube, voxel) -> k_map_reduce; cubes outside
@@ -1756,8 +1756,10 @@ int launch_insert_merge(scal_map* c, const MapStep& e, bool fused = false) {
     a.prebuild = fused && c->grid_fixed ? 1 : 0;
     a.cap = c->map_cap;
     const int lds = sizeof(unsigned long long) * MERGE_MAX;  // attribute set per device in scal_map_create
-    if (!fused)  // general path: the three-launch grid build has not computed the old points' keys (k_grid_build does on the chain)
-        SCAL_LAUNCH("k_merge_okeys", k_merge_okeys, dim3(MERGE_KB0 + MERGE_KB1), dim3(1024), 0, s, a, c->d_S.p, C);
+    // the old points' keys come with the one-launch grid (k_grid_build, or the previous step's merge write); wherever the grid was
+    // built by the three general launches - the general path, and queued steps of a context without fixed pools (filters finer than
+    // 48 voxels per cell pair) - they are computed here
+    if (!(fused && c->grid_fixed)) SCAL_LAUNCH("k_merge_okeys", k_merge_okeys, dim3(MERGE_KB0 + MERGE_KB1), dim3(1024), 0, s, a, c->d_S.p, C);
     SCAL_LAUNCH("k_merge_keys", k_merge_keys, dim3(MERGE_KEYS_GRID), dim3(1024), lds, s, a, c->d_st.p, c->d_S.p, C);
     SCAL_LAUNCH("k_merge_lookup", k_merge_lookup, dim3(2 * MERGE_CHUNKS), dim3(512), 0, s, a, c->d_S.p, C);
     MergeTail t{};

@@ -3,12 +3,14 @@
 // integration, :554-568 hand-over of the lessSharp / lessFlat clouds).  DISTORTION is 0 (:59): s == 1 everywhere.
 //
 // Kernels (one stream; one host sync per scan for the pose read-back):
-//   k_odom_assoc   one WAVE per query point (sharp then flat).  TransformToStart (:111-129) in f64 -> f32.
-//                  The kd-tree NN(1) (:302, :390) is an exact brute-force argmin over the previous scan's cloud
-//                  (<= 6k corner / <= 60k surf points, 64 lanes striding, f32 ((dx^2+dy^2)+dz^2), ties -> lower
-//                  index); the reference's sequential walks over neighbouring rings (:312-361, :402-455) become
-//                  chunked wave scans: ballots find the first index past +-2.5 rings, and a 64-bit
+//   k_odom_assoc   one WORKGROUP per query point (sharp then flat).  TransformToStart (:111-129) in f64 -> f32.
+//                  The kd-tree NN(1) (:302, :390) is an exact argmin over the previous scan's cloud (f32 ((dx^2+dy^2)+dz^2),
+//                  ties -> lower index) through a two-level hashed cell index that the hand-over builds (CellIndex below);
+//                  the reference's sequential walks over neighbouring rings (:312-361, :402-455) become
+//                  chunked wave scans: per-ring index tables give the first index past +-2.5 rings, and a 64-bit
 //                  (distance bits, visit order) key reproduces "first strictly smaller wins".
+//   k_odom_handover / k_odom_cellscan / k_odom_cellfill   the lessSharp / lessFlat clouds become the next scan's targets
+//                  (:554-568): copy + ring tables + bucket counts, bucket offsets, placement.
 //   lm_dev.hpp     the Ceres-equivalent solve, state persists across scans (para_q / para_t, :97-101).
 // Clouds are SoA x[] y[] z[] intensity[] in HBM; intensity carries the ring id in its integer part (:308).
 #include "common.hpp"
@@ -114,7 +116,7 @@ __device__ __forceinline__ unsigned long long od_cell_nn(const int* __restrict__
     return best;
 }
 
-// one wave per query
+// one workgroup per query
 __device__ __forceinline__ void k_odom_assoc_body(const CSoA4& sharp, const CSoA4& flat, const CSoA4& CL, const CSoA4& SL, const LMState* __restrict__ st, OdomCounters* C,
                                                     int outer, const FactorSoA& f, const CellIndex& ci_corner, const CellIndex& ci_surf,
                                                     const int* __restrict__ ring_tab) {

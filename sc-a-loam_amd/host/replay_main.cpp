@@ -161,6 +161,13 @@ void gather(const std::vector<float>& cloud, const int* idx, int n, std::vector<
 }
 
 // ------------------------------------------------------------------------------------------------ as integrated
+double g_stage_s[4] = {0, 0, 0, 0};  // seconds inside the library calls of nodes A..D (integrated mode; reset by main before the timed run)
+struct StageClock {
+    double& acc;
+    double t0;
+    explicit StageClock(int k) : acc(g_stage_s[k]), t0(now_s()) {}
+    ~StageClock() { acc += now_s() - t0; }
+};
 std::vector<Pose> run_integrated(const Args& a, const std::vector<Scan>& scans, int first, int last) {
     static scal_features_t* g_feat = nullptr;
     static scal_odom_t* g_odom = nullptr;
@@ -197,7 +204,10 @@ std::vector<Pose> run_integrated(const Args& a, const std::vector<Scan>& scans, 
             m.seq = k, m.t_in = now_s();
             scal_features_out o{};
             o.cloud = cloud.data(), o.sharp = sharp.data(), o.less_sharp = less.data(), o.flat = flat.data(), o.less_flat = less_flat.data();
-            CHECK(scal_features_run(g_feat, scans[k].xyz.data(), scans[k].n(), 12, &o));
+            {
+                StageClock clk(0);
+                CHECK(scal_features_run(g_feat, scans[k].xyz.data(), scans[k].n(), 12, &o));
+            }
             m.cloud.assign(cloud.begin(), cloud.begin() + static_cast<size_t>(o.n_kept) * 4);
             gather(m.cloud, sharp.data(), o.n_sharp, m.sharp);
             gather(m.cloud, less.data(), o.n_less_sharp, m.less_sharp);
@@ -214,9 +224,12 @@ std::vector<Pose> run_integrated(const Args& a, const std::vector<Scan>& scans, 
             OdomMsg o;
             o.seq = m.seq, o.t_in = m.t_in;
             double q_lc[4], t_lc[3];
-            CHECK(scal_odom_step(g_odom, m.sharp.data(), static_cast<int>(m.sharp.size() / 4), m.less_sharp.data(), static_cast<int>(m.less_sharp.size() / 4),
-                                 m.flat.data(), static_cast<int>(m.flat.size() / 4), m.less_flat.data(), static_cast<int>(m.less_flat.size() / 4), q_lc, t_lc,
-                                 o.q, o.t, nullptr));
+            {
+                StageClock clk(1);
+                CHECK(scal_odom_step(g_odom, m.sharp.data(), static_cast<int>(m.sharp.size() / 4), m.less_sharp.data(), static_cast<int>(m.less_sharp.size() / 4),
+                                     m.flat.data(), static_cast<int>(m.flat.size() / 4), m.less_flat.data(), static_cast<int>(m.less_flat.size() / 4), q_lc, t_lc,
+                                     o.q, o.t, nullptr));
+            }
             o.corner_last = std::move(m.less_sharp), o.surf_last = std::move(m.less_flat), o.full = std::move(m.cloud);
             ch_bc.put(std::move(o));
         }
@@ -230,9 +243,12 @@ std::vector<Pose> run_integrated(const Args& a, const std::vector<Scan>& scans, 
             o.seq = m.seq, o.t_in = m.t_in;
             std::vector<float> reg(m.full.size());
             scal_map_stats st;
-            CHECK(scal_map_step(g_map, m.corner_last.data(), static_cast<int>(m.corner_last.size() / 4), m.surf_last.data(),
-                                static_cast<int>(m.surf_last.size() / 4), m.full.data(), static_cast<int>(m.full.size() / 4), m.q, m.t, o.pose.q, o.pose.t,
-                                reg.data(), &st));
+            {
+                StageClock clk(2);
+                CHECK(scal_map_step(g_map, m.corner_last.data(), static_cast<int>(m.corner_last.size() / 4), m.surf_last.data(),
+                                    static_cast<int>(m.surf_last.size() / 4), m.full.data(), static_cast<int>(m.full.size() / 4), m.q, m.t, o.pose.q, o.pose.t,
+                                    reg.data(), &st));
+            }
             o.pose.t_in = m.t_in, o.pose.t_out = now_s();
             o.local = std::move(m.full);  // /velodyne_cloud_registered_local (:839-843): the scan in the sensor frame
             ch_cd.put(std::move(o));
@@ -246,6 +262,7 @@ std::vector<Pose> run_integrated(const Args& a, const std::vector<Scan>& scans, 
         while (ch_cd.get(m)) {
             Pose p = m.pose;
             if (a.sc) {
+                StageClock clk(3);
                 int n_ds = 0;
                 CHECK(scal_voxel_downsample(g_vox, m.local.data(), static_cast<int>(m.local.size() / 4), 0.4f, ds.data(), &n_ds));
                 CHECK(scal_sc_insert_cloud(g_sc, ds.data(), n_ds));
@@ -413,6 +430,7 @@ int main(int argc, char** argv) {
     }
     std::vector<Pose> all = run(a, scans, 0, W);  // warm-up: the same contexts carry on (map, poses, database)
     (void)hipDeviceSynchronize();
+    for (double& v : g_stage_s) v = 0;
     const double t0 = now_s();
     std::vector<Pose> timed = run(a, scans, W, W + K);
     (void)hipDeviceSynchronize();
@@ -435,9 +453,10 @@ int main(int argc, char** argv) {
     const Pose& fp = all.back();
     std::printf("{\"mode\": \"%s\", \"scans\": %d, \"warmup\": %d, \"seconds\": %.6f, \"scans_per_s\": %.3f, \"ms_per_scan\": %.6f, "
                 "\"latency_ms\": {\"p50\": %.4f, \"p99\": %.4f}, \"loops_detected\": %d, \"sc_db\": %d, \"resident\": %d, "
-                "\"final_map_pose\": {\"q\": [%.17g, %.17g, %.17g, %.17g], \"t\": [%.17g, %.17g, %.17g]}, \"library\": \"%s\"}\n",
+                "\"final_map_pose\": {\"q\": [%.17g, %.17g, %.17g, %.17g], \"t\": [%.17g, %.17g, %.17g]}, "
+                "\"node_call_ms\": {\"A\": %.4f, \"B\": %.4f, \"C\": %.4f, \"D\": %.4f}, \"library\": \"%s\"}\n",
                 a.mode.c_str(), K, W, dt, K / dt, dt / K * 1e3, pct(0.5), pct(0.99), loops, a.sc_db, a.resident, fp.q[0], fp.q[1], fp.q[2], fp.q[3], fp.t[0],
-                fp.t[1], fp.t[2], scal_version());
+                fp.t[1], fp.t[2], g_stage_s[0] / K * 1e3, g_stage_s[1] / K * 1e3, g_stage_s[2] / K * 1e3, g_stage_s[3] / K * 1e3, scal_version());
     std::fflush(stdout);
     if (g_pipe) scal_pipeline_destroy(g_pipe);  // joins its host threads; the per-stage contexts of the other modes are left to process exit
     return 0;

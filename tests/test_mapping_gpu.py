@@ -267,6 +267,39 @@ def test_long_stream_parity_device_pipeline(O, S, hdl64_stream):
         x.close()
 
 
+def test_fine_filters_queued_chain_without_fixed_pools(O, S, worlds):
+    """Filters of 0.2 / 0.4 m (the mulran launch values) on a VLP-16 stream - __graft_entry__.smoke()'s configuration, longer: 216 + 27
+    voxels can meet a 1 m cell, more than the fixed-slice pools of the one-launch grid are built for, so the queued chain keeps the
+    three general grid launches and computes the merge insert's old keys in a launch of its own (k_merge_okeys).  Round 3 lost that
+    launch for a few commits - every other stream in this file runs at 0.4 / 0.8 m and did not notice; smoke() did.  Poses, block counts
+    and map sizes follow the oracle, the maps hold the same points, and the steps do go through the merge insert."""
+    n = 8
+    w = worlds(O.VLP16, 101)
+    reg = S.ScanRegistration(S.VLP16, 0.1, max_points=60000)
+    od = S.LaserOdometry(max_points=60000)
+    gm = S.LaserMapping(0.2, 0.4, max_scan_points=60000, max_map_points=600000)
+    oo, om = O.Odometry(), O.Mapper(0.2, 0.4, voxel_order=1, knn_mode=0)
+    paths = []
+    for k in range(n):
+        xyz = w.scan(k)
+        reg.laserCloudHandler(xyz)
+        _, _, qw, tw, _ = od.step_features(reg)
+        qg, tg, sg = gm.process_features(reg, qw, tw)
+        f = O.features(xyz, O.VLP16, 0.1)
+        c = f["cloud"]
+        a = oo.step(c[f["sharp"]], c[f["less_sharp"]], c[f["flat"]], f["less_flat"])
+        qo, to, so, _ = om.step(c[f["less_sharp"]], f["less_flat"], c, a[2], a[3])
+        assert sg.solved == so.solved and list(sg.n_edge) == list(so.n_edge) and list(sg.n_plane) == list(so.n_plane), (k, list(sg.n_plane), list(so.n_plane))
+        assert sg.n_corner_map == so.n_corner_map and sg.n_surf_map == so.n_surf_map, k
+        assert max(np.abs(qg - qo).max(), np.abs(tg - to).max()) <= 1e-6, k
+        paths.append(sg.insert_path)
+    assert sum(p == 1 for p in paths) >= n - 2, paths   # the first scan takes the general path; the rest merge
+    for which in (0, 1):
+        assert np.array_equal(_sorted_rows(om.export(which)), _sorted_rows(gm.export(which))), which
+    for x in (reg, od, gm):
+        x.close()
+
+
 def test_degenerate_plane_fit_follows_the_reference(O, S):
     """laserMapping.cpp:664-687 with five neighbours whose sum is zero: the least-squares normal of A n = -1 is n = 0, so d = 1/0 and
     n/|n| = NaN; `fabs(NaN) > 0.2` is false, the block counts as valid and goes to the solver with NaN parameters.  Every LM step is

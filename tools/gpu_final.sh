@@ -28,4 +28,4 @@ print('config3', round(r['value'],1), r['roofline'] and r['roofline']['frac'], r
 PY
 bash tools/gpu_chains.sh --seqs 0 > $F/chains.txt 2>&1; tail -9 $F/chains.txt
 bash tools/gpu_pmc.sh > $F/pmc.log 2>&1; cp gpurun_out/pmc_summary.json $F/pmc_fetch_write.json; tail -2 $F/pmc.log
-bash tools/gpu_prof_default.sh --cpu-sample 0 --cpp-sample 0 > $F/prof.log 2>&1; cp $(ls -S gpurun_out/prof_default/*/*kernel_stats.csv | head -1) $F/bench_kernel_stats.csv; tail -1 gpurun_out/prof_default.log > $F/bench_under_rocprof.json; tail -3 $F/prof.log
+bash tools/gpu_prof_default.sh --cpu-sample 0 --cpp-sample 0 > $F/prof.log 2>&1; cp $(ls -S gpurun_out/prof_default/*/*kernel_stats.csv | head -1) $F/bench_kernel_stats.csv; grep "^{\"metric\"" gpurun_out/prof_default.log > $F/bench_under_rocprof.json; tail -3 $F/prof.log
