@@ -273,6 +273,11 @@ int scal_map_step_features(scal_map_t* ctx, scal_features_t* feat, const double*
  * before its step has been enqueued: the step would mix the prefetched inputs of one scan with the full-resolution cloud of the
  * next; the step entry points check the features context's run counter and return SCAL_E_STATE in that case. */
 int scal_map_prefetch_features(scal_map_t* ctx, scal_features_t* feat);
+/* The same in two halves, for a host that issues them from different threads (scal_pipeline does): begin queues the input gather and
+ * the corner stack filter on the features context's stream, right behind stage A; finish queues the surf stack filter on the side
+ * stream.  Halves are finished in the order they were begun; a step consumes its prefetch once both halves have been queued. */
+int scal_map_prefetch_begin(scal_map_t* ctx, scal_features_t* feat);
+int scal_map_prefetch_finish(scal_map_t* ctx, scal_features_t* feat);
 /* scal_map_step_features in two halves.  enqueue queues the whole pass; collect returns the oldest uncollected pose as soon as it
  * is on the host, while the map insertion (:738-802) and the registration (:845-849) still run behind it.  Up to four steps may
  * be queued before the first is collected: transformAssociateToMap / transformUpdate (:143-153), the rolling-window decision

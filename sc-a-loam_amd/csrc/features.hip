@@ -742,7 +742,10 @@ int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
     c->cross_stream_consumers = true;
     if (!c->done_recorded) {
-        SCAL_HIP(op_event_record(c->done_ev, c->stream));
+        // At once, also under a recorder: `done_recorded` tells the consumers on OTHER host threads (the pipeline queues stage B, the
+        // side lane and stage C from different threads) that they may wait for the event, and a record still sitting in this
+        // thread's list would let them wait for the event's previous state.  Recording later than stage A's last kernel is harmless.
+        SCAL_HIP(hipEventRecord(c->done_ev, c->stream));
         c->done_recorded = true;
     }
     SCAL_HIP(op_stream_wait_event(consumer_stream, c->done_ev, 0));

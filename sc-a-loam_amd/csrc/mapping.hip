@@ -1457,6 +1457,8 @@ struct scal_map {
     std::mutex pf_mu;  // prefetches may come from a second host thread
     Prefetch pf[MAX_PF];
     int n_pf = 0;
+    Prefetch pf_half[MAX_PF];  // scal_map_prefetch_begin done, scal_map_prefetch_finish still to come (FIFO)
+    int n_half = 0;
     int next_set = 0;  // ring allocation of input sets
     hipEvent_t ev_pre[NSETS] = {};    // side stream: surf stack ready
     hipEvent_t ev_pre_a[NSETS] = {};  // features stream: corner stack ready
@@ -2250,7 +2252,7 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     SCAL_TRY(new_step(c, &e));
     {
         std::lock_guard<std::mutex> lk(c->pf_mu);
-        c->n_pf = 0;  // queued prefetches belong to a features context: not used by this entry point
+        c->n_pf = 0, c->n_half = 0;  // queued prefetches belong to a features context: not used by this entry point
         e.set = c->alloc_set();
     }
     // per-scan counters and inputs, staged through pinned memory
@@ -2294,9 +2296,9 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
 
 // laserCloudCornerLast = lessSharp cloud, laserCloudSurfLast = lessFlat cloud (laserOdometry.cpp:554-563); the full-res cloud is
 // read in place by the registration transform
-extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) {
+extern "C" int scal_map_prefetch_begin(scal_map_t* c, scal_features_t* feat) {
     if (!c || !feat) {
-        set_error("scal_map_prefetch_features: null argument");
+        set_error("scal_map_prefetch_begin: null argument");
         return SCAL_E_ARG;
     }
     FeatDeviceView v = features_view(feat);
@@ -2308,7 +2310,7 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     const int ls_cap = std::min(c->scan_cap, v.n_scans * 120);
     const int cap = std::min(c->scan_cap, v.cap);
     std::lock_guard<std::mutex> lk(c->pf_mu);
-    if (c->n_pf >= scal_map::MAX_PF) {
+    if (c->n_pf + c->n_half >= scal_map::MAX_PF) {
         set_error("scal_map_prefetch_features: %d prefetches are already queued ahead of their steps", scal_map::MAX_PF);
         return SCAL_E_STATE;
     }
@@ -2331,12 +2333,38 @@ extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) 
     SCAL_HIP(op_event_record(c->ev_gather[nset], sa));
     SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, sa, ls_cap, nset));
     SCAL_HIP(op_event_record(c->ev_pre_a[nset], sa));
-    SCAL_HIP(op_stream_wait_event(c->side, c->ev_gather[nset], 0));
-    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, nset, true));
-    SCAL_HIP(op_event_record(c->ev_pre[nset], c->side));
-    c->pf[c->n_pf].feat = feat, c->pf[c->n_pf].set = nset, c->pf[c->n_pf].generation = v.generation;
+    c->pf_half[c->n_half].feat = feat, c->pf_half[c->n_half].set = nset, c->pf_half[c->n_half].generation = v.generation;
+    c->n_half++;
+    return SCAL_OK;
+}
+
+extern "C" int scal_map_prefetch_finish(scal_map_t* c, scal_features_t* feat) {
+    if (!c || !feat) {
+        set_error("scal_map_prefetch_finish: null argument");
+        return SCAL_E_ARG;
+    }
+    SCAL_HIP(hipSetDevice(c->cfg.device));
+    FeatDeviceView v = features_view(feat);
+    const int cap = std::min(c->scan_cap, v.cap);
+    std::lock_guard<std::mutex> lk(c->pf_mu);
+    if (c->n_half == 0 || c->pf_half[0].feat != feat) {
+        set_error("scal_map_prefetch_finish: no scal_map_prefetch_begin of this features context is waiting (halves are finished in the order they were begun)");
+        return SCAL_E_STATE;
+    }
+    const scal_map::Prefetch h = c->pf_half[0];
+    for (int i = 1; i < c->n_half; ++i) c->pf_half[i - 1] = c->pf_half[i];
+    c->n_half--;
+    SCAL_HIP(op_stream_wait_event(c->side, c->ev_gather[h.set], 0));
+    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, h.set, true));
+    SCAL_HIP(op_event_record(c->ev_pre[h.set], c->side));
+    c->pf[c->n_pf] = h;
     c->n_pf++;
     return SCAL_OK;
+}
+
+extern "C" int scal_map_prefetch_features(scal_map_t* c, scal_features_t* feat) {
+    SCAL_TRY(scal_map_prefetch_begin(c, feat));
+    return scal_map_prefetch_finish(c, feat);
 }
 
 static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double* q_wodom, const double* t_wodom) {
@@ -2362,7 +2390,7 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
             if (c->pf[0].generation != v.generation) {
                 // the prefetched inputs are of an EARLIER scan than the one now in `feat` (its full-resolution cloud, read by the
                 // registration at the end of the step, has been overwritten): refuse instead of mixing two scans
-                c->n_pf = 0;
+                c->n_pf = 0, c->n_half = 0;
                 set_error("scal_map_enqueue_features: the features context was run again between scal_map_prefetch_features and this call");
                 return SCAL_E_STATE;
             }
@@ -2370,8 +2398,8 @@ static int map_enqueue_features(scal_map* c, scal_features_t* feat, const double
             e.set = c->pf[0].set;
             for (int i = 1; i < c->n_pf; ++i) c->pf[i - 1] = c->pf[i];
             c->n_pf--;
-        } else {  // no (matching) prefetch: drop what was queued and take a fresh set
-            c->n_pf = 0;
+        } else {  // no (matching, complete) prefetch: drop what was queued and take a fresh set
+            c->n_pf = 0, c->n_half = 0;
             e.set = c->alloc_set();
         }
     }
@@ -2545,7 +2573,7 @@ extern "C" int scal_map_adapter_begin(scal_map_t* c, const float* corner_last, i
     SCAL_TRY(new_step(c, &e));
     {
         std::lock_guard<std::mutex> lk(c->pf_mu);
-        c->n_pf = 0;
+        c->n_pf = 0, c->n_half = 0;
         e.set = c->alloc_set();
     }
     SCAL_TRY(upload_step_inputs(c, e, corner_last, n_corner, surf_last, n_surf, (full_res && n_full > 0) ? full_res : nullptr, full_res ? n_full : 0));

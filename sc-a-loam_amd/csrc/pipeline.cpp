@@ -1,15 +1,17 @@
 // scal_pipeline: the reference's four concurrently running nodes (scanRegistration.cpp:475-517, laserOdometry.cpp:186-600,
 // laserMapping.cpp:909-952, laserPosegraphOptimization.cpp:874-906) as one object on one GPU.  See include/scaloam_hip.h.
 //
-// The schedule (what round 2 kept in bench.py's Python threads) lives here, on four host threads that only ever queue work:
-//   front   stage A of scan k on features context k % ring, then stage C's pose-independent prefetch (input gather + stack filters);
-//           a features context is rewritten only when the scan that used it last has left stage C (pose collected), has been queued
-//           into stage B and has been handed to ScanContext (the library's reader events then order the device side);
+// The schedule (what round 2 kept in bench.py's Python threads) lives here, on five host threads that only ever queue work:
+//   front   stage A of scan k on features context k % ring, then the lane-0 half of stage C's pose-independent prefetch (input gather
+//           + corner stack filter); a features context is rewritten only when the scan that used it last has left stage C (pose
+//           collected), has been queued into stage B and has been handed to ScanContext (the library's reader events then order the
+//           device side);
+//   side    the side-lane half of the prefetch (surf stack filter) and ScanContext's keyframe filter + descriptor + insert + search;
 //   odom    stage B is queued up to two scans ahead of the pose it hands to stage C, its poses are collected (the only thing this
 //           thread ever waits for);
 //   pose    a collected odometry pose goes straight into stage C's enqueue, which queues behind the stage-C steps still running on
 //           the device (`depth` uncollected); finished steps are collected;
-//   loop    ScanContext: keyframe filter + descriptor + insert + search per scan, answers collected one scan behind.
+//   loop    ScanContext's answers, collected one scan behind their searches.
 // Nothing here touches the device except through the per-stage C-ABI, so the poses are those of the per-stage calls.
 #include "common.hpp"
 #include <condition_variable>
@@ -83,14 +85,14 @@ struct scal_pipeline {
     std::mutex mu;
     std::condition_variable cv;
     // monotone counters, all guarded by mu: scan k is "done" for a stage when counter > k
-    long long pushed = 0, a_done = 0, b_enq = 0, b_coll = 0, c_enq = 0, c_coll = 0, d_ins = 0, d_coll = 0, popped = 0;
+    long long pushed = 0, a_done = 0, pf_done = 0, b_enq = 0, b_coll = 0, c_enq = 0, c_coll = 0, d_ins = 0, d_coll = 0, popped = 0;
     int pop_waiting = 0;
     bool drain_req = false, drained = true;
     bool stop = false;
     int err = SCAL_OK;
     std::string errmsg;
-    std::thread t_front, t_odom, t_pose, t_loop;
-    HostTimer tm_front, tm_odom, tm_pose, tm_loop;
+    std::thread t_front, t_side, t_odom, t_pose, t_loop;
+    HostTimer tm_front, tm_side, tm_odom, tm_pose, tm_loop;
 
     bool sc_on() const { return cfg.sc_mode != SCAL_PIPE_SC_OFF; }
     Rec& r(long long k) { return rec[k % REC_N]; }
@@ -135,6 +137,8 @@ struct scal_pipeline {
 
 namespace {
 
+// Lane 0's thread: stage A of scan k and, right behind it on the same stream, the first half of stage C's prefetch (input gather +
+// corner stack filter).
 void front_thread(scal_pipeline* p) {
     std::unique_lock<std::mutex> lk(p->mu);
     for (;;) {
@@ -144,7 +148,6 @@ void front_thread(scal_pipeline* p) {
             if (p->pushed <= k) return false;
             const long long old = k - p->ring;  // the scan that used this features context last
             if (old >= 0 && (p->c_coll <= old || p->b_enq <= old || (p->sc_on() && p->d_ins <= old))) return false;
-            if (p->sc_on() && k - p->d_coll >= 3) return false;  // the ScanContext context holds four searches / descriptors in flight
             return k - p->c_enq < PF_AHEAD;     // prefetches queued ahead of their stage-C steps
         });
         if (p->stop || p->err) return;
@@ -157,59 +160,83 @@ void front_thread(scal_pipeline* p) {
                 return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz[q], rc.n[q], rc.stride) : scal_features_run_device(reg, rc.d_xyz[q], rc.n[q], rc.stride);
             });
         });
-        // Everything that only needs stage A: stage C's prefetch (input gather, corner filter behind stage A; surf stack filter on the
-        // side stream) and ScanContext's keyframe filter + descriptor + insert.  The two big voxel filters - same kernels, same
-        // stream, different clouds - are recorded and SHARE their launches (zip_marked_and_launch): ~200 us of side-stream time per
-        // scan become ~110.  With several sequences all 2 S filter runs are merged the same way.
-        const bool search = p->cfg.sc_mode == SCAL_PIPE_SC_EVERY_SCAN;
-        double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(slot) * 1200 : nullptr;
         if (st == SCAL_OK)
-            st = p->tm_front.run(1, "C: prefetch + D: insert", [&]() -> int {
-                if (!p->sc_on() && p->S == 1) return scal_map_prefetch_features(p->mp[0], p->regs[0][slot]);
-                Recorder recs[2 * SMAX];
-                Recorder* ptr[2 * SMAX];
-                int nr = 0, rc2 = SCAL_OK;
-                rc2 = p->tm_front.run(3, "   record prefetch", [&] {
+            st = p->tm_front.run(1, "C: prefetch, lane 0 half", [&] { return p->for_all([&](int q) { return scal_map_prefetch_begin(p->mp[q], p->regs[q][slot]); }); });
+        lk.lock();
+        if (st != SCAL_OK) {
+            p->fail(st);
+            return;
+        }
+        p->a_done = k + 1;
+        p->cv.notify_all();
+    }
+}
+
+// The side lane's thread: everything else that only needs stage A - the second half of stage C's prefetch (surf stack filter) and
+// ScanContext's keyframe filter + descriptor + insert + search.  The two big voxel filters - same kernels, same stream, different
+// clouds - are recorded and SHARE their launches (zip_marked_and_launch): ~200 us of side-stream time per scan become ~110.  With
+// several sequences all 2 S filter runs are merged the same way.  (One thread issued lane 0's and the side lane's launches until the
+// chains got short enough for its 130-220 us of launch calls per scan to be the longest thing in the period.)
+void side_thread(scal_pipeline* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    const bool search = p->cfg.sc_mode == SCAL_PIPE_SC_EVERY_SCAN;
+    for (;;) {
+        const long long k = p->pf_done;
+        p->cv.wait(lk, [&] {
+            if (p->stop || p->err) return true;
+            if (p->a_done <= k) return false;
+            return !(p->sc_on() && k - p->d_coll >= 3);  // the ScanContext context holds four searches / descriptors in flight
+        });
+        if (p->stop || p->err) return;
+        const int slot = static_cast<int>(k % p->ring);
+        lk.unlock();
+        double* dd = p->d_desc ? p->d_desc + static_cast<size_t>(slot) * 1200 : nullptr;
+        int st = p->tm_side.run(1, "C: prefetch, side half + D: insert", [&]() -> int {
+            if (!p->sc_on() && p->S == 1) return scal_map_prefetch_finish(p->mp[0], p->regs[0][slot]);
+            Recorder recs[2 * SMAX];
+            Recorder* ptr[2 * SMAX];
+            int nr = 0, rc2 = SCAL_OK;
+            rc2 = p->tm_side.run(3, "   record prefetch", [&] {
+                int r3 = SCAL_OK;
+                for (int q = 0; q < p->S && r3 == SCAL_OK; ++q) {
+                    g_recorder = ptr[nr] = &recs[nr];
+                    ++nr;
+                    r3 = scal_map_prefetch_finish(p->mp[q], p->regs[q][slot]);
+                    g_recorder = nullptr;
+                }
+                return r3;
+            });
+            if (rc2 == SCAL_OK && p->sc_on())
+                rc2 = p->tm_side.run(4, "   record insert", [&] {
                     int r3 = SCAL_OK;
                     for (int q = 0; q < p->S && r3 == SCAL_OK; ++q) {
                         g_recorder = ptr[nr] = &recs[nr];
                         ++nr;
-                        r3 = scal_map_prefetch_features(p->mp[q], p->regs[q][slot]);
+                        r3 = search ? scal_sc_insert_features(p->sc[q], p->regs[q][slot]) : scal_sc_make_features_enqueue(p->sc[q], p->regs[q][slot], dd);
                         g_recorder = nullptr;
                     }
                     return r3;
                 });
-                if (rc2 == SCAL_OK && p->sc_on())
-                    rc2 = p->tm_front.run(4, "   record insert", [&] {
-                        int r3 = SCAL_OK;
-                        for (int q = 0; q < p->S && r3 == SCAL_OK; ++q) {
-                            g_recorder = ptr[nr] = &recs[nr];
-                            ++nr;
-                            r3 = search ? scal_sc_insert_features(p->sc[q], p->regs[q][slot]) : scal_sc_make_features_enqueue(p->sc[q], p->regs[q][slot], dd);
-                            g_recorder = nullptr;
-                        }
-                        return r3;
-                    });
-                if (rc2 != SCAL_OK) {  // what was recorded still has to run: the contexts' host state already counts on it
-                    for (int i = 0; i < nr; ++i) (void)recs[i].flush();
-                    return rc2;
+            if (rc2 != SCAL_OK) {  // what was recorded still has to run: the contexts' host state already counts on it
+                for (int i = 0; i < nr; ++i) (void)recs[i].flush();
+                return rc2;
+            }
+            return p->tm_side.run(5, "   zip + launch", [&]() -> int {
+                if (zip_marked_and_launch(ptr, nr) != hipSuccess) {
+                    set_error("scal_pipeline: a batched launch failed: %s", hipGetErrorString(hipGetLastError()));
+                    return SCAL_E_HIP;
                 }
-                return p->tm_front.run(5, "   zip + launch", [&]() -> int {
-                    if (zip_marked_and_launch(ptr, nr) != hipSuccess) {
-                        set_error("scal_pipeline: a batched launch failed: %s", hipGetErrorString(hipGetLastError()));
-                        return SCAL_E_HIP;
-                    }
-                    return SCAL_OK;
-                });
+                return SCAL_OK;
             });
-        if (st == SCAL_OK && search) st = p->tm_front.run(2, "D: sc_detect_enqueue", [&] { return p->for_all([&](int q) { return scal_sc_detect_enqueue(p->sc[q]); }); });
+        });
+        if (st == SCAL_OK && search) st = p->tm_side.run(2, "D: sc_detect_enqueue", [&] { return p->for_all([&](int q) { return scal_sc_detect_enqueue(p->sc[q]); }); });
         lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
             return;
         }
         p->r(k).res[0].d_descriptor = dd;
-        p->a_done = k + 1;
+        p->pf_done = k + 1;
         if (p->sc_on()) p->d_ins = k + 1;
         p->cv.notify_all();
     }
@@ -268,7 +295,7 @@ void pose_thread(scal_pipeline* p) {
         p->cv.wait(lk, [&] {
             if (p->stop || p->err) return true;
             const long long inflight = p->c_enq - p->c_coll;
-            if (p->c_enq < p->b_coll && inflight <= p->depth) { what = C_ENQ; return true; }
+            if (p->c_enq < p->b_coll && p->c_enq < p->pf_done && inflight <= p->depth) { what = C_ENQ; return true; }
             // A pose is collected when more than `depth` steps are queued on the device - or at once when the caller waits for it and
             // nothing more can be queued meanwhile (every pushed scan has its step queued): never at the price of an empty queue.
             if (inflight > p->depth || (inflight > 0 && (p->pop_waiting || p->drain_req) && p->c_enq == p->pushed)) { what = C_COLL; return true; }
@@ -464,6 +491,7 @@ int create(const scal_pipeline_config* cfg, int n_seqs, scal_pipeline_t** out) {
         return rc;
     }
     p->t_front = std::thread(front_thread, p);
+    p->t_side = std::thread(side_thread, p);
     p->t_odom = std::thread(odom_thread, p);
     p->t_pose = std::thread(pose_thread, p);
     if (p->sc_on()) p->t_loop = std::thread(loop_thread, p);
@@ -485,11 +513,12 @@ extern "C" void scal_pipeline_destroy(scal_pipeline_t* p) {
         p->cv.notify_all();
     }
     if (p->t_front.joinable()) p->t_front.join();
+    if (p->t_side.joinable()) p->t_side.join();
     if (p->t_odom.joinable()) p->t_odom.join();
     if (p->t_pose.joinable()) p->t_pose.join();
     if (p->t_loop.joinable()) p->t_loop.join();
     if (TIMING) {
-        p->tm_front.print("front"), p->tm_odom.print("odom"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
+        p->tm_front.print("front"), p->tm_side.print("side"), p->tm_odom.print("odom"), p->tm_pose.print("pose"), p->tm_loop.print("loop");
         std::fprintf(stderr, "[scal_pipeline] sequences %d, recorded lists flushed in the middle of an entry point: %ld\n", p->S, g_forced_flushes);
         print_forced_flushes();
     }

@@ -111,7 +111,7 @@ EXPORTED_SYMBOLS = [
     "scal_sc_insert_descriptor", "scal_sc_get_descriptor", "scal_sc_make_descriptor", "scal_sc_detect", "scal_sc_detect_enqueue", "scal_sc_batch_loop_search", "scal_sc_detect_collect", "scal_sc_distance_pairs",
     "scal_sc_distance_matrix", "scal_sc_distance_matrix_device", "scal_sc_shard_query", "scal_sc_merge_candidates", "scal_sc_insert_features", "scal_sc_make_features",
     "scal_sc_insert_descriptor_device", "scal_sc_shard_query_device", "scal_sc_shard_query_batch_device", "scal_sc_insert_descriptors_device", "scal_sc_sync", "scal_sc_make_features_enqueue", "scal_sc_wait_descriptor",
-    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_export_all", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_debug_set_lm_polls", "scal_map_debug_set_grid_cap", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_odom_adapter_begin", "scal_odom_associate", "scal_odom_get_blocks", "scal_odom_eval_blocks", "scal_odom_adapter_finish", "scal_map_prefetch_features", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
+    "scal_map_create", "scal_map_destroy", "scal_map_step", "scal_map_step_features", "scal_map_export", "scal_map_export_all", "scal_map_get_wmap_wodom", "scal_map_set_merge_insert", "scal_map_get_path_counters", "scal_map_set_poll", "scal_map_debug_set_lm_polls", "scal_map_debug_set_grid_cap", "scal_map_adapter_begin", "scal_map_associate", "scal_map_get_blocks", "scal_map_eval_blocks", "scal_map_adapter_finish", "scal_odom_adapter_begin", "scal_odom_associate", "scal_odom_get_blocks", "scal_odom_eval_blocks", "scal_odom_adapter_finish", "scal_map_prefetch_features", "scal_map_prefetch_begin", "scal_map_prefetch_finish", "scal_map_enqueue_features", "scal_map_collect", "scal_map_finish",
     "scal_set_stream_mode", "scal_mapmerge_create", "scal_mapmerge_destroy", "scal_mapmerge_reset", "scal_mapmerge_add",
     "scal_mapmerge_add_batch_device", "scal_mapmerge_size", "scal_mapmerge_download", "scal_mapmerge_device_points", "scal_mapmerge_downsample", "scal_icp_create", "scal_icp_destroy", "scal_icp_align", "scal_icp_align_device", "scal_icp_set_search",
     "scal_odom_create", "scal_odom_destroy", "scal_odom_step", "scal_odom_step_features", "scal_odom_enqueue_features", "scal_odom_collect",
@@ -206,6 +206,8 @@ def lib():
     if hasattr(L, "scal_map_debug_set_grid_cap"):  # absent from older builds compared through SCALOAM_LIB (tools/gpu_ab.sh)
         L.scal_map_debug_set_grid_cap.argtypes = [vp, C.c_int, C.c_int]
     L.scal_map_prefetch_features.argtypes = [vp, vp]
+    L.scal_map_prefetch_begin.argtypes = [vp, vp]
+    L.scal_map_prefetch_finish.argtypes = [vp, vp]
     L.scal_map_enqueue_features.argtypes = [vp, vp, _f64p, _f64p]
     L.scal_map_collect.argtypes = [vp, _f64p, _f64p, C.POINTER(MapStats)]
     L.scal_map_finish.argtypes = [vp]
