@@ -28,7 +28,13 @@
 
 namespace scal {
 
-constexpr int BATCH_MAX = 4;
+constexpr int BATCH_MAX = 4;    // sequences that step together; every kernel takes at least this many argument sets
+constexpr int BATCH_WIDE = 8;   // kernels with small argument sets take eight: two independent filter runs of four sequences each share launches
+constexpr size_t KERNARG_BYTES_MAX = 3840;  // the kernarg segment of a dispatch holds 4 KB
+template <class P>
+constexpr int batch_cap() {
+    return sizeof(P) * BATCH_WIDE <= KERNARG_BYTES_MAX ? BATCH_WIDE : BATCH_MAX;
+}
 
 // ---- argument sets ------------------------------------------------------------------------------------------------------------
 template <size_t I, class T>
@@ -49,7 +55,7 @@ __host__ __device__ __forceinline__ const T& pack_get(const PackLeaf<I, T>& l) {
 
 template <class P>
 struct Batch {
-    P p[BATCH_MAX];
+    P p[batch_cap<P>()];
 };
 
 template <class F>
@@ -72,6 +78,7 @@ struct KernelTraits<void(A...)> {
 };
 
 // ---- recorder -----------------------------------------------------------------------------------------------------------------
+// n <= the kernel's capacity (RecOp::cap: batch_cap of its argument set)
 using BatchLaunchFn = hipError_t (*)(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs);
 
 constexpr int PACK_BYTES_MAX = 1024;  // largest argument set (k_merge_write: ~620 B)
@@ -81,7 +88,7 @@ struct RecOp {  // plain data: recording an operation allocates nothing
     BatchLaunchFn fn = nullptr;
     const char* name = nullptr;  // a literal or a member string of the launching context: outlives the list
     dim3 grid, block;
-    int lds = 0, pack_size = 0;
+    int lds = 0, pack_size = 0, cap = BATCH_MAX;
     hipStream_t stream = nullptr;
     // the others, replayed per sequence
     hipEvent_t ev = nullptr;
@@ -216,7 +223,8 @@ __device__ __forceinline__ void batch_call(const P& p, std::index_sequence<I...>
 template <class P, class K>
 inline hipError_t batch_launch_impl(K kernel, const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs) {
     Batch<P> b;
-    for (int i = 0; i < n && i < BATCH_MAX; ++i) std::memcpy(static_cast<void*>(&b.p[i]), packs[i], sizeof(P));
+    static_assert(sizeof(Batch<P>) <= 4096, "argument sets exceed the kernarg segment");
+    for (int i = 0; i < n && i < batch_cap<P>(); ++i) std::memcpy(static_cast<void*>(&b.p[i]), packs[i], sizeof(P));
     grid.z = static_cast<unsigned>(n);
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (prof_begin(name, s, &pe0, &pe1))
@@ -249,6 +257,7 @@ inline void launch_or_record(BatchLaunchFn fn, const char* name, dim3 grid, dim3
     if (Recorder* r = g_recorder) {
         RecOp& o = r->add(RecOp::LAUNCH);
         o.fn = fn, o.name = name, o.grid = grid, o.block = block, o.lds = lds, o.stream = s, o.pack_size = static_cast<int>(sizeof(p));
+        o.cap = batch_cap<typename Traits::pack>();
         std::memcpy(o.pack, static_cast<const void*>(&p), sizeof(p));
         return;
     }

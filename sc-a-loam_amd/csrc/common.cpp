@@ -84,7 +84,7 @@ hipError_t zip_spans(const std::vector<Span>& spans) {
         std::vector<const Span*> group{&lead};
         done[i] = true;
         if (!lead.r->broken)
-            for (int j = i + 1; j < n && static_cast<int>(group.size()) < BATCH_MAX; ++j) {
+            for (int j = i + 1; j < n && static_cast<int>(group.size()) < BATCH_WIDE; ++j) {
                 const Span& c = spans[j];
                 if (done[j] || c.r->broken || c.e - c.b != len) continue;
                 bool ok = true;
@@ -94,14 +94,18 @@ hipError_t zip_spans(const std::vector<Span>& spans) {
         for (size_t k = 0; k < len; ++k) {
             const RecOp& o = lead.r->ops[lead.b + k];
             if (o.kind == RecOp::LAUNCH) {
-                const void* packs[BATCH_MAX];
-                const char* name = o.name;
-                for (size_t g = 0; g < group.size(); ++g) {
-                    const RecOp& og = group[g]->r->ops[group[g]->b + k];
-                    packs[g] = og.pack;
-                    if (g > 0 && std::strcmp(og.name, o.name) != 0 && !std::strstr(name, "+")) name = merged_name(o.name, og.name);
+                // a kernel takes o.cap argument sets per launch (eight when they are small, else four): larger groups take several
+                for (size_t g0 = 0; g0 < group.size(); g0 += static_cast<size_t>(o.cap)) {
+                    const size_t g1 = std::min(group.size(), g0 + static_cast<size_t>(o.cap));
+                    const void* packs[BATCH_WIDE];
+                    const char* name = o.name;
+                    for (size_t g = g0; g < g1; ++g) {
+                        const RecOp& og = group[g]->r->ops[group[g]->b + k];
+                        packs[g - g0] = og.pack;
+                        if (g > g0 && std::strcmp(og.name, o.name) != 0 && !std::strstr(name, "+")) name = merged_name(o.name, og.name);
+                    }
+                    note(o.fn(name, o.grid, o.block, o.lds, o.stream, static_cast<int>(g1 - g0), packs));
                 }
-                note(o.fn(name, o.grid, o.block, o.lds, o.stream, static_cast<int>(group.size()), packs));
             } else {
                 for (const Span* g : group) note(g->r->ops[g->b + k].replay());
             }

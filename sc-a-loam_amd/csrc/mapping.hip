@@ -1463,7 +1463,6 @@ struct scal_map {
     hipEvent_t ev_pre[NSETS] = {};    // side stream: surf stack ready
     hipEvent_t ev_pre_a[NSETS] = {};  // features stream: corner stack ready
     hipEvent_t ev_gather[NSETS] = {}; // features stream: inputs gathered
-    bool pre_a_used[NSETS] = {};
     std::deque<MapStep> steps;
     hipEvent_t ev_pose[NSLOTS] = {}, ev_done[NSLOTS] = {};
     int next_slot = 0;
@@ -1830,8 +1829,9 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     MapState* S = c->d_S.p;
     if (e.feat) {
         if (e.prefetched) {
-            SCAL_HIP(op_stream_wait_event(s, c->ev_pre[st_], 0));  // inputs gathered and downsampled: the surf cloud on the side stream ...
-            if (c->pre_a_used[st_]) SCAL_HIP(op_stream_wait_event(s, c->ev_pre_a[st_], 0));  // ... the corner cloud behind stage A
+            // inputs gathered and downsampled: the surf cloud on the side stream, the corner cloud behind stage A - the side stream
+            // recorded its event behind a wait for the corner filter's (scal_map_prefetch_finish)
+            SCAL_HIP(op_stream_wait_event(s, c->ev_pre[st_], 0));
         } else {
             FeatDeviceView v = features_view(e.feat);
             SCAL_TRY(features_wait_done(e.feat, s));
@@ -2325,7 +2325,6 @@ extern "C" int scal_map_prefetch_begin(scal_map_t* c, scal_features_t* feat) {
     // ScanContext's keyframe filter.  (More than four busy streams slow every stream down on this GPU; see stage_lane().)
     hipStream_t sa = v.stream;
     const int nbc = std::max(1, div_up(ls_cap, 256));
-    c->pre_a_used[nset] = true;
     SCAL_LAUNCH("k_map_gather", k_map_gather, dim3(nbc + std::max(1, div_up(cap, 256))), dim3(256), 0, sa, v.less_xyzi, &v.P->n_less_sharp,
                      CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc,
                      c->surf_parts[nset].p);
@@ -2356,6 +2355,9 @@ extern "C" int scal_map_prefetch_finish(scal_map_t* c, scal_features_t* feat) {
     c->n_half--;
     SCAL_HIP(op_stream_wait_event(c->side, c->ev_gather[h.set], 0));
     SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, h.set, true));
+    // the side stream also takes in the corner filter's event (long finished by now: it is a quarter of the surf filter's work), so
+    // that the step waits for ONE event: every wait is a barrier packet of ~3 us on the chain the pipeline is bound by
+    SCAL_HIP(op_stream_wait_event(c->side, c->ev_pre_a[h.set], 0));
     SCAL_HIP(op_event_record(c->ev_pre[h.set], c->side));
     c->pf[c->n_pf] = h;
     c->n_pf++;
