@@ -81,6 +81,15 @@ struct KernelTraits<void(A...)> {
 // n <= the kernel's capacity (RecOp::cap: batch_cap of its argument set)
 using BatchLaunchFn = hipError_t (*)(const char* name, dim3 grid, dim3 block, int lds, hipStream_t s, int n, const void* const* packs);
 
+// hipStreamWaitEvent, unless the event has completed already: then the wait would be satisfied the moment the command processor reads
+// it, but it would still be a barrier packet on the stream (~3 us each; the pipeline's chains wait for events that were recorded a
+// scan or a whole ring of scans ago, several per chain).  A host-side query costs a fraction of a microsecond.
+inline hipError_t stream_wait_unless_done(hipStream_t s, hipEvent_t ev, unsigned flags) {
+    if (hipEventQuery(ev) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();  // hipErrorNotReady is not an error here
+    return hipStreamWaitEvent(s, ev, flags);
+}
+
 constexpr int PACK_BYTES_MAX = 1024;  // largest argument set (k_merge_write: ~620 B)
 struct RecOp {  // plain data: recording an operation allocates nothing
     enum Kind { LAUNCH, EVENT_RECORD, STREAM_WAIT, MEMCPY, MEMSET, MARK_BEGIN, MARK_END } kind = LAUNCH;
@@ -102,7 +111,7 @@ struct RecOp {  // plain data: recording an operation allocates nothing
     hipError_t replay() const {
         switch (kind) {
             case EVENT_RECORD: return hipEventRecord(ev, stream);
-            case STREAM_WAIT: return hipStreamWaitEvent(stream, ev, flags);
+            case STREAM_WAIT: return stream_wait_unless_done(stream, ev, flags);
             case MEMCPY: return hipMemcpyAsync(dst, src, bytes, copy_kind, stream);
             case MEMSET: return hipMemsetAsync(dst, value, bytes, stream);
             default: return hipSuccess;
@@ -162,7 +171,7 @@ inline hipError_t op_stream_wait_event(hipStream_t s, hipEvent_t ev, unsigned fl
         o.ev = ev, o.stream = s, o.flags = flags;
         return hipSuccess;
     }
-    return hipStreamWaitEvent(s, ev, flags);
+    return stream_wait_unless_done(s, ev, flags);
 }
 inline hipError_t op_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
     if (Recorder* r = g_recorder) {

@@ -739,7 +739,7 @@ FeatDeviceView features_view(scal_features* c) {
 int features_wait_done(scal_features* c, hipStream_t consumer_stream) {
     if (consumer_stream == c->stream) return SCAL_OK;
     std::lock_guard<std::mutex> lk(c->ev_mu);
-    if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
+    if (!c->done_ev) SCAL_HIP(hipEventCreateWithFlags(&c->done_ev, EV_DEVICE_ONLY));
     c->cross_stream_consumers = true;
     if (!c->done_recorded) {
         // At once, also under a recorder: `done_recorded` tells the consumers on OTHER host threads (the pipeline queues stage B, the
@@ -762,7 +762,7 @@ int features_note_reader(scal_features* c, hipStream_t consumer_stream) {
         return SCAL_E_STATE;
     }
     c->reader_stream[slot] = consumer_stream;
-    if (!c->reader_ev[slot]) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev[slot], hipEventDisableTiming));
+    if (!c->reader_ev[slot]) SCAL_HIP(hipEventCreateWithFlags(&c->reader_ev[slot], EV_DEVICE_ONLY));
     SCAL_HIP(op_event_record(c->reader_ev[slot], consumer_stream));
     c->reader_pending[slot] = true;
     return SCAL_OK;

@@ -510,21 +510,138 @@ struct NNBuf {
     int cap;
 };
 
+__host__ __device__ inline void m_qmul(const double* a, const double* b, double* o) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+__host__ __device__ inline void m_rot(const double* q, const double* v, double* o) {
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux, uy += uy, uz += uz;
+    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
+    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
+}
+
+struct MapPoseIn {
+    double q_wodom[4], t_wodom[3];
+};
+
+// Start of a step: transformAssociateToMap (:143-147) and the rolling-window decision (:313-508) on the device.
+// The pointer shuffles of :324-508 are offset updates; the slabs they clear are dropped by the next re-filter.
+// allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
+// stops the chain (MAP_ABORT_WINDOW) - the grid, the keys and the counts the previous step's merge write left are for that window.
+// Two halves: map_begin_eval reads the state and decides (any thread may run it: it writes nothing), map_begin_commit stores the
+// outcome (one thread).  k_map_begin runs both; a queued step whose grid is in place has no launch between this and the first
+// neighbour search, so there every workgroup of k_assoc_knn evaluates for itself and workgroup 0 commits (MapBeginArgs::active).
+struct MapBeginArgs {
+    int active;
+    MapPoseIn in;
+    int allow_window_change;
+    float inv_line, inv_plane;
+    int slot_cap, prebuilt;
+    MapState* S;
+};
+struct MapBeginOut {
+    int abort;      // MAP_ABORT_NONE / _WINDOW / _GRID
+    MapParams mp;
+    double x0[7];
+    int nv0, nv1, drifted, same, n_slots;
+};
+__device__ __forceinline__ void map_begin_eval(const MapState* S, const MapCounters* C, const MapBeginArgs& a, MapBeginOut& o) {
+    const MapPoseIn& in = a.in;
+    o.n_slots = min(C->n_corner_stack + C->n_surf_stack, a.slot_cap);  // residual-block slots (both stack filters have finished)
+    // what the previous step's merge write left for this one (MergeArgs::prebuild)
+    o.nv0 = S->next_valid[0], o.nv1 = S->next_valid[1], o.drifted = S->next_unsorted;
+    const int over = S->next_over;
+    m_qmul(S->q_wmap_wodom, in.q_wodom, o.x0);
+    double rt[3];
+    m_rot(S->q_wmap_wodom, in.t_wodom, rt);
+    o.x0[4] = rt[0] + S->t_wmap_wodom[0], o.x0[5] = rt[1] + S->t_wmap_wodom[1], o.x0[6] = rt[2] + S->t_wmap_wodom[2];
+    int cenW = S->mp.cenW, cenH = S->mp.cenH, cenD = S->mp.cenD;
+    // :313-322
+    int cI = int((o.x0[4] + 25.0) / 50.0) + cenW, cJ = int((o.x0[5] + 25.0) / 50.0) + cenH, cK = int((o.x0[6] + 25.0) / 50.0) + cenD;
+    if (o.x0[4] + 25.0 < 0) cI--;
+    if (o.x0[5] + 25.0 < 0) cJ--;
+    if (o.x0[6] + 25.0 < 0) cK--;
+    while (cI < 3) cI++, cenW++;
+    while (cI >= CW - 3) cI--, cenW--;
+    while (cJ < 3) cJ++, cenH++;
+    while (cJ >= CH - 3) cJ--, cenH--;
+    while (cK < 3) cK++, cenD++;
+    while (cK >= CD - 3) cK--, cenD--;
+    MapParams& mp = o.mp;
+    mp.cenW = cenW, mp.cenH = cenH, mp.cenD = cenD;
+    mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
+    mp.ox = 50 * (cI - 2 - cenW) - 25, mp.oy = 50 * (cJ - 2 - cenH) - 25, mp.oz = 50 * (cK - 1 - cenD) - 25;
+    mp.inv_line = a.inv_line, mp.inv_plane = a.inv_plane;
+    const MapParams p = S->mp;
+    const bool same = S->have_mp && p.cenW == mp.cenW && p.cenH == mp.cenH && p.cenD == mp.cenD && p.cI == mp.cI && p.cJ == mp.cJ && p.cK == mp.cK;
+    o.same = same ? 1 : 0;
+    o.abort = MAP_ABORT_NONE;
+    if (!a.allow_window_change && !same) o.abort = MAP_ABORT_WINDOW;
+    else if (a.prebuilt && over) o.abort = MAP_ABORT_GRID;  // a cell of the prebuilt grid overflowed its fixed slice: as k_grid_build would have reported it
+}
+// reset_next: the words the previous merge write left are cleared here (k_map_begin) or, when other workgroups may still be reading
+// them (the evaluation inside k_assoc_knn), by this step's k_merge_keys - in front of the merge write that fills them again
+__device__ __forceinline__ void map_begin_commit(MapState* S, MapCounters* C, LMState* st, const MapBeginArgs& a, const MapBeginOut& o, bool reset_next) {
+    C->n_slots = o.n_slots;
+    if (reset_next) S->next_valid[0] = 0, S->next_valid[1] = 0, S->next_unsorted = 0, S->next_over = 0;
+    if (o.abort) {
+        S->abort = o.abort;
+        return;
+    }
+    if (a.prebuilt) {
+        C->n_valid[0] = o.nv0, C->n_valid[1] = o.nv1;
+        if (o.drifted) C->merge_fail = 1;
+    }
+    S->mp = o.mp;
+    S->have_mp = 1;
+    S->window_same = o.same;
+    S->seq++;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S->q_wodom[k] = a.in.q_wodom[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S->t_wodom[k] = a.in.t_wodom[k];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) st->x[k] = o.x0[k];
+}
+__device__ __forceinline__ void k_map_begin_body(const MapBeginArgs& a, LMState* st, MapCounters* C) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (a.S->abort) return;
+    MapBeginOut o;
+    map_begin_eval(a.S, C, a, o);
+    map_begin_commit(a.S, C, st, a, o, true);
+}
+SCAL_KERNEL(1024, k_map_begin)
+
 // slots [0, n_corner_stack): edge candidates; [n_corner_stack, n_corner_stack + n_surf_stack): plane candidates
 // k_assoc_knn: half a WAVE per stack point (the neighbour search is a handful of dependent memory round trips, so it wants
 // many waves in flight); k_assoc_fit: one THREAD per stack point (the PCA / plane fit is ~3k dependent f64 operations,
 // so it wants every lane busy with a different point).
 __device__ __forceinline__ void k_assoc_knn_body(const CSoA4& cs, const CSoA4& ss, const MapState* __restrict__ S, const int2* __restrict__ ccell, const GridPts& cg,
-                                                   const int2* __restrict__ scell, const GridPts& sg, const LMState* __restrict__ st,
-                                                   MapCounters* C, const NNBuf& nb) {
+                                                   const int2* __restrict__ scell, const GridPts& sg, LMState* st,
+                                                   MapCounters* C, const NNBuf& nb, const MapBeginArgs& mb) {
     // everything the kernel decides on, fetched together: the checks below would otherwise be a chain of dependent scalar round trips
-    const int stop = S->abort, nv0 = C->n_valid[0], nv1 = C->n_valid[1];
+    const int stop = S->abort;
+    int nv0 = C->n_valid[0], nv1 = C->n_valid[1];
     const int nc = C->n_corner_stack, ns = C->n_surf_stack;
-    const MapParams mp = S->mp;
+    MapParams mp = S->mp;
     double x7[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) x7[k] = st->x[k];
     if (stop) return;
+    if (mb.active) {
+        // the step's start (k_map_begin's work) rides on this launch: every workgroup evaluates the same decision from the same
+        // state - nothing the evaluation reads is changed by the commit - and workgroup 0 stores it for the kernels behind
+        MapBeginOut o;
+        map_begin_eval(S, C, mb, o);
+        if (blockIdx.x == 0 && threadIdx.x == 0) map_begin_commit(mb.S, C, st, mb, o, false);
+        if (o.abort) return;
+        mp = o.mp, nv0 = o.nv0, nv1 = o.nv1;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) x7[k] = o.x0[k];
+    }
     // :555 - evaluated here (the map counts are complete once the grid is): the one-launch grid build has no later
     // launch of its own that could do it; workgroup 0 publishes the decision for the fit, the solve and the host
     const bool solve_on = nv0 > 10 && nv1 > 50;
@@ -854,8 +971,11 @@ __device__ __forceinline__ void k_merge_okeys_body(const MergeArgs& a, const Map
 }
 SCAL_KERNEL(1024, k_merge_okeys)
 
-__device__ __forceinline__ void k_merge_keys_body(const MergeArgs& a, const LMState* __restrict__ st, const MapState* __restrict__ S, MapCounters* C) {
+__device__ __forceinline__ void k_merge_keys_body(const MergeArgs& a, const LMState* __restrict__ st, MapState* S, MapCounters* C) {
     if (S->abort) return;
+    // what the previous step's merge write left for this step has been taken over (k_map_begin, or the evaluation inside the first
+    // k_assoc_knn, which leaves the clearing to a kernel behind all its workgroups): cleared in front of this step's merge write
+    if (blockIdx.x == 0 && threadIdx.x == 0) S->next_valid[0] = 0, S->next_valid[1] = 0, S->next_unsorted = 0, S->next_over = 0;
     extern __shared__ __align__(16) unsigned long long sk[];  // MERGE_MAX packed keys
     __shared__ int s_scan[17];
     int b = blockIdx.x;
@@ -1208,83 +1328,6 @@ __device__ __forceinline__ void k_export_valid_body(const MapCloud& m, const Map
 SCAL_KERNEL(256, k_export_valid)
 
 // Eigen-equivalent quaternion helpers, storage (x,y,z,w); the same code on both sides of the launch
-__host__ __device__ inline void m_qmul(const double* a, const double* b, double* o) {
-    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-}
-__host__ __device__ inline void m_rot(const double* q, const double* v, double* o) {
-    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
-    ux += ux, uy += uy, uz += uz;
-    const double cx = q[1] * uz - q[2] * uy, cy = q[2] * ux - q[0] * uz, cz = q[0] * uy - q[1] * ux;
-    o[0] = (v[0] + q[3] * ux) + cx, o[1] = (v[1] + q[3] * uy) + cy, o[2] = (v[2] + q[3] * uz) + cz;
-}
-
-struct MapPoseIn {
-    double q_wodom[4], t_wodom[3];
-};
-
-// First kernel of a step: transformAssociateToMap (:143-147) and the rolling-window decision (:313-508) on the device.
-// The pointer shuffles of :324-508 are offset updates; the slabs they clear are dropped by the next re-filter.
-// allow_window_change = 0 (a step queued speculatively behind another one): a window that differs from the previous step's
-// raises the sticky abort flag instead - the host then redoes this step on the general path and replays what was queued behind.
-__device__ __forceinline__ void k_map_begin_body(MapState* S, const MapPoseIn& in, LMState* st, int allow_window_change, float inv_line, float inv_plane, MapCounters* C,
-                            int slot_cap, int prebuilt) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (S->abort) return;
-    C->n_slots = min(C->n_corner_stack + C->n_surf_stack, slot_cap);  // residual-block slots (both stack filters have finished)
-    // what the previous step's merge write left for this one (MergeArgs::prebuild); consumed here whatever happens next
-    const int nv0 = S->next_valid[0], nv1 = S->next_valid[1], drifted = S->next_unsorted, over = S->next_over;
-    S->next_valid[0] = 0, S->next_valid[1] = 0, S->next_unsorted = 0, S->next_over = 0;
-    double x0[7];
-    m_qmul(S->q_wmap_wodom, in.q_wodom, x0);
-    double rt[3];
-    m_rot(S->q_wmap_wodom, in.t_wodom, rt);
-    x0[4] = rt[0] + S->t_wmap_wodom[0], x0[5] = rt[1] + S->t_wmap_wodom[1], x0[6] = rt[2] + S->t_wmap_wodom[2];
-    int cenW = S->mp.cenW, cenH = S->mp.cenH, cenD = S->mp.cenD;
-    // :313-322
-    int cI = int((x0[4] + 25.0) / 50.0) + cenW, cJ = int((x0[5] + 25.0) / 50.0) + cenH, cK = int((x0[6] + 25.0) / 50.0) + cenD;
-    if (x0[4] + 25.0 < 0) cI--;
-    if (x0[5] + 25.0 < 0) cJ--;
-    if (x0[6] + 25.0 < 0) cK--;
-    while (cI < 3) cI++, cenW++;
-    while (cI >= CW - 3) cI--, cenW--;
-    while (cJ < 3) cJ++, cenH++;
-    while (cJ >= CH - 3) cJ--, cenH--;
-    while (cK < 3) cK++, cenD++;
-    while (cK >= CD - 3) cK--, cenD--;
-    MapParams mp;
-    mp.cenW = cenW, mp.cenH = cenH, mp.cenD = cenD;
-    mp.cI = cI, mp.cJ = cJ, mp.cK = cK;
-    mp.ox = 50 * (cI - 2 - cenW) - 25, mp.oy = 50 * (cJ - 2 - cenH) - 25, mp.oz = 50 * (cK - 1 - cenD) - 25;
-    mp.inv_line = inv_line, mp.inv_plane = inv_plane;
-    const MapParams o = S->mp;
-    const bool same = S->have_mp && o.cenW == mp.cenW && o.cenH == mp.cenH && o.cenD == mp.cenD && o.cI == mp.cI && o.cJ == mp.cJ && o.cK == mp.cK;
-    if (!allow_window_change && !same) {
-        S->abort = MAP_ABORT_WINDOW;
-        return;
-    }
-    if (prebuilt) {
-        if (over) {  // a cell of the prebuilt grid overflowed its fixed slice: as k_grid_build would have reported it
-            S->abort = MAP_ABORT_GRID;
-            return;
-        }
-        C->n_valid[0] = nv0, C->n_valid[1] = nv1;
-        if (drifted) C->merge_fail = 1;
-    }
-    S->mp = mp;
-    S->have_mp = 1;
-    S->window_same = same ? 1 : 0;
-    S->seq++;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) S->q_wodom[k] = in.q_wodom[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) S->t_wodom[k] = in.t_wodom[k];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) st->x[k] = x0[k];
-}
-SCAL_KERNEL(1024, k_map_begin)
 
 __device__ __forceinline__ void copy_words(void* dst, const void* src, int bytes) {
     const unsigned* s = static_cast<const unsigned*>(src);
@@ -1842,8 +1885,13 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
         }
     }
     if (!e.prefetched) SCAL_TRY(enqueue_stack_filters(c, c->vf, c->vf, s, e.n_corner_bound, e.n_surf_bound, st_, false));
-    SCAL_LAUNCH("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, S, e.pose, st, e.fast ? 0 : 1, 1.0f / c->cfg.line_res, 1.0f / c->cfg.plane_res, C,
-                     c->slot_cap, e.prebuilt ? 1 : 0);
+    MapBeginArgs mb;
+    mb.active = 0, mb.in = e.pose, mb.allow_window_change = e.fast ? 0 : 1, mb.inv_line = 1.0f / c->cfg.line_res, mb.inv_plane = 1.0f / c->cfg.plane_res;
+    mb.slot_cap = c->slot_cap, mb.prebuilt = e.prebuilt ? 1 : 0, mb.S = S;
+    // a queued step whose grid the previous merge write left has no launch between its start and the first neighbour search: the
+    // start rides on that launch
+    const bool begin_in_knn = e.fast && e.prebuilt && c->grid_fixed && !prepare_only;
+    if (!begin_in_knn) SCAL_LAUNCH("k_map_begin", k_map_begin, dim3(1), dim3(64), 0, s, mb, st, C);
     // cell grids over the valid cubes (both classes per launch): one launch on the speculative chain, three in general
     const bool fixed_pool = e.fast && c->grid_fixed && !prepare_only;
     const GridArgs ga = grid_args(c, e.par, fixed_pool);
@@ -1865,8 +1913,9 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
     const AssocFit fit{c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), c->nnbuf(), C, F};
     for (int outer = 0; outer < 2; ++outer) {
         {
-            SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
-                             c->grid[0].cell[e.par].p, c->grid[0].pts(e.par, fixed_pool), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par, fixed_pool), st, C, c->nnbuf());
+            mb.active = (begin_in_knn && outer == 0) ? 1 : 0;
+            SCAL_LAUNCH(mb.active ? "k_assoc_knn.0" : "k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(st_).cv(), c->surf_stack(st_).cv(), S,
+                             c->grid[0].cell[e.par].p, c->grid[0].pts(e.par, fixed_pool), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par, fixed_pool), st, C, c->nnbuf(), mb);
         }
         // PCA / plane fit of every slot (by the thread that evaluates it), the solve and (second iteration) transformUpdate + the host
         // copy + the insertion keys: one launch.  (The fit had a launch of its own while it took 17 us at one thread per slot; at 3 us
@@ -2316,9 +2365,9 @@ extern "C" int scal_map_prefetch_begin(scal_map_t* c, scal_features_t* feat) {
     }
     const int nset = c->alloc_set();
     if (!c->ev_pre[nset]) {
-        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], hipEventDisableTiming));
-        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre_a[nset], hipEventDisableTiming));
-        SCAL_HIP(hipEventCreateWithFlags(&c->ev_gather[nset], hipEventDisableTiming));
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], EV_DEVICE_ONLY));
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre_a[nset], EV_DEVICE_ONLY));
+        SCAL_HIP(hipEventCreateWithFlags(&c->ev_gather[nset], EV_DEVICE_ONLY));
     }
     // The gather (it also stores per-block bounding boxes of the surf cloud for the filter) and the small corner filter ride on the
     // features context's own stream, right behind stage A; the surf filter runs on the side stream, which it shares with
@@ -2623,7 +2672,7 @@ extern "C" int scal_map_associate(scal_map_t* c, const double* q_w_curr, const d
     FactorSoA F = c->factors();
     const int assoc_blocks = std::max(1, std::min(3072, div_up(c->slot_cap, 8)));
     SCAL_LAUNCH("k_assoc_knn", k_assoc_knn, dim3(assoc_blocks), dim3(256), 0, s, c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->d_S.p,
-                     c->grid[0].cell[e.par].p, c->grid[0].pts(e.par), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par), c->d_st.p, C, c->nnbuf());
+                     c->grid[0].cell[e.par].p, c->grid[0].pts(e.par), c->grid[1].cell[e.par].p, c->grid[1].pts(e.par), c->d_st.p, C, c->nnbuf(), MapBeginArgs{});
     const AssocFit fit{c->corner_stack(e.set).cv(), c->surf_stack(e.set).cv(), c->nnbuf(), C, F};
     SCAL_LAUNCH("k_assoc_fit", k_assoc_fit, dim3(std::max(1, div_up(c->slot_cap, 64))), dim3(64), 0, s, fit, c->d_S.p);
     SCAL_LAUNCH("k_blocks_compact", k_blocks_compact, dim3(1), dim3(1024), 0, s, F, &C->n_slots, c->block_list());

@@ -85,7 +85,7 @@ struct scal_pipeline {
     std::mutex mu;
     std::condition_variable cv;
     // monotone counters, all guarded by mu: scan k is "done" for a stage when counter > k
-    long long pushed = 0, a_done = 0, pf_done = 0, b_enq = 0, b_coll = 0, c_enq = 0, c_coll = 0, d_ins = 0, d_coll = 0, popped = 0;
+    long long pushed = 0, a_run = 0, a_done = 0, pf_done = 0, b_enq = 0, b_coll = 0, c_enq = 0, c_coll = 0, d_ins = 0, d_coll = 0, popped = 0;
     int pop_waiting = 0;
     bool drain_req = false, drained = true;
     bool stop = false;
@@ -160,8 +160,13 @@ void front_thread(scal_pipeline* p) {
                 return rc.host ? scal_features_enqueue_host(reg, rc.h_xyz[q], rc.n[q], rc.stride) : scal_features_run_device(reg, rc.d_xyz[q], rc.n[q], rc.stride);
             });
         });
-        if (st == SCAL_OK)
+        if (st == SCAL_OK) {
+            lk.lock();
+            p->a_run = k + 1;  // stage B may be queued behind stage A at once
+            p->cv.notify_all();
+            lk.unlock();
             st = p->tm_front.run(1, "C: prefetch, lane 0 half", [&] { return p->for_all([&](int q) { return scal_map_prefetch_begin(p->mp[q], p->regs[q][slot]); }); });
+        }
         lk.lock();
         if (st != SCAL_OK) {
             p->fail(st);
@@ -251,7 +256,7 @@ void odom_thread(scal_pipeline* p) {
         enum { NONE, B_ENQ, B_COLL } what = NONE;
         p->cv.wait(lk, [&] {
             if (p->stop || p->err) return true;
-            if (p->b_enq < p->a_done && p->b_enq - p->b_coll < B_AHEAD) { what = B_ENQ; return true; }
+            if (p->b_enq < p->a_run && p->b_enq - p->b_coll < B_AHEAD) { what = B_ENQ; return true; }
             // a pose is only collected when stage C has room to take it soon: the record of an uncollected step is not reused meanwhile
             if (p->b_coll < p->b_enq && p->b_coll - p->c_enq < 2) { what = B_COLL; return true; }
             return false;
