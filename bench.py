@@ -733,7 +733,7 @@ def stage_bytes(c):
 
 
 STAGE_KERNELS = {
-    "A": ("k_pre", "k_classify", "k_ringscan", "k_scatter", "k_curv", "k_ring", "k_finalize", "k_compact"),
+    "A": ("k_pre", "k_classify", "k_ringscan", "k_scatter", "k_curv", "k_ring", "k_compact"),
     "B": ("k_odom_gather", "k_odom_assoc", "k_lm_solve_odom", "k_odom_handover", "k_odom_cellscan", "k_odom_cellfill"),
     "C": ("k_map_gather", "k_map_begin", "k_grid_build", "k_grid_count", "k_grid_alloc", "k_grid_fill", "k_grid_clear", "k_assoc_knn", "k_assoc_knn.0", "k_assoc_fit",
           "k_lm_solve_map", "k_merge_keys", "k_merge_lookup", "k_merge_write", "k_map_end", "k_insert_keys", "k_map_heads", "k_map_reduce",

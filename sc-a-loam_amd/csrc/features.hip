@@ -13,8 +13,8 @@
 //                            suppression by one wave scanning 64 candidates per step (:304-403), lessFlat
 //                            collection (:405-411) and the per-ring 0.2 m voxel grid (:414-420) as an LDS sort +
 //                            ordered segmented mean
-//   k_finalize  1 block      per-segment pick slots -> the reference's emission order; lessFlat ring offsets
-//   k_compact   N'/256       ring-staged lessFlat centroids -> contiguous cloud
+//   k_compact   N'/256       per-segment pick slots -> the reference's emission order (every block derives the offsets itself);
+//                            ring-staged lessFlat centroids -> contiguous cloud; xyzi records of the picks
 // Data layout: SoA x[] y[] z[] intensity[] in HBM (coalesced 4 B/lane loads; the whole scan is < 2 MB and lives
 // in L2).  All f32 arithmetic that feeds a comparison is compiled without FMA contraction.
 #include "common.hpp"
@@ -601,39 +601,52 @@ SCAL_KERNEL(RING_THREADS, k_ring)
 SCAL_DEFINE_STAMP_READER(scal_debug_stamps_features)
 
 // one block: turn per-segment pick slots into the reference's emission order (segments in (ring, sixth) order)
-__device__ __forceinline__ void k_finalize_body(FeatParams* P, int n_scans, const int* __restrict__ seg_sharp,
-                                                   const int* __restrict__ seg_less, const int* __restrict__ seg_flat,
-                                                   const int* __restrict__ seg_cnt, int* __restrict__ sharp, int* __restrict__ less,
-                                                   int* __restrict__ flat) {
-    __shared__ int s_scan[17];
-    const int nseg = n_scans * 6;
-    const int s = threadIdx.x;
-    const int c0 = s < nseg ? seg_cnt[s * 3 + 0] : 0, c1 = s < nseg ? seg_cnt[s * 3 + 1] : 0, c2 = s < nseg ? seg_cnt[s * 3 + 2] : 0;
-    int t0, t1, t2;
-    const int o0 = block_exclusive_scan(c0, s_scan, &t0);
-    const int o1 = block_exclusive_scan(c1, s_scan, &t1);
-    const int o2 = block_exclusive_scan(c2, s_scan, &t2);
-    for (int k = 0; k < c0; ++k) sharp[o0 + k] = seg_sharp[s * 2 + k];
-    for (int k = 0; k < c1; ++k) less[o1 + k] = seg_less[s * 20 + k];
-    for (int k = 0; k < c2; ++k) flat[o2 + k] = seg_flat[s * 4 + k];
-    const int lc = s < 64 ? P->lf_ring_cnt[s] : 0;
-    int tl;
-    const int lo = block_exclusive_scan(lc, s_scan, &tl);
-    if (s < 64) P->lf_ring_off[s] = lo;
-    if (s == 0) {
-        P->n_sharp = t0, P->n_less_sharp = t1, P->n_flat = t2, P->n_less_flat = tl;
-        P->lf_ring_off[64] = tl;
-    }
-}
-SCAL_KERNEL(1024, k_finalize)
-
-__device__ __forceinline__ void k_compact_body(const FeatParams* __restrict__ P, const float* __restrict__ sx, const float* __restrict__ sy,
-                                                 const float* __restrict__ sz, const float* __restrict__ si, float* __restrict__ lx,
-                                                 float* __restrict__ ly, float* __restrict__ lz, float* __restrict__ li,
-                                                 const int* __restrict__ sharp, const int* __restrict__ less, const int* __restrict__ flat,
+// Last kernel of stage A.  Every workgroup derives the emission order itself - exclusive prefixes of the per-segment pick counts (<= 512
+// segments, two per thread) and of the per-ring lessFlat counts, in LDS - instead of reading them from a one-workgroup launch in front
+// (k_finalize until round 3: a launch, its gap and 9 us, against ~5 us more in this kernel).  Then: ring-staged lessFlat centroids -> the
+// contiguous cloud; the i-th sharp / lessSharp / flat pick in the reference's order (segment by segment, :304-403) -> the index lists
+// and its xyzi record; workgroup 0 also writes the counts.
+constexpr int SEG_MAX = 512;
+__device__ __forceinline__ void k_compact_body(FeatParams* P, int n_scans, const int* __restrict__ seg_sharp, const int* __restrict__ seg_less,
+                                                 const int* __restrict__ seg_flat, const int* __restrict__ seg_cnt, int* __restrict__ sharp,
+                                                 int* __restrict__ less, int* __restrict__ flat, const float* __restrict__ sx,
+                                                 const float* __restrict__ sy, const float* __restrict__ sz, const float* __restrict__ si,
+                                                 float* __restrict__ lx, float* __restrict__ ly, float* __restrict__ lz, float* __restrict__ li,
                                                  const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
                                                  const float* __restrict__ inten, float* __restrict__ fsharp, float* __restrict__ fless,
                                                  float* __restrict__ fflat) {
+    __shared__ int s_scan[17];
+    __shared__ int s_o[3][SEG_MAX + 1];  // exclusive prefixes of the sharp / lessSharp / flat counts per segment, total at [nseg]
+    __shared__ int s_lf[65];             // exclusive prefix of the lessFlat counts per ring
+    const int nseg = min(n_scans * 6, SEG_MAX);
+    const int t = threadIdx.x;
+    // two block scans carry the four prefix sums: (lessSharp | flat << 14) and (sharp | lessFlat << 11) - a scan is three barriers,
+    // and every workgroup pays them.  Totals: lessSharp <= 20 * 512 < 2^14, flat <= 4 * 512, sharp <= 2 * 512 < 2^11, lessFlat < 2^21.
+    int tot[3], tl;
+    {
+        const int i0 = 2 * t, i1 = 2 * t + 1;
+        const int a1 = i0 < nseg ? seg_cnt[i0 * 3 + 1] : 0, b1 = i1 < nseg ? seg_cnt[i1 * 3 + 1] : 0;
+        const int a2 = i0 < nseg ? seg_cnt[i0 * 3 + 2] : 0, b2 = i1 < nseg ? seg_cnt[i1 * 3 + 2] : 0;
+        const int a0 = i0 < nseg ? seg_cnt[i0 * 3 + 0] : 0, b0 = i1 < nseg ? seg_cnt[i1 * 3 + 0] : 0;
+        const int lc = t < 64 ? P->lf_ring_cnt[t] : 0;
+        int totA, totB;
+        const int exA = block_exclusive_scan((a1 + b1) | ((a2 + b2) << 14), s_scan, &totA);
+        const int exB = block_exclusive_scan((a0 + b0) | (lc << 11), s_scan, &totB);
+        const int e1 = exA & 0x3fff, e2 = exA >> 14, e0 = exB & 0x7ff, el = static_cast<int>(static_cast<unsigned>(exB) >> 11);
+        if (i0 < nseg) s_o[0][i0] = e0, s_o[1][i0] = e1, s_o[2][i0] = e2;
+        if (i1 < nseg) s_o[0][i1] = e0 + a0, s_o[1][i1] = e1 + a1, s_o[2][i1] = e2 + a2;
+        if (t < 64) s_lf[t] = el;
+        tot[1] = totA & 0x3fff, tot[2] = totA >> 14, tot[0] = totB & 0x7ff, tl = static_cast<int>(static_cast<unsigned>(totB) >> 11);
+        if (t == 0) s_o[0][nseg] = tot[0], s_o[1][nseg] = tot[1], s_o[2][nseg] = tot[2], s_lf[64] = tl;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {  // ring offsets and counts for the host and the later stages
+        if (t < 64) P->lf_ring_off[t] = s_lf[t];
+        if (t == 0) {
+            P->n_sharp = tot[0], P->n_less_sharp = tot[1], P->n_flat = tot[2], P->n_less_flat = tl;
+            P->lf_ring_off[64] = tl;
+        }
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = P->n_kept;
     if (i < n) {
@@ -643,22 +656,33 @@ __device__ __forceinline__ void k_compact_body(const FeatParams* __restrict__ P,
             if (P->ring_off[mid] <= i) lo = mid; else hi = mid - 1;
         }
         const int loc = i - P->ring_off[lo];
-        if (loc < P->lf_ring_cnt[lo]) {
-            const int o = P->lf_ring_off[lo] + loc;
+        if (loc < s_lf[lo + 1] - s_lf[lo]) {
+            const int o = s_lf[lo] + loc;
             lx[o] = sx[i], ly[o] = sy[i], lz[o] = sz[i], li[o] = si[i];
         }
     }
-    // SoA copies of the picked points for the downstream stages (x[], y[], z[], i[] blocks of `cap` floats)
-    if (i < P->n_sharp) {
-        const int g = sharp[i];
+    // xyzi records of the picked points for the downstream stages: the i-th pick of a class lives in segment upper_bound(prefix, i) - 1
+    auto pick = [&](int q, int per_seg, const int* __restrict__ seg_list) {
+        int lo = 0, hi = nseg;  // largest sgi with s_o[q][sgi] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_o[q][mid] <= i) lo = mid; else hi = mid;
+        }
+        return seg_list[lo * per_seg + (i - s_o[q][lo])];
+    };
+    if (i < tot[0]) {
+        const int g = pick(0, 2, seg_sharp);
+        sharp[i] = g;
         fsharp[i * 4 + 0] = x[g], fsharp[i * 4 + 1] = y[g], fsharp[i * 4 + 2] = z[g], fsharp[i * 4 + 3] = inten[g];
     }
-    if (i < P->n_less_sharp) {
-        const int g = less[i];
+    if (i < tot[1]) {
+        const int g = pick(1, 20, seg_less);
+        less[i] = g;
         fless[i * 4 + 0] = x[g], fless[i * 4 + 1] = y[g], fless[i * 4 + 2] = z[g], fless[i * 4 + 3] = inten[g];
     }
-    if (i < P->n_flat) {
-        const int g = flat[i];
+    if (i < tot[2]) {
+        const int g = pick(2, 4, seg_flat);
+        flat[i] = g;
         fflat[i * 4 + 0] = x[g], fflat[i * 4 + 1] = y[g], fflat[i * 4 + 2] = z[g], fflat[i * 4 + 3] = inten[g];
     }
 }
@@ -895,10 +919,9 @@ static int launch_chain(scal_features* c, const float* d_xyz, int n, int stride)
         SCAL_LAUNCH("k_ring", k_ring, dim3(g.n_scans), dim3(RING_THREADS), lds, s, P, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->d_curv.p, c->d_label.p,
                        c->d_gap.p, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->sx.p, c->sy.p, c->sz.p, c->si.p);
     }
-    SCAL_LAUNCH("k_finalize", k_finalize, dim3(1), dim3(1024), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p,
-                       c->d_sharp.p, c->d_less.p, c->d_flat.p);
-    SCAL_LAUNCH("k_compact", k_compact, dim3(nb256), dim3(256), 0, s, P, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p,
-                       c->d_sharp.p, c->d_less.p, c->d_flat.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p, c->f_sharp.p, c->f_less.p, c->f_flat.p);
+    SCAL_LAUNCH("k_compact", k_compact, dim3(nb256), dim3(256), 0, s, P, g.n_scans, c->seg_sharp.p, c->seg_less.p, c->seg_flat.p, c->seg_cnt.p, c->d_sharp.p,
+                       c->d_less.p, c->d_flat.p, c->sx.p, c->sy.p, c->sz.p, c->si.p, c->lx.p, c->ly.p, c->lz.p, c->li.p, c->ox.p, c->oy.p, c->oz.p, c->oi.p,
+                       c->f_sharp.p, c->f_less.p, c->f_flat.p);
     SCAL_HIP(hipGetLastError());
     ev_lk.lock();
     if (c->cross_stream_consumers) {  // the event must sit right behind stage A, not behind whatever the stream gets next

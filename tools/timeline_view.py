@@ -7,7 +7,7 @@ for line in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/timeline.csv"
     rows.append((float(a) * 1e3, float(b) * 1e3, n))
 rows.sort()
 stage = {}
-for n in "k_pre k_classify k_ringscan k_scatter k_curv k_ring k_finalize k_compact".split(): stage[n] = "A"
+for n in "k_pre k_classify k_ringscan k_scatter k_curv k_ring k_compact".split(): stage[n] = "A"
 for n in "k_odom_gather k_odom_assoc k_odom_handover k_odom_cellscan k_odom_cellfill".split(): stage[n] = "B"
 for n in "k_map_begin k_grid_count k_grid_alloc k_grid_fill k_assoc_knn k_assoc_fit k_map_pose_done k_merge_keys k_merge_lookup k_merge_write k_transform_cloud k_map_end k_grid_clear k_insert_keys k_map_heads k_map_reduce".split(): stage[n] = "C"
 for n in "k_sc_bin k_sc_finish k_sc_topk k_sc_detect k_sc_keys k_sc_store".split(): stage[n] = "D"
