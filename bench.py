@@ -9,7 +9,7 @@ A "step" is one scan through the whole hot path on one GPU, inputs already resid
   stage D  ScanContext insert + loop search   (Scancontext.cpp:151-260, :336-427) over a pre-filled keyframe database
 Default schedule: scal_pipeline (include/scaloam_hip.h) - the four stages on their own streams with consecutive scans overlapping,
 the way the reference's four ROS nodes (scanRegistration, laserOdometry, laserMapping, laserPosegraphOptimization) work on different
-scans at the same time.  The schedule lives INSIDE the library (four C++ host threads); this file only pushes scans and pops poses,
+scans at the same time.  The schedule lives INSIDE the library (five C++ host threads); this file only pushes scans and pops poses,
 exactly what the C++ host sc-a-loam_amd/host/replay_main.cpp does.  Every scan still goes through A -> B -> C and A -> D with the
 reference's data dependencies, and the K timed steps end only when the last scan's map insertion is done.  --no-overlap runs one
 scan at a time through the per-stage calls on one stream; both schedules give bit-identical poses (`final_map_pose`).
@@ -702,7 +702,7 @@ def main():
                                    "odometry prior and ScanContext insert+detect per scan",
                        "points_per_scan_in": int(np.mean(npts)), "sc_db_keyframes": a.sc_db, "sc_db_revisits": n_rev, "line_res": 0.4, "plane_res": 0.8,
                        "parallelism": (f"replicas for A-C, SC database sharded i % N with two RCCL all-gathers per {Q} scan(s)" if world > 1 else "single GPU"),
-                       "schedule": "scal_pipeline (in-library, four C++ host threads): one stream per stage, consecutive scans overlap as the "
+                       "schedule": "scal_pipeline (in-library, five C++ host threads): one stream per stage, consecutive scans overlap as the "
                                    "reference's four nodes do" if pipelined else "serial: one scan at a time through the per-stage calls"},
             "roofline": roofline, "cpu_baseline": cpu, "cpp_host": cpp,
             "kernel_ms_per_step": {k: v[0] / max(1, n_all_steps) for k, v in sorted(prof_all.items())}, "profiled_steps": n_all_steps,
