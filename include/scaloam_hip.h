@@ -441,8 +441,8 @@ int scal_icp_set_search(scal_icp_t* ctx, int mode);
  * laserPosegraphOptimization.cpp:874-906; hand-over by ROS topics with queue size 100).  scal_pipeline is that arrangement inside one
  * process and one GPU: it owns a ring of features contexts, one odometry, one mapping and one ScanContext context, puts each stage on
  * its own stream (scal_set_stream_mode(1) semantics) and keeps the schedule - which scan each stage may start, when a features
- * context may be rewritten, how many stage-C steps are queued on the device - on five internal host threads (stage A + the lane-0 half of stage C's
- * prefetch; stage B; stage C; ScanContext).  Scans go in with push, poses come out IN ORDER with pop; every scan passes through
+ * context may be rewritten, how many stage-C steps are queued on the device - on five internal host threads (stage A + the first half of
+ * stage C's prefetch; its second half + ScanContext's filter, insert and search; stage B; stage C; ScanContext's answers).  Scans go in with push, poses come out IN ORDER with pop; every scan passes through
  * A -> B -> C and A -> D with the reference's data dependencies, and the poses are bit-identical to calling the four stage APIs one
  * scan at a time.  A C++ host (host/replay_main.cpp) and bench.py drive the same object. */
 enum {
