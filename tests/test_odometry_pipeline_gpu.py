@@ -77,6 +77,31 @@ def test_odometry_stream(O, S, hdl64_stream):
     go.close()
 
 
+def test_odometry_sparse_targets_reach_every_level_of_the_cell_index(O, S, hdl64_stream):
+    """Stage B's NN(1) goes through a two-level hashed cell index (1 m cells, then 5 m cells, then a sweep of the cloud when the nearest
+    candidate is not certified within 5 m).  Consecutive dense scans almost always answer at the first level; here every third scan is
+    used (3 m of motion against the constant-velocity prior) and the target clouds are thinned to every 9th / 25th point, so that many
+    queries find their neighbour between 1 and 5 m, at the 5 m edge or not at all.  Block counts of both outer iterations, LM
+    iterations, costs and poses must still follow the oracle's kd-tree."""
+    ks = [0, 3, 6, 9, 12, 15]
+    fa = _stage_a(O, [hdl64_stream(k) for k in ks])
+    for step_c, step_s in ((9, 25), (2, 3)):
+        oo = O.Odometry()
+        go = S.LaserOdometry(max_points=200000)
+        for k, f in enumerate(fa):
+            ls, lf = f["less_sharp"][::step_c].copy(), f["less_flat"][::step_s].copy()
+            a = oo.step(f["sharp"], ls, f["flat"], lf)
+            b = go.step(f["sharp"], ls, f["flat"], lf)
+            so, sg = a[4], b[4]
+            assert list(sg.n_edge) == list(so.n_edge) and list(sg.n_plane) == list(so.n_plane), (step_c, k, list(sg.n_edge), list(so.n_edge), list(sg.n_plane), list(so.n_plane))
+            assert list(sg.lm_iters) == list(so.lm_iters), (step_c, k)
+            for o in range(2):
+                assert abs(sg.cost_init[o] - so.cost_init[o]) <= 1e-9 * max(1.0, so.cost_init[o]), (step_c, k)
+            assert max(np.abs(a[i] - b[i]).max() for i in range(4)) <= 1e-7, (step_c, k)
+        print("thinning", step_c, step_s, "blocks of the last scan:", list(sg.n_edge), list(sg.n_plane))
+        go.close()
+
+
 def test_device_resident_pipeline(O, S, hdl64_stream):
     """A -> B -> C with every intermediate left in HBM (scal_*_step_features) must equal the host-array path."""
     reg = S.ScanRegistration(S.HDL64, 5.0, max_points=200000)
