@@ -412,7 +412,9 @@ __device__ __forceinline__ void lm_compute_candidate(State* st) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) d2[a] = fmin(fmax(Hs[hidx(a, a)], 1e-6), 1e32) * inv_radius;
         double y[6];
+        if (blockIdx.x == 0) SCAL_STAMP(26);
         bool ok = chol_solve6(Hs, d2, gs, y);
+        if (blockIdx.x == 0) SCAL_STAMP(27);
         double mcc = 0.0;
         if (ok) {
             // model_cost_change = -(J s).(r + J s/2) with s = -y  =  y.gs - y^T Hs y / 2
@@ -710,6 +712,7 @@ __device__ __forceinline__ void k_lm_solve_body(const FactorSoA& f, const int* _
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 4);
         if (tid == 0) {
+            if (blockIdx.x == 0 && round == 1) SCAL_STAMP(24);
             // The serial step runs on a register copy of the state (LMCore: no run-time indexed arrays, so it does not go to
             // scratch) and of the totals: on the LDS copy every field access was a dependent ~100-cycle round trip.
             if (phase == 0) L.log_n_edge[outer] = static_cast<int>(tot[28]), L.log_n_plane[outer] = static_cast<int>(tot[29]);
@@ -726,7 +729,9 @@ __device__ __forceinline__ void k_lm_solve_body(const FactorSoA& f, const int* _
             for (int k = 0; k < 6; ++k) R.g[k] = L.g[k], R.scale[k] = L.scale[k];
             R.iteration = L.iteration, R.done = L.done, R.successful = L.successful, R.started = L.started, R.enabled = L.enabled;
             R.termination = L.termination, R.cost_init = L.cost_init, R.cost_final = L.cost_final;
+            if (blockIdx.x == 0 && round == 1) SCAL_STAMP(25);
             lm_tail(&R, t, phase);
+            if (blockIdx.x == 0 && round == 1) SCAL_STAMP(30);
 #pragma unroll
             for (int k = 0; k < 7; ++k) L.x[k] = R.x[k], L.cand[k] = R.cand[k];
             L.x_cost = R.x_cost, L.mcc = R.mcc, L.radius = R.radius, L.decrease_factor = R.decrease_factor, L.x_norm = R.x_norm;
@@ -736,6 +741,7 @@ __device__ __forceinline__ void k_lm_solve_body(const FactorSoA& f, const int* _
             for (int k = 0; k < 6; ++k) L.g[k] = R.g[k], L.scale[k] = R.scale[k];
             L.iteration = R.iteration, L.done = R.done, L.successful = R.successful, L.started = R.started, L.enabled = R.enabled;
             L.termination = R.termination, L.cost_init = R.cost_init, L.cost_final = R.cost_final;
+            if (blockIdx.x == 0 && round == 1) SCAL_STAMP(31);
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && round < 4) SCAL_STAMP(round * 6 + 5);

@@ -28,6 +28,7 @@ for k in range(12):
         nxt = sv[6 * (r + 1)] if r < 3 else s[5]
         rows.append(' '.join(f'{n}={(s[i + 1] - s[i]) * 0.01:.1f}' for i, n in enumerate(names)) + f' to-next-round={(nxt - s[5]) * 0.01:.1f}')
     print(f'scan {k}: blocks {st.n_edge[1]}+{st.n_plane[1]} iters {list(st.lm_iters)}')
-    print(f'   k_assoc_fit: edge thread {(ex[1] - ex[0]) * 0.01:.1f} us, plane thread {(ex[3] - ex[2]) * 0.01:.1f} us; knn5_half: edge query {(ex[5] - ex[4]) * 0.01:.1f} us')
+    print(f'   serial step of round 1: copy in {(ex[1] - ex[0]) * 0.01:.2f}, trust-region logic + candidate {(ex[6] - ex[1]) * 0.01:.2f} (of which the Cholesky solve of the last round: {(ex[3] - ex[2]) * 0.01:.2f}), copy out {(ex[7] - ex[6]) * 0.01:.2f} us')
+    if False: print(f'   k_assoc_fit: edge thread {(ex[1] - ex[0]) * 0.01:.1f} us, plane thread {(ex[3] - ex[2]) * 0.01:.1f} us; knn5_half: edge query {(ex[5] - ex[4]) * 0.01:.1f} us')
     for r, row in enumerate(rows):
         print(f'   round {r}: {row}   round total {(sv[6 * r + 5] - sv[6 * r]) * 0.01:.1f} us')
