@@ -503,10 +503,9 @@ __device__ __forceinline__ void associate_to_map(const double* x7, float px, flo
 }
 
 struct NNBuf {
-    float* px;  // [5][cap] neighbour coordinates, ascending (distance, map index)
-    float* py;
-    float* pz;
-    float* d5;  // [cap] squared distance of the 5th neighbour
+    float* rec;  // [cap][16]: the five neighbours of a slot as x y z triples, ascending (distance, map index), then the squared distance
+                 // of the 5th in [15] - one 64-byte line per slot, written by five lanes of the search, read by the one thread that fits
+                 // (SoA columns until round 3: 16 scattered 4-byte stores per slot, 1.8 MB of write traffic for 0.7 MB of payload)
     int cap;
 };
 
@@ -673,11 +672,10 @@ __device__ __forceinline__ void k_assoc_knn_body(const CSoA4& cs, const CSoA4& s
         if (active && hl < 5) {
             const bool have = mine >= 0;
             const float4 pt = have ? pool[mine] : make_float4(0.f, 0.f, 0.f, 0.f);
-            nb.px[hl * nb.cap + i] = pt.x;
-            nb.py[hl * nb.cap + i] = pt.y;
-            nb.pz[hl * nb.cap + i] = pt.z;
+            float* r = nb.rec + static_cast<size_t>(i) * 16 + 3 * hl;
+            r[0] = pt.x, r[1] = pt.y, r[2] = pt.z;
         }
-        if (active && hl == 0) nb.d5[i] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
+        if (active && hl == 5) nb.rec[static_cast<size_t>(i) * 16 + 15] = bp[4] >= 0 ? __uint_as_float(static_cast<unsigned>(bk[4] >> 32)) : 3.4e38f;
     }
 }
 SCAL_KERNEL(256, k_assoc_knn)
@@ -699,10 +697,10 @@ struct AssocFit {
         const int j = is_edge ? i : i - nc;
         const float ox = is_edge ? cs.x[j] : ss.x[j], oy = is_edge ? cs.y[j] : ss.y[j], oz = is_edge ? cs.z[j] : ss.z[j];
         double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0};
-        if (static_cast<double>(nb.d5[i]) < 1.0) {  // :585 / :653
-            float px[5], py[5], pz[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) px[k] = nb.px[k * nb.cap + i], py[k] = nb.py[k * nb.cap + i], pz[k] = nb.pz[k * nb.cap + i];
+        const float4* rec = reinterpret_cast<const float4*>(nb.rec + static_cast<size_t>(i) * 16);
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        if (static_cast<double>(r3.w) < 1.0) {  // :585 / :653
+            const float px[5] = {r0.x, r0.w, r1.z, r2.y, r3.x}, py[5] = {r0.y, r1.x, r1.w, r2.z, r3.y}, pz[5] = {r0.z, r1.y, r2.x, r2.w, r3.z};
             if (is_edge) {
                 double cx = 0, cy = 0, cz = 0;
 #pragma unroll
@@ -1559,8 +1557,8 @@ struct scal_map {
     DevBuf<int> fvalid, fkind;
     DevBuf<double> fcp, fpa, fpb, partials;
     DevBuf<LMSync> lm_sync;
-    DevBuf<float> nnx, nny, nnz, nnd5;
-    NNBuf nnbuf() { return NNBuf{nnx.p, nny.p, nnz.p, nnd5.p, slot_cap}; }
+    DevBuf<float> nnrec;
+    NNBuf nnbuf() { return NNBuf{nnrec.p, slot_cap}; }
     DevBuf<LMState> d_st;
     DevBuf<MapCounters> d_C2[NSETS];
     DevBuf<unsigned> surf_parts[NSETS];  // per-block bounding boxes of surf_in (written by the prefetch's gather)
@@ -1623,7 +1621,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
         A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 16));
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
-    A(c->nnx.alloc(5 * sc)); A(c->nny.alloc(5 * sc)); A(c->nnz.alloc(5 * sc)); A(c->nnd5.alloc(sc));
+    A(c->nnrec.alloc(16 * sc));
     A(c->partials.alloc(LM_PARTIAL_WORDS));
     A(c->lm_sync.alloc(1));
     A(c->d_st.alloc(1)); A(c->d_S.alloc(1)); A(c->d_nfull.alloc(4)); A(c->d_done.alloc(1));
