@@ -900,7 +900,7 @@ struct MergeNew {            // per class, MERGE_MAX entries
     int* cube;
     unsigned long long* pkey;    // (key << 13 | arrival index) in arrival order, ~0 = outside the cube window (k_map_pose_done)
     unsigned long long* sorted;  // the same, ascending; n_eff entries
-    unsigned long long* samp;    // [MERGE_MAX / 16] key of every 16th sorted entry (top level of k_merge_write's search)
+    unsigned long long* samp;    // [MERGE_MAX / 8] key of every 8th sorted entry (top level of k_merge_write's search)
     int* pre;                    // inserted (unmatched) runs that start before sorted position t, counted inside t's 512-block
     int* lb;                     // run heads: number of old points in front of the run
     unsigned char* hm;           // bit 0: run head, bit 1: run joins an old point
@@ -1077,7 +1077,7 @@ __device__ __forceinline__ void k_merge_lookup_body(const MergeArgs& a, const Ma
         nw.hm[t] = (head ? 1 : 0) | (matched ? 2 : 0);
         nw.lb[t] = lo;
         nw.pre[t] = pre;
-        if ((t & 15) == 0) nw.samp[t >> 4] = key;
+        if ((t & 7) == 0) nw.samp[t >> 3] = key;
     }
     if (threadIdx.x == 0) nw.blocktot[blk] = total;
 }
@@ -1104,7 +1104,7 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
     }
     if (static_cast<int>(blockIdx.x) >= MERGE_WRITE_GRID) return;  // registration blocks of the fused form
     __shared__ int s_base[MERGE_CHUNKS + 1];
-    __shared__ unsigned long long s_samp[MERGE_MAX / 16];
+    __shared__ unsigned long long s_samp[MERGE_MAX / 8];
     int b = blockIdx.x;
     int cls, part, nblk;
     if (b < MERGE_WB0) cls = 0, part = 0, nblk = MERGE_WB0;
@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
     const int n_eff = C->merge_neff[cls];
     const int n_old = S->n_map[cls];
     if (part == 0 && b * 256 >= n_old && b > 0) return;  // nothing to do (block 0 of each class always commits the new size)
-    const int n_samp = (n_eff + 15) >> 4;
+    const int n_samp = (n_eff + 7) >> 3;
     if (part == 0)
         for (int q = threadIdx.x; q < n_samp; q += 256) s_samp[q] = nw.samp[q];
     if (threadIdx.x < MERGE_CHUNKS) s_base[threadIdx.x + 1] = nw.blocktot[threadIdx.x];
@@ -1167,38 +1167,56 @@ __device__ __forceinline__ void merge_write_body(const MergeArgs& a, MapState* S
     if (part == 0) {
         for (int i = b * 256 + threadIdx.x; i < n_old; i += nblk * 256) {
             const unsigned long long k = a.okeys[cls][i];
+            // the point itself, fetched with its key: nothing below depends on the search
+            const float ix = in.x[i], iy = in.y[i], iz = in.z[i], iw = in.w[i];
+            const int cube = in.cube[i];
             int lo, hi;
-            {   // two-level lower bound among the sorted new keys: samples in LDS, then a window of <= 16 entries
+            {   // two-level lower bound among the sorted new keys: every 8th key in LDS, then a window of <= 7 entries and the sample
+                // behind it, fetched together (the 16-entry windows of rounds 2-3 took four dependent probes)
                 int x = 0, y = n_samp;
                 while (x < y) {
                     const int mid = (x + y) >> 1;
                     if (s_samp[mid] < k) x = mid + 1;
                     else y = mid;
                 }
-                lo = x > 0 ? (x - 1) * 16 + 1 : 0;
-                hi = min(n_eff, x * 16);
+                lo = x > 0 ? (x - 1) * 8 + 1 : 0;
+                hi = min(n_eff, x * 8);
                 if (lo > hi) lo = hi;
             }
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((nw.sorted[mid] >> MERGE_IDX_BITS) < k) lo = mid + 1;
-                else hi = mid;
-            }
-            const int o = i + pre_at(lo);
+            unsigned long long e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = lo + j < n_eff ? nw.sorted[lo + j] : ~0ull;
+            int cn = 0;  // entries of the window below k: the lower bound is lo + cn <= hi <= lo + 7
+#pragma unroll
+            for (int j = 0; j < 7; ++j) cn += (lo + j < hi && (e[j] >> MERGE_IDX_BITS) < k) ? 1 : 0;
+            const int at = lo + cn;
+            const int o = i + pre_at(at);
             // (0 + x) / 1: what the re-filter computes for a voxel holding this point alone
             float ax = 0.f, ay = 0.f, az = 0.f, aw = 0.f;
-            ax += in.x[i], ay += in.y[i], az += in.z[i], aw += in.w[i];
+            ax += ix, ay += iy, az += iz, aw += iw;
             int cnt = 1;
-            if (!key_nomerge(k)) {
-                int u = lo;
-                while (u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k) {  // new points of the same voxel, arrival order
-                    const int j = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
-                    ax += nw.x[j], ay += nw.y[j], az += nw.z[j], aw += nw.w[j];
-                    ++u, ++cnt;
+            if (!key_nomerge(k)) {  // new points of the same voxel, arrival order: first the fetched entries, then (rarely) beyond them
+                bool run = true;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j >= cn) {
+                        run = run && (e[j] >> MERGE_IDX_BITS) == k;  // ~0 (past the end) never equals a key
+                        if (run) {
+                            const int jn = static_cast<int>(e[j] & (MERGE_MAX - 1));
+                            ax += nw.x[jn], ay += nw.y[jn], az += nw.z[jn], aw += nw.w[jn];
+                            ++cnt;
+                        }
+                    }
+                if (run) {
+                    int u = lo + 8;
+                    while (u < n_eff && (nw.sorted[u] >> MERGE_IDX_BITS) == k) {
+                        const int jn = static_cast<int>(nw.sorted[u] & (MERGE_MAX - 1));
+                        ax += nw.x[jn], ay += nw.y[jn], az += nw.z[jn], aw += nw.w[jn];
+                        ++u, ++cnt;
+                    }
                 }
             }
             const float c = static_cast<float>(cnt);
-            const int cube = in.cube[i];
             const float ox = ax / c, oy = ay / c, oz = az / c;
             out.x[o] = ox, out.y[o] = oy, out.z[o] = oz, out.w[o] = aw / c, out.cube[o] = cube;
             if (a.prebuild) prebuild(o, ox, oy, oz, cube, k);
@@ -1618,7 +1636,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
     for (int k = 0; k < 2; ++k) {
         A(c->mnew[k].alloc(MERGE_MAX)); A(c->mcube[k].alloc(MERGE_MAX)); A(c->mpre[k].alloc(MERGE_MAX + 1)); A(c->mlb[k].alloc(MERGE_MAX));
         A(c->msorted[k].alloc(MERGE_MAX)); A(c->mhm[k].alloc(MERGE_MAX)); A(c->mblocktot[k].alloc(MERGE_CHUNKS));
-        A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 16));
+        A(c->mpkey[k].alloc(MERGE_MAX)); A(c->msamp[k].alloc(MERGE_MAX / 8));
     }
     A(c->fvalid.alloc(sc)); A(c->fkind.alloc(sc)); A(c->fcp.alloc(3 * sc)); A(c->fpa.alloc(3 * sc)); A(c->fpb.alloc(3 * sc));
     A(c->nnrec.alloc(16 * sc));
