@@ -131,12 +131,12 @@ def build_database(S, world_gen, a, n_scans, cap, device):
     return rev + [d.T for d in fill], len(rev)
 
 
-def cpp_host(mode, stream_file, n_warm, sc_db, resident=0, timeout=600):
+def cpp_host(mode, stream_file, n_warm, sc_db, resident=0, stream_mode=0, timeout=600):
     """The C++ host (sc-a-loam_amd/host/replay_main.cpp: includes include/scaloam_hip.h, links libscaloam_hip.so) as a child process."""
     if not os.path.exists(REPLAY):
         return {"error": "sc-a-loam_amd/bin/replay_main is not built"}
     try:
-        r = subprocess.run([REPLAY, "--scans", stream_file, "--mode", mode, "--warmup", str(n_warm), "--sc-db", str(sc_db), "--resident", str(resident)],
+        r = subprocess.run([REPLAY, "--scans", stream_file, "--mode", mode, "--warmup", str(n_warm), "--sc-db", str(sc_db), "--resident", str(resident), "--stream-mode", str(stream_mode)],
                            capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
             return {"error": f"replay_main rc {r.returncode}: {r.stderr[-300:]}"}
@@ -678,7 +678,8 @@ def main():
                     P.close()  # the child builds its own contexts (5.3 GB of grid pools each): free ours first
                     P = None
                 integ = cpp_host("integrated", f, 5, a.sc_db)
-                cpp = {"integrated": integ, "pipeline_resident": cpp_host("pipeline", f, 5, a.sc_db, resident=1),
+                integ1 = cpp_host("integrated", f, 5, a.sc_db, stream_mode=1)
+                cpp = {"integrated": integ, "integrated_own_streams": integ1, "pipeline_resident": cpp_host("pipeline", f, 5, a.sc_db, resident=1),
                        "pipeline_host_scans": cpp_host("pipeline", f, 5, a.sc_db, resident=0)}
             if "error" not in integ:
                 as_integrated = {"value": integ["scans_per_s"], "unit": "scans/s", "ms_per_scan": integ["ms_per_scan"],
@@ -686,7 +687,11 @@ def main():
                                  "note": "sc-a-loam_amd/host/replay_main.cpp --mode integrated (C++, a child process): the synchronous host-array entry "
                                          "points scal_features_run / scal_odom_step / scal_map_step / scal_voxel_downsample + scal_sc_insert_cloud + "
                                          "scal_sc_detect exactly as INTEGRATION.md sections 1-4 place them in the reference's four nodes, one thread per "
-                                         "stage, clouds handed over as host arrays; latency = scan in -> mapping pose on the host; not the metric's value"}
+                                         "stage, clouds handed over as host arrays; latency = scan in -> mapping pose on the host; not the metric's value",
+                                 "own_streams": None if "error" in integ1 else {
+                                     "value": integ1["scans_per_s"], "ms_per_scan": integ1["ms_per_scan"], "latency_ms_p50": integ1["latency_ms"]["p50"],
+                                     "note": "the same with scal_set_stream_mode(1): every node's context on its own stream, as four separate node "
+                                             "processes have it (in one process and the default mode all contexts share one in-order stream)"}}
         out = {
             "metric": METRIC, "value": value, "unit": "scans/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
             "repetitions": R, "timed_total_s": float(sum(rep_dt)), "rep_ms_per_step": [x / K * 1e3 for x in rep_dt],

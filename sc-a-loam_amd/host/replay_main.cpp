@@ -132,7 +132,7 @@ struct Channel {  // a ROS topic between two nodes: FIFO, bounded like the refer
 
 struct Args {
     std::string scans, mode = "pipeline", poses;
-    int lidar = SCAL_HDL64, n_scans = 64, warmup = 5, sc_db = 0, resident = 0, max_points = 0, steps = 0, sc = 1, ahead = 4;
+    int lidar = SCAL_HDL64, n_scans = 64, warmup = 5, sc_db = 0, resident = 0, max_points = 0, steps = 0, sc = 1, ahead = 4, stream_mode = 0;
     double min_range = 5.0, sc_thres = 0.4;
     float line = 0.4f, plane = 0.8f;
 };
@@ -390,6 +390,7 @@ int main(int argc, char** argv) {
         else if (k == "--sc-thres") a.sc_thres = std::atof(val());
         else if (k == "--resident") a.resident = std::atoi(val());
         else if (k == "--ahead") a.ahead = std::max(0, std::min(24, std::atoi(val())));
+        else if (k == "--stream-mode") a.stream_mode = std::atoi(val()) ? 1 : 0;
         else if (k == "--min-range") a.min_range = std::atof(val());
         else if (k == "--line") a.line = static_cast<float>(std::atof(val()));
         else if (k == "--plane") a.plane = static_cast<float>(std::atof(val()));
@@ -405,7 +406,8 @@ int main(int argc, char** argv) {
             }
         } else {
             std::fprintf(stderr, "usage: replay_main --scans FILE [--mode pipeline|integrated|serial] [--lidar hdl64|vlp16|hdl32|os1] [--min-range m]\n"
-                                 "                   [--line m --plane m] [--sc 0|1] [--sc-db n] [--sc-thres d] [--warmup n] [--steps n] [--resident 0|1] [--ahead n] [--poses FILE]\n");
+                                 "                   [--line m --plane m] [--sc 0|1] [--sc-db n] [--sc-thres d] [--warmup n] [--steps n] [--resident 0|1] [--ahead n] [--stream-mode 0|1] [--poses FILE]\n"
+                                 "  --stream-mode 1 (integrated / serial modes): every stage context on its own stream, as four separate node processes have it\n");
             return 2;
         }
     }
@@ -428,6 +430,7 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "unknown --mode %s\n", a.mode.c_str());
         return 2;
     }
+    if (a.mode != "pipeline") CHECK(scal_set_stream_mode(a.stream_mode));  // the pipeline object picks its own streams
     std::vector<Pose> all = run(a, scans, 0, W);  // warm-up: the same contexts carry on (map, poses, database)
     (void)hipDeviceSynchronize();
     for (double& v : g_stage_s) v = 0;
@@ -452,10 +455,10 @@ int main(int argc, char** argv) {
     }
     const Pose& fp = all.back();
     std::printf("{\"mode\": \"%s\", \"scans\": %d, \"warmup\": %d, \"seconds\": %.6f, \"scans_per_s\": %.3f, \"ms_per_scan\": %.6f, "
-                "\"latency_ms\": {\"p50\": %.4f, \"p99\": %.4f}, \"loops_detected\": %d, \"sc_db\": %d, \"resident\": %d, "
+                "\"latency_ms\": {\"p50\": %.4f, \"p99\": %.4f}, \"loops_detected\": %d, \"sc_db\": %d, \"resident\": %d, \"stream_mode\": %d, "
                 "\"final_map_pose\": {\"q\": [%.17g, %.17g, %.17g, %.17g], \"t\": [%.17g, %.17g, %.17g]}, "
                 "\"node_call_ms\": {\"A\": %.4f, \"B\": %.4f, \"C\": %.4f, \"D\": %.4f}, \"library\": \"%s\"}\n",
-                a.mode.c_str(), K, W, dt, K / dt, dt / K * 1e3, pct(0.5), pct(0.99), loops, a.sc_db, a.resident, fp.q[0], fp.q[1], fp.q[2], fp.q[3], fp.t[0],
+                a.mode.c_str(), K, W, dt, K / dt, dt / K * 1e3, pct(0.5), pct(0.99), loops, a.sc_db, a.resident, a.stream_mode, fp.q[0], fp.q[1], fp.q[2], fp.q[3], fp.t[0],
                 fp.t[1], fp.t[2], g_stage_s[0] / K * 1e3, g_stage_s[1] / K * 1e3, g_stage_s[2] / K * 1e3, g_stage_s[3] / K * 1e3, scal_version());
     std::fflush(stdout);
     if (g_pipe) scal_pipeline_destroy(g_pipe);  // joins its host threads; the per-stage contexts of the other modes are left to process exit
