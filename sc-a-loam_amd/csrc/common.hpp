@@ -112,6 +112,53 @@ struct PinBuf {
 
 inline int div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Host arrays of the synchronous entry points are the caller's (pageable) memory: a copy straight to or from them is staged by the
+// runtime in small synchronous pieces.  This keeps one pinned area per context instead: downloads land there with ONE asynchronous
+// copy each and are handed to the caller's arrays after the stream has been synchronised; uploads are copied in first.
+struct HostStage {
+    PinBuf<unsigned char> pin;
+    size_t used = 0;
+    struct Item {
+        void* dst;
+        size_t off, bytes;
+    };
+    std::vector<Item> items;
+    // the staging area holds `total` bytes from now on (only grows while nothing is pending); false: no memory, callers copy directly
+    bool reserve(size_t total) {
+        if (pin.p && pin.n >= total) return true;
+        if (used) return false;
+        if (pin.alloc(total) != SCAL_OK) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return true;
+    }
+    hipError_t d2h(void* user, const void* dev, size_t bytes, hipStream_t s) {
+        if (!bytes) return hipSuccess;
+        const size_t need = (bytes + 255) & ~static_cast<size_t>(255);
+        if (!pin.p || used + need > pin.n) return hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, s);
+        const hipError_t e = hipMemcpyAsync(pin.p + used, dev, bytes, hipMemcpyDeviceToHost, s);
+        items.push_back({user, used, bytes});
+        used += need;
+        return e;
+    }
+    hipError_t h2d(void* dev, const void* user, size_t bytes, hipStream_t s) {
+        if (!bytes) return hipSuccess;
+        const size_t need = (bytes + 255) & ~static_cast<size_t>(255);
+        if (!pin.p || used + need > pin.n) return hipMemcpyAsync(dev, user, bytes, hipMemcpyHostToDevice, s);
+        std::memcpy(pin.p + used, user, bytes);
+        const hipError_t e = hipMemcpyAsync(dev, pin.p + used, bytes, hipMemcpyHostToDevice, s);
+        used += need;
+        return e;
+    }
+    // the stream the copies were queued on has been synchronised: deliver the downloads, the area is free again
+    void finish() {
+        for (const Item& it : items) std::memcpy(it.dst, pin.p + it.off, it.bytes);
+        items.clear();
+        used = 0;
+    }
+};
+
 // Optional per-kernel timing (bench.py's roofline leg).  The start/stop events are attached to the kernel's own dispatch
 // (hipExtLaunchKernelGGL), so they read the dispatch's begin/end timestamps and put no extra packet on the stream: separate
 // hipEventRecord calls cost ~5 us of stream time each, more than many of the kernels they would bracket.

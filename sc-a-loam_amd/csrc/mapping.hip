@@ -1556,6 +1556,7 @@ struct scal_map {
     VoxelFilter vf, vf_side, vf_corner;  // main stream / prefetch (surf, side stream) / prefetch (corner, behind stage A): no shared scratch
     MapStore map[2];  // corner, surf
     GridStore grid[2];
+    HostStage hs_reg;               // pinned landing area of the registered cloud (host-array entry points, first use)
     bool grid_fixed = false;        // both fixed pools exist: speculative steps build the grid in one launch
     bool grid_prebuilt = false;     // the last queued step was a speculative one: its merge write leaves the next step's grid
     int grid_cap_now[2] = {0, 0};   // <= fixed_cap (scal_map_debug_set_grid_cap lowers it to force the overflow path in tests)
@@ -2353,8 +2354,10 @@ extern "C" int scal_map_step(scal_map_t* c, const float* corner_last, int n_corn
     }
     if (have_full && registered) {
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
-        SCAL_HIP(op_memcpy_async(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        (void)c->hs_reg.reserve((size_t)c->scan_cap * 16 + 4096);
+        SCAL_HIP(c->hs_reg.d2h(registered, c->aos.p, sizeof(float) * 4 * n_full, s));
         SCAL_HIP(op_stream_synchronize(s));
+        c->hs_reg.finish();
     }
     return SCAL_OK;
 }
@@ -2781,8 +2784,10 @@ extern "C" int scal_map_adapter_finish(scal_map_t* c, const double* q_w_curr, co
     if (e.have_full && registered) {
         const int n_full = c->h_misc.p[0];
         launch_interleave(s, c->d_nfull.p, n_full, c->full_out.cv(), c->aos.p);
-        SCAL_HIP(op_memcpy_async(registered, c->aos.p, sizeof(float) * 4 * n_full, hipMemcpyDeviceToHost, s));
+        (void)c->hs_reg.reserve((size_t)c->scan_cap * 16 + 4096);
+        SCAL_HIP(c->hs_reg.d2h(registered, c->aos.p, sizeof(float) * 4 * n_full, s));
         SCAL_HIP(op_stream_synchronize(s));
+        c->hs_reg.finish();
     }
     return SCAL_OK;
 }

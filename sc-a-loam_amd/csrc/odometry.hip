@@ -535,6 +535,7 @@ struct scal_odom {
     DevBuf<OdomCounters> d_C;
     PinBuf<LMState> h_st;       // [MAX_STEPS]
     PinBuf<OdomCounters> h_up;  // upload staging of scal_odom_step
+    HostStage hs;               // pinned staging of its four host clouds (first call)
     // Ceres-adapter mode (scal_odom_adapter_begin ... _finish)
     bool adapter_active = false, adapter_solve = false;
     DevBuf<int> bl_live, bl_rowoff, bl_counts;
@@ -741,6 +742,8 @@ static int odom_upload(scal_odom* c, const float* sharp, int n_sharp, const floa
                        const float* less_flat, int n_less_flat) {
     hipStream_t s = c->stream;
     SCAL_HIP(op_stream_synchronize(s));  // the upload staging may still feed the previous call's copy
+    c->hs.finish();
+    (void)c->hs.reserve(((size_t)2 * c->slot_cap + c->feat_cap + c->cap) * 16 + 4096);
     OdomCounters& H = *c->h_up.p;
     // keep the device-resident n_corner_last / n_surf_last, refresh the per-scan part from pinned memory
     OdomCounters fresh;
@@ -752,7 +755,7 @@ static int odom_upload(scal_odom* c, const float* sharp, int n_sharp, const floa
                             hipMemcpyHostToDevice, s));
     auto up = [&](const float* src, int n, OSoA& dst) -> int {
         if (n > 0) {
-            SCAL_HIP(op_memcpy_async(c->aos.p, src, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+            SCAL_HIP(c->hs.h2d(c->aos.p, src, sizeof(float) * 4 * n, s));
             launch_deinterleave(s, c->aos.p, n, dst.v());
         }
         return SCAL_OK;

@@ -651,6 +651,7 @@ using namespace scal;
 struct scal_sc {
     scal_sc_config cfg;
     hipStream_t stream = nullptr;
+    HostStage hs;  // pinned staging of scal_sc_insert_cloud's host array (first call)
     // keyframe filter of the *_features entry points: on its own lane in the stage-pipelined mode (the filter is three quarters of a
     // keyframe's device time, descriptor + search are short), on `stream` otherwise.  One set of filter outputs: ev_ds = filter
     // done (the main stream waits for it), ev_tail = descriptor built from them (the next filter waits for it).
@@ -830,7 +831,16 @@ static int upload_points(scal_sc* c, const float* xyzi, int n) {
         SCAL_TRY(c->pts.alloc((size_t)nc * 4));
         c->pts_cap = nc;
     }
-    if (n > 0) SCAL_HIP(op_memcpy_async(c->pts.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        // through pinned staging (four clouds' worth; when it is full the stream is synchronised once and the area starts over)
+        const size_t bytes = sizeof(float) * 4 * n;
+        (void)c->hs.reserve(std::max<size_t>(4 * bytes, (size_t)1 << 22));
+        if (c->hs.pin.p && c->hs.used + bytes + 256 > c->hs.pin.n && bytes + 256 <= c->hs.pin.n) {
+            SCAL_HIP(op_stream_synchronize(c->stream));
+            c->hs.finish();
+        }
+        SCAL_HIP(c->hs.h2d(c->pts.p, xyzi, bytes, c->stream));
+    }
     return SCAL_OK;
 }
 

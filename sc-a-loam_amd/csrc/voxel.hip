@@ -449,6 +449,7 @@ struct scal_voxel {
     VoxelFilter vf;
     DevBuf<float> aos, ix, iy, iz, iw, ox, oy, oz, ow;
     DevBuf<int> d_n;  // [0] in, [1] out
+    HostStage hs;     // pinned staging of the host-array entry point (first call)
     std::mutex mu;
 };
 
@@ -506,7 +507,8 @@ static int voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float lea
     hipStream_t s = c->stream;
     const float* d_in = xyzi;
     if (!on_device) {
-        SCAL_HIP(op_memcpy_async(c->aos.p, xyzi, sizeof(float) * 4 * n, hipMemcpyHostToDevice, s));
+        (void)c->hs.reserve((size_t)c->cap * 16 + 4096);
+        SCAL_HIP(c->hs.h2d(c->aos.p, xyzi, sizeof(float) * 4 * n, s));
         d_in = c->aos.p;
     }
     SCAL_HIP(op_memcpy_async(c->d_n.p, &n, sizeof(int), hipMemcpyHostToDevice, s));
@@ -519,13 +521,15 @@ static int voxel_downsample(scal_voxel_t* c, const float* xyzi, int n, float lea
     int m = 0;
     SCAL_HIP(op_memcpy_async(&m, c->d_n.p + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     SCAL_HIP(op_stream_synchronize(s));
+    c->hs.finish();  // the upload's staging is free again
     if (hm.error) {
         set_error("voxel grid bounding box needs more than 45 key bits (or 16383 cells per axis on the small-cloud path)");
         return SCAL_E_CAPACITY;
     }
     if (!on_device) {
-        SCAL_HIP(op_memcpy_async(out_xyzi, c->aos.p, sizeof(float) * 4 * m, hipMemcpyDeviceToHost, s));
+        SCAL_HIP(c->hs.d2h(out_xyzi, c->aos.p, sizeof(float) * 4 * m, s));
         SCAL_HIP(op_stream_synchronize(s));
+        c->hs.finish();
     }
     *n_out = m;
     return SCAL_OK;
