@@ -559,12 +559,28 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, 
     __syncthreads();
     const int tile = blockIdx.y * 4 + w;
     const T* fa = frag + static_cast<size_t>(tile) * GKS * 64 + lane;
-    const T* bp = ext + ((lane >> 4) - (lane & 15) + 16);
-    acc_t acc[GE][4];
+    // The (entry, shift) pairs of the GE entries form ONE axis of GE x 60 columns, cut into 16-column MFMA tiles: 15 tiles for four
+    // entries, 30 for eight - no padded shifts (rounds 1-2 gave every entry four tiles of its own, 64 columns for 60 shifts: 6 % of the
+    // MFMAs computed nothing).  Column c = 16 t + n (n = lane & 15) belongs to entry e = c / 60 at shift s = c - 60 e; its operand
+    // sits at ext[e][r][col - s + 64] = base(lane) + e * (entry stride + 60) - 16 t + r * GROW + col.  For most tiles e is the same
+    // for all lanes (the offset is an immediate); the tile that holds an entry's last columns and the next entry's first ones - c
+    // crosses 60 (e + 1) at n = thr_e = 60 (e + 1) mod 16 - adds a per-lane adjustment kept in one register per entry.
+    constexpr int NT = GE * NS / 16;
+    constexpr int ESTR = NR * GROW + NS;
+    static_assert(GE * NS % 16 == 0, "the packed shift axis must be whole tiles");
+    const int n16 = lane & 15;
+    const T* bp = ext + ((lane >> 4) - n16 + 64 - 48);  // - 48: the offsets below stay non-negative
+    int xadj[GE];
 #pragma unroll
-    for (int e = 0; e < GE; ++e)
+    for (int e = 0; e < GE; ++e) xadj[e] = n16 >= ((NS * (e + 1)) & 15) ? ESTR : 0;
+    auto toff = [&](int t) {  // element offset of tile t's operand from bp (+ r * GROW + 4 j): compile-time part + per-lane part
+        const int e_lo = (16 * t) / NS;
+        const int thr = NS * (e_lo + 1) - 16 * t;  // lanes n >= thr belong to the next entry (only if thr < 16)
+        return e_lo * ESTR - 16 * t + 48 + (thr < 16 ? xadj[e_lo] : 0);
+    };
+    acc_t acc[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[e][t] = acc_t{0, 0, 0, 0};
+    for (int t = 0; t < NT; ++t) acc[t] = acc_t{0, 0, 0, 0};
     // one ring (15 k-steps) of the query operand lives in registers; each value is reloaded for the next ring right after its
     // MFMAs have been issued, so the load has the other 14 k-steps to land
     T a[15];
@@ -572,11 +588,9 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, 
     for (int j = 0; j < 15; ++j) a[j] = fa[j * 64];
     // the circulant operands of a k-step are read from LDS one k-step ahead (bn) and the issue order is pinned to one
     // ds_read per MFMA, so no MFMA waits on the read issued just in front of it
-    T bc[GE * 4], bn[GE * 4];
+    T bc[NT], bn[NT];
 #pragma unroll
-    for (int e = 0; e < GE; ++e)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bc[e * 4 + t] = bp[e * (NR * GROW) + 16 * (3 - t)];
+    for (int t = 0; t < NT; ++t) bc[t] = bp[toff(t)];
     for (int r = 0; r < NR; ++r) {
         const T* br = bp + r * GROW;
         const T* fn = fa + (r + 1 < NR ? r + 1 : r) * 15 * 64;
@@ -585,60 +599,65 @@ __global__ void __launch_bounds__(256, 2) k_sc_gram(const T* __restrict__ bhat, 
             // next k-step: j + 1 of this ring, or the first of the next ring (the last ring re-reads its own: unused)
             const T* bx = j + 1 < 15 ? br + 4 * (j + 1) : (r + 1 < NR ? br + GROW : br);
 #pragma unroll
-            for (int e = 0; e < GE; ++e)
+            for (int t = 0; t < NT; ++t) bn[t] = bx[toff(t)];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bn[e * 4 + t] = bx[e * (NR * GROW) + 16 * (3 - t)];
-#pragma unroll
-            for (int e = 0; e < GE; ++e)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[e][t] = G::mma(a[j], bc[e * 4 + t], acc[e][t]);
+            for (int t = 0; t < NT; ++t) acc[t] = G::mma(a[j], bc[t], acc[t]);
             a[j] = fn[j * 64];
 #pragma unroll
-            for (int i = 0; i < GE * 4; ++i) {
+            for (int i = 0; i < NT; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS read
             }
 #pragma unroll
-            for (int i = 0; i < GE * 4; ++i) bc[i] = bn[i];
+            for (int i = 0; i < NT; ++i) bc[i] = bn[i];
         }
     }
-    // acc[e][t][reg]: query = 16 tile + row(lane, reg), shift = 16 t + (lane & 15)
+    // acc[t][reg]: query = 16 tile + row(lane, reg), column c = 16 t + n16 -> (entry, shift)
     const unsigned long long m60 = (1ull << NS) - 1;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int q = tile * 16 + G::row(lane, reg);
         const unsigned long long ma = qmask[q];
+        double bd[GE];
+        int bs[GE];
+#pragma unroll
+        for (int e = 0; e < GE; ++e) bd[e] = 1e300, bs[e] = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int e_lo = (16 * t) / NS;
+            const int thr = NS * (e_lo + 1) - 16 * t;
+            const bool next = thr < 16 && n16 >= thr;   // this lane's column of tile t belongs to entry e_lo + 1
+            const int s = 16 * t + n16 - NS * e_lo - (next ? NS : 0);
+            const unsigned long long mb = (thr < 16 && e_lo + 1 < GE) ? (next ? bmask[e_lo + 1] : bmask[e_lo]) : bmask[e_lo];
+            const unsigned long long rot = ((mb << s) | (mb >> (NS - s))) & m60;
+            const int eff = __popcll(ma & rot);
+            double dd;
+            if (sizeof(T) == 4)
+                dd = 1.0 - static_cast<double>(acc[t][reg]) * inv_eff[eff];
+            else
+                dd = 1.0 - acc[t][reg] / eff;
+            if (eff == 0 || !(dd == dd)) dd = 1e300;
+            // ascending t = ascending shift inside an entry, so "first strict minimum" keeps the smallest shift
+            if (!next && dd < bd[e_lo]) bd[e_lo] = dd, bs[e_lo] = s;
+            if (thr < 16 && e_lo + 1 < GE) {
+                if (next && dd < bd[e_lo + 1]) bd[e_lo + 1] = dd, bs[e_lo + 1] = s;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < GE; ++e) {
-            const unsigned long long mb = bmask[e];
-            double bd = 1e300;
-            int bs = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int s = 16 * t + (lane & 15);
-                if (s < NS) {
-                    const unsigned long long rot = ((mb << s) | (mb >> (NS - s))) & m60;
-                    const int eff = __popcll(ma & rot);
-                    double dd;
-                    if (sizeof(T) == 4)
-                        dd = 1.0 - static_cast<double>(acc[e][t][reg]) * inv_eff[eff];
-                    else
-                        dd = 1.0 - acc[e][t][reg] / eff;
-                    if (eff == 0 || !(dd == dd)) dd = 1e300;
-                    if (dd < bd) bd = dd, bs = s;
-                }
-            }
+            double b1 = bd[e];
+            int s1 = bs[e];
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) {
-                const double ob = __shfl_xor(bd, o, 64);
-                const int os = __shfl_xor(bs, o, 64);
-                if (ob < bd || (ob == bd && os < bs)) bd = ob, bs = os;
+                const double ob = __shfl_xor(b1, o, 64);
+                const int os = __shfl_xor(s1, o, 64);
+                if (ob < b1 || (ob == b1 && os < s1)) b1 = ob, s1 = os;
             }
-            if (!(bd < 10000000)) bd = 10000000, bs = 0;
+            if (!(b1 < 10000000)) b1 = 10000000, s1 = 0;
             const int b = chunk * GE + e;
-            if ((lane & 15) == 0 && q < nq && b < nd) {
-                dist[static_cast<size_t>(q) * nd + b] = bd;
-                shift[static_cast<size_t>(q) * nd + b] = bs;
+            if (n16 == 0 && q < nq && b < nd) {
+                dist[static_cast<size_t>(q) * nd + b] = b1;
+                shift[static_cast<size_t>(q) * nd + b] = s1;
             }
         }
     }
