@@ -210,7 +210,7 @@ def main():
         "descriptors": n, "ms_per_matrix": dt * 1e3, "dtype": "f64",
         "roofline": {"bound": "mfma", "kernel": "k_sc_gram", "achieved": ach, "peak": PEAK_F64_MFMA, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA,
                      "avg_launch_ms": gram_s * 1e3, "algorithmic_flop_per_launch": FLOP_PER_PAIR * n * n, "issued_flop_per_launch":
-                     2048.0 * 15 * 300 * 4 * ((n + 63) // 64) * ((n + 3) // 4),  # 15 MFMAs of 16x16x4 per k-step and wave: the (entry, shift) axis holds no padded shifts "measured_issue_peak": probe, "traffic": None},
+                     2048.0 * 15 * 300 * 4 * ((n + 63) // 64) * ((n + 3) // 4), "measured_issue_peak": probe, "traffic": None},
         "prep_ms": prep_ms,
         "mode3_f32_mfma": {"kernel": "k_sc_gram_f32", "avg_launch_ms": f32_ms / f32_cnt, "pairs_per_s": n * n / (f32_ms / f32_cnt * 1e-3),
                            "achieved": FLOP_PER_PAIR * n * n / (f32_ms / f32_cnt * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
