@@ -1521,7 +1521,6 @@ struct scal_map {
     int next_set = 0;  // ring allocation of input sets
     hipEvent_t ev_pre[NSETS] = {};    // side stream: surf stack ready
     hipEvent_t ev_pre_a[NSETS] = {};  // features stream: corner stack ready
-    hipEvent_t ev_gather[NSETS] = {}; // features stream: inputs gathered
     std::deque<MapStep> steps;
     hipEvent_t ev_pose[NSLOTS] = {}, ev_done[NSLOTS] = {};
     int next_slot = 0;
@@ -1722,7 +1721,6 @@ extern "C" void scal_map_destroy(scal_map_t* c) {
     for (int k = 0; k < scal_map::NSETS; ++k) {
         if (c->ev_pre[k]) (void)hipEventDestroy(c->ev_pre[k]);
         if (c->ev_pre_a[k]) (void)hipEventDestroy(c->ev_pre_a[k]);
-        if (c->ev_gather[k]) (void)hipEventDestroy(c->ev_gather[k]);
     }
     for (int k = 0; k < scal_map::NSLOTS; ++k) {
         if (c->ev_pose[k]) (void)hipEventDestroy(c->ev_pose[k]);
@@ -2386,7 +2384,6 @@ extern "C" int scal_map_prefetch_begin(scal_map_t* c, scal_features_t* feat) {
     if (!c->ev_pre[nset]) {
         SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre[nset], EV_DEVICE_ONLY));
         SCAL_HIP(hipEventCreateWithFlags(&c->ev_pre_a[nset], EV_DEVICE_ONLY));
-        SCAL_HIP(hipEventCreateWithFlags(&c->ev_gather[nset], EV_DEVICE_ONLY));
     }
     // The gather (it also stores per-block bounding boxes of the surf cloud for the filter) and the small corner filter ride on the
     // features context's own stream, right behind stage A; the surf filter runs on the side stream, which it shares with
@@ -2397,7 +2394,6 @@ extern "C" int scal_map_prefetch_begin(scal_map_t* c, scal_features_t* feat) {
                      CSoA4{v.lfx, v.lfy, v.lfz, v.lfi}, &v.P->n_less_flat, c->corner_in(nset).v(), c->surf_in(nset).v(), c->d_C(nset).p, c->scan_cap, nbc,
                      c->surf_parts[nset].p);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(op_event_record(c->ev_gather[nset], sa));
     SCAL_TRY(enqueue_corner_filter(c, c->vf_corner, sa, ls_cap, nset));
     SCAL_HIP(op_event_record(c->ev_pre_a[nset], sa));
     c->pf_half[c->n_half].feat = feat, c->pf_half[c->n_half].set = nset, c->pf_half[c->n_half].generation = v.generation;
@@ -2421,11 +2417,12 @@ extern "C" int scal_map_prefetch_finish(scal_map_t* c, scal_features_t* feat) {
     const scal_map::Prefetch h = c->pf_half[0];
     for (int i = 1; i < c->n_half; ++i) c->pf_half[i - 1] = c->pf_half[i];
     c->n_half--;
-    SCAL_HIP(op_stream_wait_event(c->side, c->ev_gather[h.set], 0));
-    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, h.set, true));
-    // the side stream also takes in the corner filter's event (long finished by now: it is a quarter of the surf filter's work), so
-    // that the step waits for ONE event: every wait is a barrier packet of ~3 us on the chain the pipeline is bound by
+    // ONE event from the features stream, recorded behind gather AND corner filter: the surf filter starts ~35 us later than it could
+    // (it has that slack: the side lane is busy 190 of every ~217 us and the step needs its output a whole stage B later), the
+    // features stream saves an event record between two kernels of the chain the pipeline is bound by, and the step waits for one
+    // event that covers both halves
     SCAL_HIP(op_stream_wait_event(c->side, c->ev_pre_a[h.set], 0));
+    SCAL_TRY(enqueue_surf_filter(c, c->vf_side, c->side, cap, h.set, true));
     SCAL_HIP(op_event_record(c->ev_pre[h.set], c->side));
     c->pf[c->n_pf] = h;
     c->n_pf++;
