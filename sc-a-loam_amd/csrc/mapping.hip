@@ -21,6 +21,7 @@
 //   registration (:845-849)            k_transform_cloud
 #include "common.hpp"
 #include <mutex>
+#include <atomic>
 #include "device_utils.hpp"
 #include "voxel_dev.hpp"
 #include "radix_sort.hpp"
@@ -1256,6 +1257,10 @@ struct MapResult {
     LMState st;
     MapCounters C1, C2;
     MapState S1, S2;
+    // Written last, behind a system-scope fence, by the kernels that fill (1) and (2): the sequence number of the step.  On the
+    // speculative chain the host polls these words instead of waiting for events - an event record behind a kernel is a packet of
+    // its own on the chain and, for an event the host reads memory behind, a cache write-back (~6 us each, two per step).
+    unsigned seq_pose, seq_done;
 };
 
 // k_merge_write.  tail.fused = 0: the merge write alone.  tail.fused = 1 (speculative chain): the launch also carries the registration
@@ -1364,6 +1369,7 @@ struct PoseDoneNew {
 };
 struct MapPoseDone {
     int active;  // the hook runs behind the second outer iteration only
+    unsigned seq;  // the step's sequence number, published in MapResult::seq_pose when the host slot is complete
     MapState* S;
     const LMState* st;
     MapCounters* C;
@@ -1410,6 +1416,9 @@ struct MapPoseDone {
         copy_words(&host->st, st, sizeof(LMState));
         copy_words(&host->C1, C, sizeof(MapCounters));
         copy_words(&host->S1, S, sizeof(MapState));
+        __threadfence_system();  // every thread's part of the slot is out before ...
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&host->seq_pose, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // ... the word the host polls
     }
     __device__ __forceinline__ void operator()(int, int, int) const {}
 };
@@ -1421,11 +1430,14 @@ __device__ __forceinline__ void k_map_pose_done_body(const MapPoseDone& pd) {
 SCAL_KERNEL(256, k_map_pose_done)
 
 // End of a step: the new map sizes are committed (unless the speculative chain was stopped), counters and state go to the host.
-__device__ __forceinline__ void k_map_end_body(MapState* S, const MapCounters* C, MapResult* host) {
+__device__ __forceinline__ void k_map_end_body(MapState* S, const MapCounters* C, MapResult* host, unsigned seq) {
     if (threadIdx.x == 0 && !S->abort) S->n_map[0] = C->n_map_new[0], S->n_map[1] = C->n_map_new[1];
     __syncthreads();
     copy_words(&host->C2, C, sizeof(MapCounters));
     copy_words(&host->S2, S, sizeof(MapState));
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&host->seq_done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 SCAL_KERNEL(256, k_map_end)
 
@@ -1493,6 +1505,7 @@ struct MapStep {
     bool confirmed = false;       // the insertion is known to have completed; a step leaves the queue when both hold
     bool failed = false;          // the LM solve was abandoned twice (MAP_ABORT_LM): nothing of this step was committed
     bool prebuilt = false;        // the previous step's merge write left this step's cell grid, keys and counts in place
+    unsigned seq = 0;             // set at every (re)launch: what the step's kernels publish in MapResult::seq_pose / seq_done
     unsigned feat_generation = 0; // run of `feat` this step was enqueued for: a replay must find the same scan in the context
     int n_corner_bound = 0, n_surf_bound = 0;
     int insert_path = 0;
@@ -1557,6 +1570,7 @@ struct scal_map {
     GridStore grid[2];
     HostStage hs_reg;               // pinned landing area of the registered cloud (host-array entry points, first use)
     bool grid_fixed = false;        // both fixed pools exist: speculative steps build the grid in one launch
+    unsigned seq_counter = 0;       // MapStep::seq of the last launch
     bool grid_prebuilt = false;     // the last queued step was a speculative one: its merge write leaves the next step's grid
     int grid_cap_now[2] = {0, 0};   // <= fixed_cap (scal_map_debug_set_grid_cap lowers it to force the overflow path in tests)
     RadixSort sorter;
@@ -1669,6 +1683,7 @@ extern "C" int scal_map_create(const scal_map_config* cfg, scal_map_t** out) {
             }
         }
     }
+    if (rc == SCAL_OK) std::memset(static_cast<void*>(c->res.p), 0, sizeof(MapResult) * scal_map::NSLOTS);  // seq_pose / seq_done: no step has reported
     c->lane = stage_lane(STAGE_MAP);
     if (rc == SCAL_OK) rc = lm_check_residency<AssocFit, MapPoseDone>(c->cfg.device);
     // per device, hence here and not behind a process-wide flag at the first launch
@@ -1855,7 +1870,7 @@ int launch_tail(scal_map* c, const MapStep& e) {
                                c->full_out.v());
         }
     }
-    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot, e.seq);
     SCAL_HIP(hipGetLastError());
     SCAL_HIP(op_event_record(c->ev_done[e.slot], s));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, s));  // the registration transform reads the full-resolution cloud last
@@ -1865,7 +1880,7 @@ int launch_tail(scal_map* c, const MapStep& e) {
 MapPoseDone make_pose_done(scal_map* c, const MapStep& e) {
     MapCounters* C = c->d_C(e.set).p;
     MapPoseDone pd;
-    pd.active = 1;
+    pd.active = 1, pd.seq = e.seq;
     pd.S = c->d_S.p, pd.st = c->d_st.p, pd.C = C, pd.host = c->res.p + e.slot;
     for (int k = 0; k < 2; ++k) {
         pd.nw.stack[k] = k == 0 ? c->corner_stack(e.set).cv() : c->surf_stack(e.set).cv();
@@ -1939,8 +1954,43 @@ int launch_pose_part(scal_map* c, const MapStep& e, bool prepare_only = false) {
         launch_lm_solve(s, F, &C->n_slots, st, &C->solve_on, c->partials.p, c->lm_sync.p, outer, &S->abort, fit, pd, "k_lm_solve_map");
     }
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(op_event_record(c->ev_pose[e.slot], s));
+    if (!e.fast) SCAL_HIP(op_event_record(c->ev_pose[e.slot], s));  // a queued step announces its pose through MapResult::seq_pose
     return SCAL_OK;
+}
+
+// The host's view of a queued (speculative) step: the two words its kernels publish last.  A blocking wait spins on the word; while
+// it does, it checks now and then that the stream still has work - a stream that has gone idle without the word means the kernels
+// never ran (a launch error): SCAL_E_HIP instead of a hang.
+static bool step_flag_set(const volatile unsigned* w, unsigned seq) {
+    if (*w != seq) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+static int step_flag_wait(scal_map* c, const volatile unsigned* w, unsigned seq) {
+    if (g_recorder) SCAL_HIP(op_flush_for_wait(__FILE__, __LINE__));  // launches still sitting in this thread's list would never run
+    for (unsigned spins = 0;; ++spins) {
+        if (step_flag_set(w, seq)) return SCAL_OK;
+        if ((spins & 0xfff) == 0xfff && hipStreamQuery(c->stream) == hipSuccess) {
+            if (step_flag_set(w, seq)) return SCAL_OK;
+            set_error("scal_map: the stream is idle and the step never reported (a kernel launch failed?)");
+            return SCAL_E_HIP;
+        }
+        __builtin_ia32_pause();
+    }
+}
+static int wait_pose(scal_map* c, const MapStep& e) {
+    if (e.fast) return step_flag_wait(c, &c->res.p[e.slot].seq_pose, e.seq);
+    SCAL_HIP(op_event_synchronize(c->ev_pose[e.slot]));
+    return SCAL_OK;
+}
+static int wait_done(scal_map* c, const MapStep& e) {
+    if (e.fast) return step_flag_wait(c, &c->res.p[e.slot].seq_done, e.seq);
+    SCAL_HIP(op_event_synchronize(c->ev_done[e.slot]));
+    return SCAL_OK;
+}
+static bool done_ready(scal_map* c, const MapStep& e) {
+    if (e.fast) return step_flag_set(&c->res.p[e.slot].seq_done, e.seq);
+    return op_event_query(c->ev_done[e.slot]) == hipSuccess;
 }
 
 int report_device_error(scal_map* c, int err) {
@@ -1987,6 +2037,7 @@ int drop_prebuilt_grid(scal_map* c) {
 int run_general_once(scal_map* c, MapStep& e) {
     e.fast = false, e.prebuilt = false;
     e.par = c->cur;
+    e.seq = ++c->seq_counter;
     SCAL_TRY(drop_prebuilt_grid(c));  // a general step starts and ends with both grid sets empty
     c->n_general++;
     SCAL_TRY(launch_pose_part(c, e));
@@ -2022,7 +2073,7 @@ int general_insert(scal_map* c, MapStep& e) {
     e.insert_path = 1;
     if (try_merge) {
         SCAL_TRY(launch_insert_merge(c, e));
-        SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot);
+        SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, s, c->d_S.p, C, c->res.p + e.slot, e.seq);
         SCAL_HIP(op_stream_synchronize(s));
         if (R.S2.abort) {  // a case the merge does not cover: redo with the full sort
             SCAL_HIP(op_memset_async(&c->d_S.p->abort, 0, sizeof(int), s));
@@ -2052,12 +2103,12 @@ int launch_fast(scal_map* c, MapStep& e) {
     e.par = c->cur;
     e.insert_path = 1;
     e.prebuilt = c->grid_prebuilt && c->grid_fixed;
+    e.seq = ++c->seq_counter;  // a fresh number at every launch: a replayed step must not be taken for its stopped first run
     c->n_fast++;
     SCAL_TRY(launch_pose_part(c, e));
     SCAL_TRY(launch_insert_merge(c, e, true));
-    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, c->stream, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot);
+    SCAL_LAUNCH("k_map_end", k_map_end, dim3(1), dim3(256), 0, c->stream, c->d_S.p, c->d_C(e.set).p, c->res.p + e.slot, e.seq);
     SCAL_HIP(hipGetLastError());
-    SCAL_HIP(op_event_record(c->ev_done[e.slot], c->stream));
     if (e.feat) SCAL_TRY(features_note_reader(e.feat, c->stream));  // the registration transform reads the full-resolution cloud last
     c->cur = e.par ^ 1;
     c->grid_prebuilt = c->grid_fixed;
@@ -2162,8 +2213,8 @@ int confirm_steps(scal_map* c, bool wait) {
         if (c->steps[i].confirmed) continue;
         const int slot = c->steps[i].slot;
         if (wait) {
-            SCAL_HIP(op_event_synchronize(c->ev_done[slot]));
-        } else if (op_event_query(c->ev_done[slot]) != hipSuccess) {
+            SCAL_TRY(wait_done(c, c->steps[i]));
+        } else if (!done_ready(c, c->steps[i])) {
             break;
         }
         const MapResult& R = c->res.p[slot];
@@ -2202,8 +2253,7 @@ int map_make_room(scal_map* c) {
             set_error("scal_map: %d steps are queued and not collected", scal_map::MAX_STEPS);
             return SCAL_E_STATE;
         }
-        const int slot = c->steps.front().slot;
-        SCAL_HIP(op_event_synchronize(c->ev_done[slot]));
+        SCAL_TRY(wait_done(c, c->steps.front()));
         SCAL_TRY(map_poll(c));
     }
     return SCAL_OK;
@@ -2249,7 +2299,7 @@ int map_collect_pose(scal_map* c, double* q_out, double* t_out, scal_map_stats* 
     }
     const int slot = pe->slot;
     for (int round = 0;; ++round) {
-        SCAL_HIP(op_event_synchronize(c->ev_pose[slot]));
+        SCAL_TRY(wait_pose(c, *pe));
         if (pe->failed || (!c->res.p[slot].S1.abort && c->res.p[slot].st.termination != 5)) break;
         if (round > scal_map::MAX_STEPS + 1) {
             set_error("scal_map_collect: internal error (recovery does not converge)");
